@@ -1,0 +1,274 @@
+/*
+ * oracle/orc_beamformer.c -- TEST INFRASTRUCTURE (see orc.h).
+ * CPU restatement of the subband beamformers:
+ *   btk/beamformer/beamformer.cc:531-594   beamformerWeights::calcMainlobe
+ *   btk/src/superdirectiveBeamformer.cc:118-137 calcDelaysPolar2
+ *   btk/beamformer/beamformer.cc:2486-2553 SubbandMVDR::setDiffuseNoiseModel
+ *   btk/beamformer/beamformer.h:362-378    divide(All)NonDiagonalElements
+ *   btk/beamformer/beamformer.cc:2555-2581 set(All)Level(s)OfDiagonalLoading
+ *   btk/beamformer/beamformer.cc:253-305   pseudoinverse (complex<float> SVD)
+ *   btk/beamformer/beamformer.cc:2392-2446 SubbandMVDR::calcMVDRWeights
+ *   btk/beamformer/beamformer.cc:61-90,1137-1200,2583-2635 SnapShotArray + DS/MVDR next()
+ *   btk/beamformer/beamformer.cc:398-479   _calcBlockingMatrix
+ *   btk/beamformer/beamformer.cc:1251-1287,1297-1363 calcOutputOfGSC / SubbandGSC::next
+ * The reference's SVD is LINPACK csvdc (in-tree third party, btk/matrix/linpack_c.cc:9518);
+ * here the SVD is restated as a one-sided Jacobi iteration in complex<float>, and the
+ * resulting pseudo-inverse is pinned against csvdc built from the reference sources
+ * (oracle/_ref/, tests/test_oracle_linpack.py).
+ */
+#include "orc.h"
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#include <complex.h>
+
+typedef double complex zc;
+typedef float complex cc;
+
+#define SOUNDSPEED 343740.0   /* superdirectiveBeamformer.cc, mm/s */
+
+static inline zc ZGET(const double* p, size_t i) { return p[2*i] + I * p[2*i+1]; }
+static inline void ZSET(double* p, size_t i, zc v) { p[2*i] = creal(v); p[2*i+1] = cimag(v); }
+
+void orc_calc_mainlobe(double fs, const double* delays, int C, int M, double* wq)
+{
+  /* halfBandShift == false branch, beamformer.cc:557-581 */
+  const int M2 = M / 2;
+  for (int c = 0; c < C; c++) ZSET(wq, (size_t) 0 * C + c, (cos(0.0) + I * sin(0.0)) / (double) C);
+  for (int f = 1; f < M2; f++)
+    for (int c = 0; c < C; c++) {
+      double val = -2.0 * M_PI * f * delays[c] * fs / M;
+      ZSET(wq, (size_t) f * C + c, (cos(val) + I * sin(val)) / (double) C);
+      ZSET(wq, (size_t) (M - f) * C + c, (cos(-val) + I * sin(-val)) / (double) C);
+    }
+  for (int c = 0; c < C; c++) {
+    double val = -M_PI * fs * delays[c];
+    ZSET(wq, (size_t) M2 * C + c, (cos(val) + I * sin(val)) / (double) C);
+  }
+}
+
+void orc_calc_delays_polar2(float azimuth, float elevation, const double* micpos, int C,
+                            double* delays)
+{
+  /* all arithmetic in float as in the driver (superdirectiveBeamformer.cc:125-134) */
+  /* C++ overloads sin(float)/cos(float) -> float versions */
+  float c_x = - sinf(elevation) * cosf(azimuth);
+  float c_y = - sinf(elevation) * sinf(azimuth);
+  float c_z = - cosf(elevation);
+  for (int i = 0; i < C; i++) {
+    float x = micpos[3*i], y = micpos[3*i+1], z = micpos[3*i+2];
+    float t = (c_x * x + c_y * y + c_z * z) / SOUNDSPEED;
+    delays[i] = t;
+  }
+}
+
+static double gsl_sinc(double x)   /* gsl_sf_sinc: sin(pi x)/(pi x) */
+{
+  double ax = fabs(x);
+  if (ax < 1e-300) return 1.0;
+  return sin(M_PI * x) / (M_PI * x);
+}
+
+void orc_diffuse_noise_model(const double* micpos, int C, int M, double fs, double sspeed, double* R)
+{
+  double* dm = (double*) calloc((size_t) C * C, sizeof(double));
+  for (int m = 0; m < C; m++)
+    for (int n = 0; n < m; n++) {
+      double dx = micpos[3*m] - micpos[3*n], dy = micpos[3*m+1] - micpos[3*n+1], dz = micpos[3*m+2] - micpos[3*n+2];
+      dm[m*C+n] = sqrt(dx*dx + dy*dy + dz*dz);
+    }
+  for (int f = 0; f <= M / 2; f++) {
+    double omega_d_c = 2.0 * fs * f / (M * sspeed);
+    double* Rf = R + (size_t) f * C * C * 2;
+    for (int m = 0; m < C; m++)
+      for (int n = 0; n < m; n++) ZSET(Rf, (size_t) m*C+n, gsl_sinc(omega_d_c * dm[m*C+n]));
+    for (int m = 0; m < C; m++) ZSET(Rf, (size_t) m*C+m, 1.0);
+    for (int m = 0; m < C; m++)
+      for (int n = m + 1; n < C; n++) ZSET(Rf, (size_t) m*C+n, ZGET(Rf, (size_t) n*C+m));
+  }
+  free(dm);
+}
+
+void orc_divide_nondiag(double* R, int C, int M, float mu)
+{
+  for (int f = 0; f <= M / 2; f++) {
+    double* Rf = R + (size_t) f * C * C * 2;
+    for (int x = 0; x < C; x++)
+      for (int y = 0; y < C; y++)
+        if (x != y) ZSET(Rf, (size_t) x*C+y, ZGET(Rf, (size_t) x*C+y) / ((1.0 + mu) + 0.0 * I));
+  }
+}
+
+void orc_diagonal_loading(double* R, int C, int M, float w)
+{
+  for (int f = 0; f <= M / 2; f++) {
+    double* Rf = R + (size_t) f * C * C * 2;
+    for (int c = 0; c < C; c++) Rf[2*((size_t)c*C+c)] += (double) w;
+  }
+}
+
+/* One-sided (Hestenes) Jacobi SVD in complex<float>: A (n x n, column major a[i+j*n])
+   -> U diag(s) V^H.  Works on the columns of A; V accumulates the rotations. */
+static void csvd_jacobi(cc* a, int n, float* s, cc* u, cc* v)
+{
+  for (int i = 0; i < n; i++) for (int j = 0; j < n; j++) v[i + j*n] = (i == j) ? 1.0f : 0.0f;
+  for (int sweep = 0; sweep < 60; sweep++) {
+    float off = 0.0f;
+    for (int p = 0; p < n - 1; p++)
+      for (int q = p + 1; q < n; q++) {
+        float app = 0.0f, aqq = 0.0f; cc apq = 0.0f;
+        for (int i = 0; i < n; i++) {
+          app += crealf(a[i+p*n] * conjf(a[i+p*n]));
+          aqq += crealf(a[i+q*n] * conjf(a[i+q*n]));
+          apq += conjf(a[i+p*n]) * a[i+q*n];
+        }
+        float mag = cabsf(apq);
+        if (mag <= 1e-30f || mag <= 1e-7f * sqrtf(app * aqq)) continue;
+        off = fmaxf(off, mag / sqrtf(app * aqq + 1e-38f));
+        cc ph = apq / mag;                         /* unit phase */
+        float tau = (aqq - app) / (2.0f * mag);
+        float t = (tau >= 0.0f ? 1.0f : -1.0f) / (fabsf(tau) + sqrtf(1.0f + tau * tau));
+        float c = 1.0f / sqrtf(1.0f + t * t), sn = c * t;
+        for (int i = 0; i < n; i++) {
+          cc x = a[i+p*n], y = a[i+q*n];
+          a[i+p*n] = c * x - sn * conjf(ph) * y;
+          a[i+q*n] = sn * ph * x + c * y;
+          cc vx = v[i+p*n], vy = v[i+q*n];
+          v[i+p*n] = c * vx - sn * conjf(ph) * vy;
+          v[i+q*n] = sn * ph * vx + c * vy;
+        }
+      }
+    if (off < 1e-7f) break;
+  }
+  for (int j = 0; j < n; j++) {
+    float nr = 0.0f;
+    for (int i = 0; i < n; i++) nr += crealf(a[i+j*n] * conjf(a[i+j*n]));
+    nr = sqrtf(nr); s[j] = nr;
+    for (int i = 0; i < n; i++) u[i+j*n] = (nr > 0.0f) ? a[i+j*n] / nr : 0.0f;
+  }
+}
+
+int orc_pseudoinverse(const double* A, int n, double* invA, float thr)
+{
+  /* beamformer.cc:253-305: everything in complex<float>; singular values below the
+     threshold are zeroed and flag failure (the caller then substitutes identity). */
+  cc* a = (cc*) malloc(sizeof(cc) * n * n); cc* u = (cc*) malloc(sizeof(cc) * n * n);
+  cc* v = (cc*) malloc(sizeof(cc) * n * n); float* s = (float*) malloc(sizeof(float) * n);
+  cc* sinv = (cc*) malloc(sizeof(cc) * n);
+  int ret = 1;
+  for (int i = 0; i < n; i++) for (int j = 0; j < n; j++)
+    a[i + j*n] = (float) A[2*((size_t)i*n+j)] + I * (float) A[2*((size_t)i*n+j)+1];
+  csvd_jacobi(a, n, s, u, v);
+  for (int k = 0; k < n; k++) {
+    if (fabsf(s[k]) < thr) { sinv[k] = 0.0f; ret = 0; }
+    else sinv[k] = 1.0f / s[k];
+  }
+  for (int i = 0; i < n; i++)
+    for (int j = 0; j < n; j++) {
+      cc x = 0.0f;
+      for (int k = 0; k < n; k++) x = x + v[j+k*n] * sinv[k] * conjf(u[i+k*n]);
+      invA[2*((size_t)j*n+i)] = crealf(x); invA[2*((size_t)j*n+i)+1] = cimagf(x);
+    }
+  free(a); free(u); free(v); free(s); free(sinv);
+  return ret;
+}
+
+void orc_mvdr_weights(const double* wq, const double* R, int C, int M, double thr, double* w)
+{
+  /* beamformer.cc:2392-2446 */
+  double* invR = (double*) malloc(sizeof(double) * 2 * C * C);
+  zc* tmpH = (zc*) malloc(sizeof(zc) * C);
+  for (int c = 0; c < C; c++) ZSET(w, c, 1.0);            /* DC bin: all ones (:2413-2415) */
+  for (int f = 1; f <= M / 2; f++) {
+    const double* d = wq + (size_t) f * C * 2;
+    int ok = orc_pseudoinverse(R + (size_t) f * C * C * 2, C, invR, (float) thr);
+    if (!ok) {                                              /* :2425-2427 */
+      memset(invR, 0, sizeof(double) * 2 * C * C);
+      for (int c = 0; c < C; c++) invR[2*((size_t)c*C+c)] = 1.0;
+    }
+    for (int i = 0; i < C; i++) {                           /* tmpH = invR^H d (:2430) */
+      zc acc = 0.0;
+      for (int j = 0; j < C; j++) acc += conj(ZGET(invR, (size_t) j*C+i)) * ZGET(d, j);
+      tmpH[i] = acc;
+    }
+    zc Lambda = 0.0;                                        /* zdotc(tmpH, d) (:2431) */
+    for (int i = 0; i < C; i++) Lambda += conj(tmpH[i]) * ZGET(d, i);
+    zc norm = Lambda * (double) C;
+    for (int c = 0; c < C; c++) ZSET(w, (size_t) f * C + c, tmpH[c] / norm);
+  }
+  free(invR); free(tmpH);
+}
+
+void orc_beamform_apply(const double* X, const double* W, int C, int T, int M, double* Y)
+{
+  /* Y[f] = w_f^H X[f] for f=0..M/2; Y[M-f] = conj(Y[f]) (beamformer.cc:2609-2631) */
+  for (int t = 0; t < T; t++) {
+    double* y = Y + (size_t) t * M * 2;
+    for (int f = 0; f <= M / 2; f++) {
+      zc val = 0.0;
+      for (int c = 0; c < C; c++)
+        val += conj(ZGET(W, (size_t) f*C+c)) * ZGET(X, ((size_t) c * T + t) * M + f);
+      ZSET(y, f, val);
+      if (f > 0 && f < M / 2) ZSET(y, M - f, conj(val));
+    }
+  }
+}
+
+int orc_blocking_matrix(const double* d, int C, double* B)
+{
+  /* NC = 1, beamformer.cc:398-479 */
+  const int bsize = C - 1;
+  if (bsize <= 0) return 0;
+  zc* P = (zc*) malloc(sizeof(zc) * C * C);
+  zc* vec = (zc*) malloc(sizeof(zc) * C);
+  double nrm = 0.0;
+  for (int i = 0; i < C; i++) nrm += creal(ZGET(d, i) * conj(ZGET(d, i)));
+  nrm = sqrt(nrm); nrm = nrm * nrm;
+  for (int i = 0; i < C; i++)
+    for (int j = 0; j < C; j++)
+      P[i*C+j] = ((i == j) ? 1.0 : 0.0) + (-1.0 / nrm) * conj(ZGET(d, i)) * ZGET(d, j);
+  memset(B, 0, sizeof(double) * 2 * C * bsize);
+  for (int idim = 0; idim < bsize; idim++) {
+    for (int i = 0; i < C; i++) vec[i] = P[i*C+idim];
+    for (int jdim = 0; jdim < idim; jdim++) {
+      zc ip = 0.0;
+      for (int i = 0; i < C; i++) ip += conj(ZGET(B, (size_t) i*bsize+jdim)) * vec[i];
+      ip = -ip;
+      for (int i = 0; i < C; i++) vec[i] += ip * ZGET(B, (size_t) i*bsize+jdim);
+    }
+    double nv = 0.0;
+    for (int i = 0; i < C; i++) nv += creal(vec[i] * conj(vec[i]));
+    nv = sqrt(nv);
+    for (int i = 0; i < C; i++) ZSET(B, (size_t) i*bsize+idim, vec[i] * (1.0 / nv));
+  }
+  free(P); free(vec);
+  return 1;
+}
+
+void orc_gsc_apply(const double* X, const double* wq, const double* B, const double* wa,
+                   int C, int T, int M, int normalize, double* Y)
+{
+  /* per bin effective weight w = wq - B wa (optionally / (||w|| C)); bin 0 uses wq only
+     (beamformer.cc:1335-1342).  B: [M/2+1][C][C-1], wa: [M/2+1][C-1] */
+  const int bs = C - 1;
+  double* W = (double*) malloc(sizeof(double) * 2 * (size_t)(M/2+1) * C);
+  for (int c = 0; c < C; c++) ZSET(W, c, ZGET(wq, c));
+  for (int f = 1; f <= M / 2; f++) {
+    const double* Bf = B + (size_t) f * C * bs * 2;
+    const double* waf = wa + (size_t) f * bs * 2;
+    double nrm = 0.0;
+    for (int i = 0; i < C; i++) {
+      zc wl = 0.0;
+      for (int j = 0; j < bs; j++) wl += ZGET(Bf, (size_t) i*bs+j) * ZGET(waf, j);
+      zc w = ZGET(wq, (size_t) f*C+i) - wl;
+      ZSET(W, (size_t) f*C+i, w);
+      nrm += creal(w * conj(w));
+    }
+    if (normalize) {
+      nrm = sqrt(nrm);
+      for (int i = 0; i < C; i++) ZSET(W, (size_t) f*C+i, ZGET(W, (size_t) f*C+i) / (nrm * C));
+    }
+  }
+  orc_beamform_apply(X, W, C, T, M, Y);
+  free(W);
+}
