@@ -1,0 +1,65 @@
+// csrc/common.h -- shared helpers of libdsr_hip.so (error convention, HIP checks, device buffers).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+#include <stdexcept>
+#include "../../include/dsr.h"
+
+namespace dsr {
+
+// Mirrors j_error + error_type (btk/common/jexception.h:41-70): thrown inside the library,
+// translated to a dsr_status at the C-ABI.
+struct Error : std::exception {
+  int code; std::string msg;
+  Error(int c, const char* fmt, ...) : code(c) {
+    char buf[1024]; va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof buf, fmt, ap); va_end(ap); msg = buf;
+  }
+  const char* what() const noexcept override { return msg.c_str(); }
+};
+
+void set_last_error(const std::string& s);
+
+#define DSR_HIP(expr) do { hipError_t e__ = (expr); if (e__ != hipSuccess) \
+  throw dsr::Error(DSR_E_INITIALIZATION, "HIP error %s at %s:%d (%s)", hipGetErrorString(e__), __FILE__, __LINE__, #expr); } while (0)
+
+// C-ABI guard: run body, map exceptions to status codes.
+template <class F> static inline dsr_status guard(F&& f) {
+  try { f(); return DSR_OK; }
+  catch (const Error& e) { set_last_error(e.msg); return e.code; }
+  catch (const std::bad_alloc&) { set_last_error("out of host memory"); return DSR_E_ALLOCATION; }
+  catch (const std::exception& e) { set_last_error(e.what()); return DSR_E_ERROR; }
+}
+
+void require_device();   // throws DSR_E_INITIALIZATION when no HIP device is usable
+
+// Owning device buffer (grows, never shrinks).
+template <class T> struct DevBuf {
+  T* p = nullptr; size_t n = 0;
+  DevBuf() = default; DevBuf(const DevBuf&) = delete; DevBuf& operator=(const DevBuf&) = delete;
+  ~DevBuf() { if (p) (void) hipFree(p); }
+  void reserve(size_t m) {
+    if (m <= n) return;
+    if (p) { DSR_HIP(hipFree(p)); p = nullptr; n = 0; }
+    hipError_t e = hipMalloc((void**) &p, m * sizeof(T));
+    if (e != hipSuccess) { p = nullptr; throw Error(DSR_E_ALLOCATION, "hipMalloc of %zu bytes failed: %s", m * sizeof(T), hipGetErrorString(e)); }
+    n = m;
+  }
+  void upload(const T* h, size_t m, hipStream_t s = nullptr) {
+    reserve(m);
+    if (m) DSR_HIP(hipMemcpyAsync(p, h, m * sizeof(T), hipMemcpyHostToDevice, s));
+    if (m) DSR_HIP(hipStreamSynchronize(s));
+  }
+  void upload(const std::vector<T>& v) { upload(v.data(), v.size()); }
+};
+
+static inline int ilog2(unsigned v) { int l = 0; while ((1u << l) < v) l++; return l; }
+static inline bool is_pow2(unsigned v) { return v && !(v & (v - 1)); }
+static inline int cdiv(long a, long b) { return (int) ((a + b - 1) / b); }
+
+}  // namespace dsr

@@ -1,0 +1,365 @@
+// csrc/k_beamform.hip -- subband beamformers: host-side weight design + the per-bin apply kernel.
+//
+// Weight design is set-up work exactly as in the reference (done once per array geometry):
+//   beamformerWeights::calcMainlobe              btk/beamformer/beamformer.cc:531-594
+//   SubbandMVDR::setDiffuseNoiseModel            :2486-2553      divideNonDiagonalElements  beamformer.h:362-378
+//   SubbandMVDR::setAllLevelsOfDiagonalLoading   :2555-2567      setNoiseSpatialSpectralMatrix :2454-2477
+//   pseudoinverse (complex<float> SVD)           :253-305        calcMVDRWeights :2392-2446
+//   _calcBlockingMatrix                          :398-479        calcSidelobeCancellerP_f :761-783
+// The hot loop -- SnapShotArray::update + one zdotc per bin per frame (:76-90, :2609-2631) -- is
+// k_bf_apply: one thread per (frame, bin), channel spectra read coalesced along the bin axis from the
+// [chan][frame][bin] layout the analysis kernel writes, weights staged in LDS.
+#include "common.h"
+#include <complex>
+#include <cmath>
+
+namespace dsr {
+
+typedef std::complex<double> zc;
+typedef std::complex<float> cf;
+
+struct BfState {
+  int M = 0, C = 0, halfBandShift = 0, mode = 0;
+  std::vector<zc> wq;      // [M][C]
+  std::vector<zc> R;       // [M/2+1][C][C]
+  bool haveR = false, haveWq = false, haveMvdr = false, haveB = false;
+  std::vector<zc> mvdr;    // [M/2+1][C]
+  std::vector<zc> B;       // [M][C][C-1]
+  std::vector<zc> wa;      // [M][C-1]
+  std::vector<zc> eff;     // [M/2+1][C] weights in use
+  DevBuf<float2> d_w;      // [M/2+1][C]
+  bool dirty = true;
+};
+
+// Hestenes one-sided Jacobi SVD, complex<float>, square n x n, column-major a(i,j)=a[i+j*n].
+// On return: columns of a are u_j*s_j, v holds the right singular vectors.
+static void jacobi_svd_cf(std::vector<cf>& a, std::vector<cf>& v, int n)
+{
+  v.assign((size_t) n * n, cf(0.f, 0.f));
+  for (int i = 0; i < n; i++) v[i + (size_t) i * n] = cf(1.f, 0.f);
+  for (int sweep = 0; sweep < 64; sweep++) {
+    bool rotated = false;
+    for (int p = 0; p + 1 < n; p++)
+      for (int q = p + 1; q < n; q++) {
+        float alpha = 0.f, beta = 0.f; cf gamma(0.f, 0.f);
+        for (int i = 0; i < n; i++) {
+          const cf x = a[i + (size_t) p * n], y = a[i + (size_t) q * n];
+          alpha += std::norm(x); beta += std::norm(y); gamma += std::conj(x) * y;
+        }
+        const float g = std::abs(gamma);
+        if (g == 0.f || g <= 1e-7f * std::sqrt(alpha * beta)) continue;
+        rotated = true;
+        const cf phase = gamma / g;
+        const float zeta = (beta - alpha) / (2.f * g);
+        const float t = (zeta >= 0.f ? 1.f : -1.f) / (std::fabs(zeta) + std::sqrt(1.f + zeta * zeta));
+        const float cs = 1.f / std::sqrt(1.f + t * t), sn = cs * t;
+        const cf e1 = sn * std::conj(phase), e2 = sn * phase;
+        for (int i = 0; i < n; i++) {
+          cf& x = a[i + (size_t) p * n]; cf& y = a[i + (size_t) q * n];
+          const cf nx = cs * x - e1 * y, ny = e2 * x + cs * y; x = nx; y = ny;
+          cf& vx = v[i + (size_t) p * n]; cf& vy = v[i + (size_t) q * n];
+          const cf nvx = cs * vx - e1 * vy, nvy = e2 * vx + cs * vy; vx = nvx; vy = nvy;
+        }
+      }
+    if (!rotated) break;
+  }
+}
+
+// beamformer.cc:253-305.  A, invA row-major n x n.  Returns false when a singular value fell
+// below the threshold (the caller then uses identity, :2425-2427).
+static bool pseudoinverse_cf(const zc* A, zc* invA, int n, float thr)
+{
+  std::vector<cf> a((size_t) n * n), v;
+  for (int i = 0; i < n; i++) for (int j = 0; j < n; j++) a[i + (size_t) j * n] = cf((float) A[(size_t) i * n + j].real(), (float) A[(size_t) i * n + j].imag());
+  jacobi_svd_cf(a, v, n);
+  std::vector<float> sinv(n); bool ok = true;
+  std::vector<cf> u((size_t) n * n);
+  for (int j = 0; j < n; j++) {
+    float s = 0.f; for (int i = 0; i < n; i++) s += std::norm(a[i + (size_t) j * n]);
+    s = std::sqrt(s);
+    for (int i = 0; i < n; i++) u[i + (size_t) j * n] = s > 0.f ? a[i + (size_t) j * n] / s : cf(0.f, 0.f);
+    if (std::fabs(s) < thr) { sinv[j] = 0.f; ok = false; } else sinv[j] = 1.f / s;
+  }
+  for (int i = 0; i < n; i++)
+    for (int j = 0; j < n; j++) {
+      cf x(0.f, 0.f);
+      for (int k = 0; k < n; k++) x = x + v[j + (size_t) k * n] * sinv[k] * std::conj(u[i + (size_t) k * n]);
+      invA[(size_t) j * n + i] = zc(x.real(), x.imag());
+    }
+  return ok;
+}
+
+static double sinc_pi(double x) { return std::fabs(x) < 1e-300 ? 1.0 : std::sin(M_PI * x) / (M_PI * x); }   // gsl_sf_sinc
+
+static void calc_mainlobe(BfState& s, double fs, const double* delays)
+{
+  const int M = s.M, C = s.C, M2 = M / 2;
+  s.wq.assign((size_t) M * C, zc(0, 0));
+  if (s.halfBandShift) {                                   // beamformer.cc:544-555
+    const float fshift = 0.5f;
+    for (int f = 0; f < M2; f++)
+      for (int c = 0; c < C; c++) {
+        const double val = -2.0 * M_PI * (fshift + f) * fs * delays[c] / M;
+        s.wq[(size_t) f * C + c] = std::polar(1.0, val) / (double) C;
+        s.wq[(size_t) (M - 1 - f) * C + c] = std::polar(1.0, -val) / (double) C;
+      }
+  } else {                                                  // :557-581
+    for (int c = 0; c < C; c++) s.wq[c] = std::polar(1.0, 0.0) / (double) C;
+    for (int f = 1; f < M2; f++)
+      for (int c = 0; c < C; c++) {
+        const double val = -2.0 * M_PI * f * delays[c] * fs / M;
+        s.wq[(size_t) f * C + c] = std::polar(1.0, val) / (double) C;
+        s.wq[(size_t) (M - f) * C + c] = std::polar(1.0, -val) / (double) C;
+      }
+    for (int c = 0; c < C; c++) { const double val = -M_PI * fs * delays[c]; s.wq[(size_t) M2 * C + c] = std::polar(1.0, val) / (double) C; }
+  }
+  s.haveWq = true; s.dirty = true;
+}
+
+static void blocking_matrix(const zc* d, int C, zc* B)       // NC = 1, beamformer.cc:398-479
+{
+  const int bs = C - 1;
+  std::vector<zc> P((size_t) C * C), vec(C);
+  double nrm = 0; for (int i = 0; i < C; i++) nrm += std::norm(d[i]);
+  nrm = std::sqrt(nrm); nrm = nrm * nrm;
+  for (int i = 0; i < C; i++) for (int j = 0; j < C; j++) P[(size_t) i * C + j] = (i == j ? 1.0 : 0.0) + (-1.0 / nrm) * std::conj(d[i]) * d[j];
+  for (int k = 0; k < C * bs; k++) B[k] = zc(0, 0);
+  for (int id = 0; id < bs; id++) {
+    for (int i = 0; i < C; i++) vec[i] = P[(size_t) i * C + id];
+    for (int jd = 0; jd < id; jd++) {
+      zc ip(0, 0); for (int i = 0; i < C; i++) ip += std::conj(B[(size_t) i * bs + jd]) * vec[i];
+      ip = -ip; for (int i = 0; i < C; i++) vec[i] += ip * B[(size_t) i * bs + jd];
+    }
+    double nv = 0; for (int i = 0; i < C; i++) nv += std::norm(vec[i]); nv = std::sqrt(nv);
+    for (int i = 0; i < C; i++) B[(size_t) i * bs + id] = vec[i] * (1.0 / nv);
+  }
+}
+
+static void refresh_effective(BfState& s)
+{
+  const int M = s.M, C = s.C, F = M / 2 + 1;
+  if (s.halfBandShift) throw Error(DSR_E_PARAMETER, "halfBandShift==true apply is not supported on the device path");
+  s.eff.assign((size_t) F * C, zc(0, 0));
+  if (s.mode == 0) {
+    if (!s.haveWq) throw Error(DSR_E_ERROR, "call calcArrayManifoldVectorsX() once");          // beamformer.cc:1140-1143
+    for (int f = 0; f < F; f++) for (int c = 0; c < C; c++) s.eff[(size_t) f * C + c] = s.wq[(size_t) f * C + c];
+  } else if (s.mode == 1) {
+    if (!s.haveMvdr) throw Error(DSR_E_ERROR, "call calcMVDRWeights() once");                    // :2591-2594
+    s.eff = s.mvdr;
+  } else {
+    if (!s.haveWq || !s.haveB) throw Error(DSR_E_ERROR, "call calcGSCWeightsX() once");          // :1310-1313
+    const int bs = C - 1;
+    for (int c = 0; c < C; c++) s.eff[c] = s.wq[c];                                              // bin 0: wq only (:1335-1338)
+    for (int f = 1; f < F; f++) {
+      double nrm = 0;
+      for (int i = 0; i < C; i++) {
+        zc wl(0, 0); for (int j = 0; j < bs; j++) wl += s.B[((size_t) f * C + i) * bs + j] * s.wa[(size_t) f * bs + j];
+        const zc w = s.wq[(size_t) f * C + i] - wl; s.eff[(size_t) f * C + i] = w; nrm += std::norm(w);
+      }
+      if (s.mode == 3) { nrm = std::sqrt(nrm); for (int i = 0; i < C; i++) s.eff[(size_t) f * C + i] /= (nrm * C); }   // :1272-1281
+    }
+  }
+  std::vector<float2> w((size_t) F * C);
+  for (size_t i = 0; i < w.size(); i++) w[i] = make_float2((float) s.eff[i].real(), (float) s.eff[i].imag());
+  s.d_w.upload(w);
+  s.dirty = false;
+}
+
+// Y[u][t][f] = sum_c conj(w[f][c]) X[u][c][t][f]
+__global__ __launch_bounds__(256) void k_bf_apply(const float2* __restrict__ X, const float2* __restrict__ W,
+                                                  float2* __restrict__ Y, int C, int Tmax, int F, long perUtt /*Tmax*F*/)
+{
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  float2* w = reinterpret_cast<float2*>(smem);
+  for (int i = threadIdx.x; i < F * C; i += blockDim.x) w[i] = W[i];
+  __syncthreads();
+  const int u = blockIdx.y;
+  const float2* Xu = X + (long) u * C * perUtt;
+  float2* Yu = Y + (long) u * perUtt;
+  for (long idx = (long) blockIdx.x * blockDim.x + threadIdx.x; idx < perUtt; idx += (long) gridDim.x * blockDim.x) {
+    const int f = (int) (idx % F);
+    float2 acc = make_float2(0.f, 0.f);
+    for (int c = 0; c < C; c++) {
+      const float2 x = Xu[(long) c * perUtt + idx];
+      const float2 wc = w[f * C + c];
+      acc.x += wc.x * x.x + wc.y * x.y;       // conj(w) * x
+      acc.y += wc.x * x.y - wc.y * x.x;
+    }
+    Yu[idx] = acc;
+  }
+}
+
+}  // namespace dsr
+
+using namespace dsr;
+struct dsr_bf : BfState {};
+
+extern "C" {
+
+dsr_status dsr_bf_create(int fftLen, int chanN, int halfBandShift, dsr_bf** out)
+{
+  return guard([&] {
+    if (!out) throw Error(DSR_E_PARAMETER, "null argument");
+    if (fftLen < 2 || (fftLen & 1) || chanN < 1) throw Error(DSR_E_DIMENSION, "bad fftLen=%d chanN=%d", fftLen, chanN);
+    dsr_bf* s = new dsr_bf(); s->M = fftLen; s->C = chanN; s->halfBandShift = halfBandShift; *out = s;
+  });
+}
+void dsr_bf_destroy(dsr_bf* s) { delete s; }
+int dsr_bf_fft_len(const dsr_bf* s) { return s->M; }
+int dsr_bf_chan_n(const dsr_bf* s) { return s->C; }
+
+dsr_status dsr_bf_calc_array_manifold(dsr_bf* s, double fs, const double* delays)
+{ return guard([&] { if (!s || !delays) throw Error(DSR_E_PARAMETER, "null argument"); calc_mainlobe(*s, fs, delays); }); }
+
+dsr_status dsr_calc_delays_polar2(float azimuth, float elevation, const double* micPos, int C, double* delays)
+{
+  return guard([&] {
+    if (!micPos || !delays) throw Error(DSR_E_PARAMETER, "null argument");
+    // superdirectiveBeamformer.cc:118-137 -- float arithmetic, float sin/cos overloads, mm/s
+    const float c_x = -sinf(elevation) * cosf(azimuth), c_y = -sinf(elevation) * sinf(azimuth), c_z = -cosf(elevation);
+    for (int i = 0; i < C; i++) {
+      const float x = (float) micPos[3 * i], y = (float) micPos[3 * i + 1], z = (float) micPos[3 * i + 2];
+      const float t = (c_x * x + c_y * y + c_z * z) / 343740.0;
+      delays[i] = t;
+    }
+  });
+}
+
+dsr_status dsr_bf_set_diffuse_noise_model(dsr_bf* s, const double* mp, double fs, double sspeed)
+{
+  return guard([&] {
+    if (!s || !mp) throw Error(DSR_E_PARAMETER, "null argument");
+    const int C = s->C, M = s->M, F = M / 2 + 1;
+    std::vector<double> dm((size_t) C * C, 0.0);
+    for (int m = 0; m < C; m++) for (int n = 0; n < m; n++) {
+      const double dx = mp[3*m] - mp[3*n], dy = mp[3*m+1] - mp[3*n+1], dz = mp[3*m+2] - mp[3*n+2];
+      dm[(size_t) m * C + n] = std::sqrt(dx * dx + dy * dy + dz * dz);
+    }
+    s->R.assign((size_t) F * C * C, zc(0, 0));
+    for (int f = 0; f < F; f++) {
+      const double odc = 2.0 * fs * f / (M * sspeed);
+      zc* Rf = &s->R[(size_t) f * C * C];
+      for (int m = 0; m < C; m++) for (int n = 0; n < m; n++) Rf[(size_t) m * C + n] = zc(sinc_pi(odc * dm[(size_t) m * C + n]), 0.0);
+      for (int m = 0; m < C; m++) Rf[(size_t) m * C + m] = zc(1.0, 0.0);
+      for (int m = 0; m < C; m++) for (int n = m + 1; n < C; n++) Rf[(size_t) m * C + n] = Rf[(size_t) n * C + m];
+    }
+    s->haveR = true;
+  });
+}
+dsr_status dsr_bf_divide_nondiagonal(dsr_bf* s, float myu)
+{
+  return guard([&] {
+    if (!s || !s->haveR) throw Error(DSR_E_ERROR, "Construct first a noise covariance matrix");
+    const int C = s->C, F = s->M / 2 + 1;
+    for (int f = 0; f < F; f++) for (int x = 0; x < C; x++) for (int y = 0; y < C; y++)
+      if (x != y) s->R[((size_t) f * C + x) * C + y] /= zc(1.0 + myu, 0.0);
+  });
+}
+dsr_status dsr_bf_diagonal_loading(dsr_bf* s, float w)
+{
+  return guard([&] {
+    if (!s || !s->haveR) throw Error(DSR_E_ERROR, "Construct first a noise covariance matrix");
+    const int C = s->C, F = s->M / 2 + 1;
+    for (int f = 0; f < F; f++) for (int c = 0; c < C; c++) s->R[((size_t) f * C + c) * C + c] += (double) w;
+  });
+}
+dsr_status dsr_bf_set_noise_matrix(dsr_bf* s, int f, const double* Rnn)
+{
+  return guard([&] {
+    if (!s || !Rnn) throw Error(DSR_E_PARAMETER, "null argument");
+    const int C = s->C, F = s->M / 2 + 1;
+    if (f < 0 || f >= F) throw Error(DSR_E_INDEX, "frequency bin %d out of range", f);
+    if (!s->haveR) { s->R.assign((size_t) F * C * C, zc(0, 0)); s->haveR = true; }
+    for (int i = 0; i < C * C; i++) s->R[(size_t) f * C * C + i] = zc(Rnn[2 * i], Rnn[2 * i + 1]);
+  });
+}
+dsr_status dsr_bf_calc_mvdr_weights(dsr_bf* s, double fs, double thr)
+{
+  (void) fs;
+  return guard([&] {
+    if (!s) throw Error(DSR_E_PARAMETER, "null argument");
+    if (!s->haveR) throw Error(DSR_E_ALLOCATION, "Set a spatial spectral matrix before calling calcMVDRWeights()");
+    if (!s->haveWq) throw Error(DSR_E_ERROR, "call calcArrayManifoldVectorsX() once");
+    const int C = s->C, F = s->M / 2 + 1;
+    s->mvdr.assign((size_t) F * C, zc(0, 0));
+    std::vector<zc> invR((size_t) C * C), tmpH(C);
+    for (int c = 0; c < C; c++) s->mvdr[c] = zc(1.0, 0.0);                          // :2413-2415
+    for (int f = 1; f < F; f++) {
+      const zc* d = &s->wq[(size_t) f * C];
+      if (!pseudoinverse_cf(&s->R[(size_t) f * C * C], invR.data(), C, (float) thr)) {
+        for (int i = 0; i < C * C; i++) invR[i] = zc(0, 0);
+        for (int c = 0; c < C; c++) invR[(size_t) c * C + c] = zc(1, 0);
+      }
+      for (int i = 0; i < C; i++) { zc acc(0, 0); for (int j = 0; j < C; j++) acc += std::conj(invR[(size_t) j * C + i]) * d[j]; tmpH[i] = acc; }
+      zc Lambda(0, 0); for (int i = 0; i < C; i++) Lambda += std::conj(tmpH[i]) * d[i];
+      const zc norm = Lambda * (double) C;
+      for (int c = 0; c < C; c++) s->mvdr[(size_t) f * C + c] = tmpH[c] / norm;
+    }
+    s->haveMvdr = true; s->dirty = true;
+  });
+}
+dsr_status dsr_bf_calc_gsc_weights(dsr_bf* s, double fs, const double* delays)
+{
+  return guard([&] {
+    if (!s || !delays) throw Error(DSR_E_PARAMETER, "null argument");
+    if (s->C <= 1) throw Error(DSR_E_DIMENSION, "The number of channels must be > 1 but it is %d", s->C);
+    calc_mainlobe(*s, fs, delays);
+    const int C = s->C, M = s->M, bs = C - 1;
+    s->B.assign((size_t) M * C * bs, zc(0, 0)); s->wa.assign((size_t) M * bs, zc(0, 0));
+    for (int f = 0; f < M; f++) blocking_matrix(&s->wq[(size_t) f * C], C, &s->B[(size_t) f * C * bs]);
+    s->haveB = true; s->dirty = true;
+  });
+}
+dsr_status dsr_bf_set_active_weights(dsr_bf* s, int f, const double* packed)
+{
+  return guard([&] {
+    if (!s || !packed) throw Error(DSR_E_PARAMETER, "null argument");
+    if (!s->haveB) throw Error(DSR_E_ERROR, "call calcGSCWeightsX() once");
+    if (f < 0 || f >= s->M) throw Error(DSR_E_DIMENSION, "Must be a frequency bin %d < the length of FFT %d", f, s->M);
+    for (int c = 0; c < s->C - 1; c++) s->wa[(size_t) f * (s->C - 1) + c] = zc(packed[2 * c], packed[2 * c + 1]);
+    s->dirty = true;
+  });
+}
+dsr_status dsr_bf_zero_active_weights(dsr_bf* s)
+{
+  return guard([&] {
+    if (!s || !s->haveB) throw Error(DSR_E_ERROR, "call calcGSCWeightsX() once");
+    std::fill(s->wa.begin(), s->wa.end(), zc(0, 0)); s->dirty = true;
+  });
+}
+dsr_status dsr_bf_select(dsr_bf* s, int mode)
+{ return guard([&] { if (!s || mode < 0 || mode > 3) throw Error(DSR_E_PARAMETER, "bad mode"); s->mode = mode; s->dirty = true; }); }
+
+dsr_status dsr_bf_get(const dsr_bf* cs, int kind, double* out, size_t nd)
+{
+  return guard([&] {
+    dsr_bf* s = const_cast<dsr_bf*>(cs);
+    if (!s || !out) throw Error(DSR_E_PARAMETER, "null argument");
+    const std::vector<zc>* v = nullptr;
+    if (kind == 4) { if (s->dirty) { require_device(); refresh_effective(*s); } v = &s->eff; }
+    else v = kind == 0 ? &s->wq : kind == 1 ? &s->mvdr : kind == 2 ? &s->R : kind == 3 ? &s->B : nullptr;
+    if (!v) throw Error(DSR_E_PARAMETER, "bad kind %d", kind);
+    if (nd < 2 * v->size()) throw Error(DSR_E_DIMENSION, "output holds %zu doubles, need %zu", nd, 2 * v->size());
+    for (size_t i = 0; i < v->size(); i++) { out[2 * i] = (*v)[i].real(); out[2 * i + 1] = (*v)[i].imag(); }
+  });
+}
+
+dsr_status dsr_bf_apply(dsr_bf* s, const float* X, int U, int Tmax, float* Y, void* stream)
+{
+  return guard([&] {
+    if (!s || !X || !Y) throw Error(DSR_E_PARAMETER, "null argument");
+    require_device();
+    if (s->dirty) refresh_effective(*s);
+    if (U <= 0 || Tmax <= 0) return;
+    const int F = s->M / 2 + 1; const long perUtt = (long) Tmax * F;
+    const size_t lds = sizeof(float2) * (size_t) F * s->C;
+    if (lds > 160 * 1024) throw Error(DSR_E_DIMENSION, "beamformer weights need %zu bytes of LDS", lds);
+    DSR_HIP(hipFuncSetAttribute((const void*) k_bf_apply, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
+    int gx = cdiv(perUtt, 256 * 4); if (gx < 1) gx = 1; if (gx > 4096) gx = 4096;
+    hipLaunchKernelGGL(k_bf_apply, dim3(gx, U), dim3(256), lds, (hipStream_t) stream, (const float2*) X, s->d_w.p, (float2*) Y,
+                       s->C, Tmax, F, perUtt);
+    DSR_HIP(hipGetLastError());
+  });
+}
+
+}  // extern "C"

@@ -1,0 +1,337 @@
+// csrc/k_filterbank.hip -- oversampled uniform DFT analysis / synthesis banks on gfx950.
+//
+// Replaces OverSampledDFTAnalysisBank::next (btk/modulated/modulated.cc:412-452, buffers
+// :400-410,461-516) and OverSampledDFTSynthesisBank::next (:586-664).  The reference keeps
+// two ring buffers per operator and rebuilds an M-vector per frame; here a workgroup owns a
+// tile of frames of one (utterance, channel): the sample window of the tile is staged once in
+// LDS (coalesced HBM read), the polyphase sums are 4 LDS reads per output, and the length-M
+// real DFT runs as a length-M/2 complex Stockham radix-4 FFT in LDS followed by the
+// even/odd split.  Only bins 0..M/2 exist in HBM (the input is real).
+//
+// Closed forms used (checked against the oracle):
+//   analysis : u_t[k] = sum_q h[k+qM] x[n_t-k-qM],  n_t = (t+laN+1)D-1,   X_t[f] = sum_k u_t[k] e^{+2 pi j fk/M}
+//   synthesis: v_tau[k] = Re sum_f Y_tau[f] e^{-2 pi j fk/M} (Hermitian extension, DC/Nyquist imaginary parts dropped)
+//              out_t[D-1-d] = sum_{i<R, t-R+1+i>=0} sum_q g[(M-1-k)+qM] v_{t-R+1+i+pd-Rq}[k],  k = d+iD
+#include "common.h"
+#include <cmath>
+
+namespace dsr {
+
+struct FbPlan {
+  int M, m, r, R, D, synthesis, dctype, gain, pd, laN;
+  std::vector<double> proto;
+  DevBuf<float> d_proto;     // [m*M] taps as fp32
+  DevBuf<float2> d_tw;       // tw[k] = e^{+2 pi j k / M}
+};
+
+// ---------------------------------------------------------------------------------------------
+// Stockham autosort FFT of `nfft` independent length-N sequences living in LDS (sequence f at
+// x + f*N).  tw[k*twStep] = e^{+2 pi j k / N}.  sign=+1: e^{+...} (gsl backward), -1: forward.
+// Cooperative: all `nthr` threads of the workgroup call it; returns the buffer holding the result.
+template <int N>
+__device__ __forceinline__ float2* fft_lds(float2* x, float2* y, const float2* tw, int twStep, int nfft,
+                                            int sign, int tid, int nthr)
+{
+  int n = N, s = 1;
+  const float sj = (float) sign;
+  while (n >= 4) {
+    const int m4 = n >> 2;           // sub-sequence quarter length
+    const int twn = (N / n) * twStep;
+    for (int idx = tid; idx < nfft * (N / 4); idx += nthr) {
+      const int f = idx / (N / 4), j = idx - f * (N / 4);
+      const int p = j / s, q = j - p * s;
+      const float2* xi = x + f * N; float2* yo = y + f * N;
+      const float2 a = xi[q + s * p], b = xi[q + s * (p + m4)], c = xi[q + s * (p + 2 * m4)], d = xi[q + s * (p + 3 * m4)];
+      const float2 apc = make_float2(a.x + c.x, a.y + c.y), amc = make_float2(a.x - c.x, a.y - c.y);
+      const float2 bpd = make_float2(b.x + d.x, b.y + d.y), bmd = make_float2(b.x - d.x, b.y - d.y);
+      // sign*j*(b-d)
+      const float2 jb = make_float2(-sj * bmd.y, sj * bmd.x);
+      float2 w1 = tw[p * twn], w2 = tw[2 * p * twn], w3 = tw[3 * p * twn];
+      w1.y *= sj; w2.y *= sj; w3.y *= sj;
+      const float2 r0 = make_float2(apc.x + bpd.x, apc.y + bpd.y);
+      const float2 t1 = make_float2(amc.x + jb.x, amc.y + jb.y);
+      const float2 t2 = make_float2(apc.x - bpd.x, apc.y - bpd.y);
+      const float2 t3 = make_float2(amc.x - jb.x, amc.y - jb.y);
+      yo[q + s * (4 * p + 0)] = r0;
+      yo[q + s * (4 * p + 1)] = make_float2(t1.x * w1.x - t1.y * w1.y, t1.x * w1.y + t1.y * w1.x);
+      yo[q + s * (4 * p + 2)] = make_float2(t2.x * w2.x - t2.y * w2.y, t2.x * w2.y + t2.y * w2.x);
+      yo[q + s * (4 * p + 3)] = make_float2(t3.x * w3.x - t3.y * w3.y, t3.x * w3.y + t3.y * w3.x);
+    }
+    __syncthreads();
+    float2* t = x; x = y; y = t;
+    n >>= 2; s <<= 2;
+  }
+  if (n == 2) {
+    for (int idx = tid; idx < nfft * (N / 2); idx += nthr) {
+      const int f = idx / (N / 2), q = idx - f * (N / 2);
+      const float2 a = x[f * N + q], b = x[f * N + q + s];
+      y[f * N + q] = make_float2(a.x + b.x, a.y + b.y);
+      y[f * N + q + s] = make_float2(a.x - b.x, a.y - b.y);
+    }
+    __syncthreads();
+    float2* t = x; x = y; y = t;
+  }
+  return x;
+}
+
+// LDS layout (dynamic): [tw: M float2][proto: m*M float][win: winLen float][bufA: FB*M float][bufB: FB*M float]
+template <int M>
+__global__ __launch_bounds__(256) void k_analysis(const float* __restrict__ x, const int* __restrict__ nsampArr,
+                                                  const float* __restrict__ proto, const float2* __restrict__ twG,
+                                                  float2* __restrict__ X, int C, long sampStride, int Tmax,
+                                                  int m, int r, int pd, int laN, int gain, int TF, int FB)
+{
+  constexpr int N = M / 2;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int D = M >> r;
+  const int winLen = (TF - 1) * D + m * M;
+  float2* tw = reinterpret_cast<float2*>(smem);
+  float* h = reinterpret_cast<float*>(tw + M);
+  float* win = h + m * M;
+  float* bufA = win + ((winLen + 3) & ~3);
+  float* bufB = bufA + FB * M;
+  const int tid = threadIdx.x, nthr = blockDim.x;
+  const int tile = blockIdx.x, c = blockIdx.y, u = blockIdx.z;
+  const int t0 = tile * TF;
+  const int nsamp = nsampArr[u];
+  const int nblk = (nsamp + D - 1) / D;
+  const int Tu = (nblk < laN) ? 0 : (nblk - laN + pd);
+  const float* xs = x + ((long) u * C + c) * sampStride;
+  float2* Xo = X + ((long) u * C + c) * (long) Tmax * (N + 1);
+
+  for (int i = tid; i < M; i += nthr) tw[i] = twG[i];
+  for (int i = tid; i < m * M; i += nthr) h[i] = proto[i];
+  const long lo = (long) (t0 + laN + 1) * D - (long) m * M;
+  for (int i = tid; i < winLen; i += nthr) {
+    const long n = lo + i;
+    win[i] = (n >= 0 && n < nsamp) ? xs[n] : 0.0f;
+  }
+  __syncthreads();
+
+  for (int fb0 = 0; fb0 < TF; fb0 += FB) {
+    // polyphase sums -> bufA[(frame)*M + k]  (== z[n] = u[2n] + j u[2n+1] when read as float2)
+    for (int idx = tid; idx < FB * M; idx += nthr) {
+      const int fr = idx / M, k = idx - fr * M;
+      const int base = (fb0 + fr) * D + m * M - 1 - k;
+      float sum = 0.0f;
+      for (int q = 0; q < m; q++) sum += h[k + q * M] * win[base - q * M];
+      bufA[idx] = sum;
+    }
+    __syncthreads();
+    float2* Z = fft_lds<N>(reinterpret_cast<float2*>(bufA), reinterpret_cast<float2*>(bufB), tw, 2, FB, +1, tid, nthr);
+    // even/odd split and store bins 0..N
+    const float g = (gain > 0) ? (float) gain : 1.0f;
+    for (int idx = tid; idx < FB * (N + 1); idx += nthr) {
+      const int fr = idx / (N + 1), f = idx - fr * (N + 1);
+      const int t = t0 + fb0 + fr;
+      if (t >= Tmax) continue;
+      float2 out = make_float2(0.0f, 0.0f);
+      if (t < Tu) {
+        const float2 zf = Z[fr * N + (f & (N - 1))];
+        float2 zc = Z[fr * N + ((N - f) & (N - 1))]; zc.y = -zc.y;
+        const float2 E = make_float2(0.5f * (zf.x + zc.x), 0.5f * (zf.y + zc.y));
+        const float2 dd = make_float2(zf.x - zc.x, zf.y - zc.y);
+        const float2 O = make_float2(0.5f * dd.y, -0.5f * dd.x);       // -0.5j*(zf - zc)
+        const float2 w = tw[f];
+        out.x = (E.x + w.x * O.x - w.y * O.y) * g;
+        out.y = (E.y + w.x * O.y + w.y * O.x) * g;
+      }
+      Xo[(long) t * (N + 1) + f] = out;
+    }
+    __syncthreads();
+  }
+}
+
+// LDS layout: [tw: M float2][proto g: m*M float][v: NV*M float][bufA: FB*M float][bufB: FB*M float]
+template <int M>
+__global__ __launch_bounds__(256) void k_synthesis(const float2* __restrict__ Y, const int* __restrict__ nframesArr,
+                                                   const float* __restrict__ proto, const float2* __restrict__ twG,
+                                                   float* __restrict__ y, int Tmax, long outStride,
+                                                   int m, int r, int pd, int gain, int TO, int FB)
+{
+  constexpr int N = M / 2;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int R = 1 << r, D = M >> r;
+  const int NV = TO + R * m - 1;
+  float2* tw = reinterpret_cast<float2*>(smem);
+  float* g = reinterpret_cast<float*>(tw + M);
+  float* v = g + m * M;
+  float* bufA = v + NV * M;
+  float* bufB = bufA + FB * M;
+  const int tid = threadIdx.x, nthr = blockDim.x;
+  const int u = blockIdx.y;
+  const int t0 = blockIdx.x * TO;
+  const int Tu = nframesArr[u];
+  const int nOut = (Tu - pd > 0) ? (Tu - pd) : 0;        // valid output blocks
+  const float2* Yu = Y + (long) u * Tmax * (N + 1);
+  float* yu = y + (long) u * outStride;
+
+  for (int i = tid; i < M; i += nthr) tw[i] = twG[i];
+  for (int i = tid; i < m * M; i += nthr) g[i] = proto[i];
+  const int tA = t0 + pd - R * (m - 1) - (R - 1);       // first needed subband frame
+  __syncthreads();
+
+  for (int b0 = 0; b0 < NV; b0 += FB) {
+    // build the packed spectrum Zc[f], f < N, of frames tA+b0 .. (+FB)
+    for (int idx = tid; idx < FB * N; idx += nthr) {
+      const int fr = idx / N, f = idx - fr * N;
+      const int tau = tA + b0 + fr;
+      float2 zc = make_float2(0.0f, 0.0f);
+      if (b0 + fr < NV && tau >= 0 && tau < Tu) {
+        float2 gf = Yu[(long) tau * (N + 1) + f];
+        float2 gn = Yu[(long) tau * (N + 1) + (N - f)];
+        if (f == 0) { gf.y = 0.0f; gn.y = 0.0f; }      // G[0], G[N]: real parts only
+        gn.y = -gn.y;                                    // conj(G[N-f])
+        const float2 s = make_float2(gf.x + gn.x, gf.y + gn.y);
+        const float2 d = make_float2(gf.x - gn.x, gf.y - gn.y);
+        float2 w = tw[f]; w.y = -w.y;                    // e^{-2 pi j f/M}
+        const float2 wd = make_float2(w.x * d.x - w.y * d.y, w.x * d.y + w.y * d.x);
+        zc = make_float2(s.x - wd.y, s.y + wd.x);        // s + j*wd
+      }
+      reinterpret_cast<float2*>(bufA)[idx] = zc;
+    }
+    __syncthreads();
+    float2* Z = fft_lds<N>(reinterpret_cast<float2*>(bufA), reinterpret_cast<float2*>(bufB), tw, 2, FB, -1, tid, nthr);
+    for (int idx = tid; idx < FB * N; idx += nthr) {
+      const int fr = idx / N;
+      if (b0 + fr < NV) reinterpret_cast<float2*>(v)[(b0 + fr) * N + (idx - fr * N)] = Z[idx];
+    }
+    __syncthreads();
+  }
+
+  const float gf = (gain > 0) ? (float) gain : 1.0f;
+  for (int idx = tid; idx < TO * D; idx += nthr) {
+    const int tt = idx / D, d = idx - tt * D;
+    const int t = t0 + tt;
+    if ((long) t * D + (D - 1 - d) >= outStride) continue;
+    float acc = 0.0f;
+    if (t < nOut) {
+      for (int i = 0; i < R; i++) {
+        const int ts = t - R + 1 + i;                    // s_{ts}
+        if (ts < 0) continue;
+        const int k = d + i * D;
+        float s = 0.0f;
+        for (int q = 0; q < m; q++) {
+          const int tau = ts + pd - R * q;               // v_{tau}[k]
+          s += g[(M - 1 - k) + q * M] * v[(tau - tA) * M + k];
+        }
+        acc += s;
+      }
+      acc *= gf;
+    }
+    yu[(long) t * D + (D - 1 - d)] = acc;
+  }
+}
+
+template <int M> static void launch_analysis(const FbPlan& p, const float* x, const int* nsamp, int U, int C,
+                                             long sampStride, int Tmax, float* X, hipStream_t st)
+{
+  const int D = p.D;
+  int FB = 4096 / M; if (FB < 1) FB = 1;
+  int TF = FB * 2; if (TF > 64) TF = 64; if (TF < FB) TF = FB;
+  const int winLen = (TF - 1) * D + p.m * M;
+  size_t lds = sizeof(float2) * M + sizeof(float) * ((size_t) p.m * M + ((winLen + 3) & ~3) + 2 * (size_t) FB * M);
+  if (lds > 160 * 1024) throw Error(DSR_E_DIMENSION, "analysis bank M=%d m=%d needs %zu bytes of LDS", M, p.m, lds);
+  DSR_HIP(hipFuncSetAttribute((const void*) k_analysis<M>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
+  dim3 grid(cdiv(Tmax, TF), C, U);
+  hipLaunchKernelGGL(k_analysis<M>, grid, dim3(256), lds, st, x, nsamp, p.d_proto.p, p.d_tw.p, (float2*) X, C,
+                     sampStride, Tmax, p.m, p.r, p.pd, p.laN, p.gain, TF, FB);
+  DSR_HIP(hipGetLastError());
+}
+
+template <int M> static void launch_synthesis(const FbPlan& p, const float* Y, const int* nframes, int U, int Tmax,
+                                              long outStride, float* y, hipStream_t st)
+{
+  int FB = 4096 / M; if (FB < 1) FB = 1;
+  int TO = 32; while (TO > 1 && (size_t) (TO + p.R * p.m - 1) * M * 4 > 48 * 1024) TO >>= 1;
+  const int NV = TO + p.R * p.m - 1;
+  size_t lds = sizeof(float2) * M + sizeof(float) * ((size_t) p.m * M + (size_t) NV * M + 2 * (size_t) FB * M);
+  if (lds > 160 * 1024) throw Error(DSR_E_DIMENSION, "synthesis bank M=%d m=%d needs %zu bytes of LDS", M, p.m, lds);
+  DSR_HIP(hipFuncSetAttribute((const void*) k_synthesis<M>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
+  const int nblkMax = (int) (outStride / p.D);
+  dim3 grid(cdiv(nblkMax > 0 ? nblkMax : 1, TO), U);
+  hipLaunchKernelGGL(k_synthesis<M>, grid, dim3(256), lds, st, (const float2*) Y, nframes, p.d_proto.p, p.d_tw.p, y,
+                     Tmax, outStride, p.m, p.r, p.pd, p.gain, TO, FB);
+  DSR_HIP(hipGetLastError());
+}
+
+#define DSR_M_DISPATCH(M_, CALL) switch (M_) { \
+  case 16: CALL(16); break; case 32: CALL(32); break; case 64: CALL(64); break; case 128: CALL(128); break; \
+  case 256: CALL(256); break; case 512: CALL(512); break; case 1024: CALL(1024); break; case 2048: CALL(2048); break; \
+  default: throw Error(DSR_E_DIMENSION, "unsupported number of subbands M=%d (power of two in [16,2048])", M_); }
+
+void fb_analysis(const FbPlan& p, const float* x, const int* nsamp, int U, int C, long sampStride, int Tmax, float* X, hipStream_t st)
+{
+#define CALL(MM) launch_analysis<MM>(p, x, nsamp, U, C, sampStride, Tmax, X, st)
+  DSR_M_DISPATCH(p.M, CALL)
+#undef CALL
+}
+void fb_synthesis(const FbPlan& p, const float* Y, const int* nframes, int U, int Tmax, long outStride, float* y, hipStream_t st)
+{
+#define CALL(MM) launch_synthesis<MM>(p, Y, nframes, U, Tmax, outStride, y, st)
+  DSR_M_DISPATCH(p.M, CALL)
+#undef CALL
+}
+
+}  // namespace dsr
+
+using namespace dsr;
+struct dsr_fb : FbPlan {};
+
+extern "C" {
+
+dsr_status dsr_fb_create(const double* prototype, int M, int m, int r, int synthesis, int dctype, int gain, dsr_fb** out)
+{
+  return guard([&] {
+    if (!out || !prototype) throw Error(DSR_E_PARAMETER, "null argument");
+    if (!is_pow2((unsigned) M) || M < 16 || M > 2048) throw Error(DSR_E_DIMENSION, "M=%d must be a power of two in [16,2048]", M);
+    if (m < 1 || r < 0 || (M >> r) < 1) throw Error(DSR_E_DIMENSION, "bad m=%d r=%d", m, r);
+    require_device();
+    dsr_fb* p = new dsr_fb();
+    p->M = M; p->m = m; p->r = r; p->R = 1 << r; p->D = M >> r; p->synthesis = synthesis; p->dctype = dctype; p->gain = gain;
+    // modulated.cc:279-296
+    p->laN = 0;
+    switch (dctype) {
+    case 1: p->pd = m * p->R - 1; break;
+    case 2: if (synthesis) p->pd = m * p->R / 2; else { p->pd = m * p->R - 1; p->laN = m * p->R / 2 - 1; } break;
+    default: p->pd = 2 * m - 1; break;
+    }
+    p->proto.assign(prototype, prototype + (size_t) m * M);
+    std::vector<float> pf((size_t) m * M); for (size_t i = 0; i < pf.size(); i++) pf[i] = (float) prototype[i];
+    std::vector<float2> tw(M);
+    for (int k = 0; k < M; k++) { double a = 2.0 * M_PI * k / M; tw[k] = make_float2((float) cos(a), (float) sin(a)); }
+    p->d_proto.upload(pf); p->d_tw.upload(tw);
+    *out = p;
+  });
+}
+void dsr_fb_destroy(dsr_fb* p) { delete p; }
+int dsr_fb_analysis_frames(const dsr_fb* p, int nsamp)
+{ int nblk = (nsamp + p->D - 1) / p->D; return nblk < p->laN ? 0 : nblk - p->laN + p->pd; }
+int dsr_fb_synthesis_blocks(const dsr_fb* p, int nframes) { return nframes - p->pd > 0 ? nframes - p->pd : 0; }
+int dsr_fb_processing_delay(const dsr_fb* p) { return p->pd; }
+int dsr_fb_block_len(const dsr_fb* p) { return p->D; }
+
+dsr_status dsr_fb_analysis(const dsr_fb* p, const float* x, const int32_t* nsamp, int U, int C, int64_t sampStride,
+                           int Tmax, float* X, void* stream)
+{
+  return guard([&] {
+    if (!p || !x || !nsamp || !X) throw Error(DSR_E_PARAMETER, "null argument");
+    if (p->synthesis) throw Error(DSR_E_CONSISTENCY, "plan was created for synthesis");
+    if (U <= 0 || C <= 0 || Tmax <= 0) return;
+    if (C > 65535 || U > 65535) throw Error(DSR_E_DIMENSION, "U and C must be <= 65535 per call");
+    fb_analysis(*p, x, nsamp, U, C, (long) sampStride, Tmax, X, (hipStream_t) stream);
+  });
+}
+dsr_status dsr_fb_synthesis(const dsr_fb* p, const float* Y, const int32_t* nframes, int U, int Tmax,
+                            int64_t outStride, float* y, void* stream)
+{
+  return guard([&] {
+    if (!p || !Y || !nframes || !y) throw Error(DSR_E_PARAMETER, "null argument");
+    if (!p->synthesis) throw Error(DSR_E_CONSISTENCY, "plan was created for analysis");
+    if (U <= 0 || Tmax <= 0 || outStride <= 0) return;
+    if (U > 65535) throw Error(DSR_E_DIMENSION, "U must be <= 65535 per call");
+    fb_synthesis(*p, Y, nframes, U, Tmax, (long) outStride, y, (hipStream_t) stream);
+  });
+}
+
+}  // extern "C"

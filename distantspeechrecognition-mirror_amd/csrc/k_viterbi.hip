@@ -1,0 +1,537 @@
+// csrc/k_viterbi.hip -- time-synchronous Viterbi token passing over a static WFST, batched over
+// utterances, bit-exact with the reference's sequential decoder.
+//
+// Replaces _Decoder::decode and everything under it (asr/decoder/decoder.h:488-737, 956-1015),
+// the _TokenList hash/list (decoder.h:48-320), _Token (asr/lattice/lattice.h:37-79) and
+// bestHypo (decoder.h:748-773) for DecoderFlyWeight (decoder.h:1127-1139).
+//
+// What "bit-exact" needs and how it is kept in a parallel kernel:
+//   * token scores live as two floats; every placement is computed in double from them and rounded on
+//     construction; recombination compares the UNROUNDED double candidate with the incumbent's
+//     float sum (decoder.h:519-528).  That fold is order dependent, so it is replayed literally:
+//     every placement of a frame gets its arrival rank ("slot") = its position in the reference's
+//     nested loops (token list order x arc order x depth-first epsilon recursion); the placements
+//     of one destination state are folded in slot order by one thread.
+//   * the next frame's list order is "last inserted first" (decoder.h:246-247, replacement keeps the
+//     position): a state's position is decided by its FIRST arrival, so the new list is the
+//     first-arrival candidates in reverse slot order -- a stream compaction, no sort.
+//   * the beam uses the previous frame's best UNROUNDED emitting placement (decoder.h:521,566-588).
+//   * epsilon arcs are expanded depth first without recombination (decoder.h:979-983); the graph's
+//     expansion tables (wfst_graph.h) enumerate those paths in the reference's order, and the float
+//     rounding of every intermediate epsilon token is reproduced when the path is walked.
+// One workgroup (1024 threads) owns one utterance at a time and loops over its frames; workgroups pull
+// utterances from a queue.  All arithmetic that decides a comparison is done with explicit
+// non-contracted IEEE operations (this file is compiled with -ffp-contract=off).
+#include "common.h"
+#include "wfst_graph.h"
+#include <cmath>
+
+namespace dsr {
+
+struct Tok { int32_t node; float ac; float lm; uint32_t bp; };        // node bit31: edge input == silenceX
+struct CandA { double ttl; float ac; float lm; };
+struct CandB { int32_t dst; int32_t next; int32_t rec; int32_t win; };
+struct Bp { uint32_t prev; uint32_t rec; };
+
+static constexpr uint32_t kNone = 0xFFFFFFFFu;
+static constexpr uint32_t kEndBit = 0x80000000u;
+static constexpr int kThreads = 1024;
+static constexpr int kWaves = kThreads / 64;
+
+struct GraphDev {
+  int nNodes, initial;
+  const int* xoff; const XRec* xrec; const int* xarc; const int* xpathOff;
+  const int* eoff; const ERec* erec; const int* path;
+  const float* arcCost; const uint32_t* arcOut; const uint32_t* arcIn;
+  const int* nodeFinal; const float* nodeCost;
+};
+
+struct DecDev {
+  double beam, lmScale, lmPenalty, silPenalty; uint32_t silenceX;
+  int maxTok, maxCand; long arenaCap;
+  // per-slot scratch (slot s at base + s*stride)
+  Tok* tok; int* tokOff; int* owner; int* rank; CandA* cA; CandB* cB; unsigned* first; int* head; Bp* arena;
+  int* queue;
+  // dump (slot 0 only)
+  int dumpOn; long dumpCap; long* dumpFrameOff; int* dumpNode; float* dumpAc; float* dumpLm; int* dumpArc; long* dumpCount;
+};
+
+__device__ __forceinline__ unsigned ld_u32(const unsigned* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ int ld_i32(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_u32(unsigned* p, unsigned v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_i32(int* p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+__device__ __forceinline__ int wave_incl_scan(int v, int lane)
+{
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(v, d, 64); if (lane >= d) v += o; }
+  return v;
+}
+__device__ __forceinline__ double wave_min_d(double v)
+{
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) { const double o = __shfl_xor(v, d, 64); v = (o < v) ? o : v; }
+  return v;
+}
+__device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long v)
+{
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) { const unsigned long long o = __shfl_xor(v, d, 64); v = (o < v) ? o : v; }
+  return v;
+}
+__device__ __forceinline__ unsigned f2ord(float f) { const unsigned u = __float_as_uint(f); return (u & 0x80000000u) ? ~u : (u | 0x80000000u); }
+
+// One decoded utterance per loop iteration of a persistent workgroup.
+__global__ __launch_bounds__(kThreads) void k_viterbi(GraphDev G, DecDev Dd, const float* __restrict__ scores,
+                                                      const int* __restrict__ nframesArr, int U, int Tmax, int nDist,
+                                                      dsr_decode_result* __restrict__ res, int* __restrict__ arcsOut,
+                                                      unsigned* __restrict__ wordsOut, int maxPath, int useLdsRow)
+{
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  float* srow = reinterpret_cast<float*>(smem);                       // [nDist] when useLdsRow
+  __shared__ int s_waveTot[kWaves];
+  __shared__ double s_waveMin[kWaves];
+  __shared__ unsigned long long s_waveKey[kWaves];
+  __shared__ int s_u;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int slot = blockIdx.x;
+  Tok* tokA = Dd.tok + (size_t) slot * 2 * Dd.maxTok; Tok* tokB = tokA + Dd.maxTok;
+  int* tokOff = Dd.tokOff + (size_t) slot * (Dd.maxTok + 1);
+  int* owner = Dd.owner + (size_t) slot * Dd.maxCand;
+  int* rank = Dd.rank + (size_t) slot * Dd.maxCand;
+  CandA* cA = Dd.cA + (size_t) slot * Dd.maxCand; CandB* cB = Dd.cB + (size_t) slot * Dd.maxCand;
+  unsigned* first = Dd.first + (size_t) slot * G.nNodes; int* head = Dd.head + (size_t) slot * G.nNodes;
+  Bp* arena = Dd.arena + (size_t) slot * Dd.arenaCap;
+
+  for (;;) {
+    __syncthreads();
+    if (tid == 0) s_u = atomicAdd(Dd.queue, 1);
+    __syncthreads();
+    const int u = s_u;
+    if (u >= U) break;
+    const int T = nframesArr[u] < Tmax ? nframesArr[u] : Tmax;
+    const float* sc = scores + (size_t) u * Tmax * nDist;
+    const bool dump = Dd.dumpOn && slot == 0;
+
+    int status = DSR_OK;
+    if (T <= 0) status = DSR_E_ITERATOR;         // no frame at all: the exception escapes decode() (decoder.h:691)
+
+    Tok* cur = tokA; Tok* nxt = tokB;
+    int n = 1; long arenaOff = 0; long activeHypos = 0; int maxActive = 0;
+    double thresh = HUGE_VAL, topScore = HUGE_VAL;
+    if (tid == 0) { Tok t0; t0.node = G.initial; t0.ac = 0.0f; t0.lm = 0.0f; t0.bp = kNone; cur[0] = t0; }
+    __syncthreads();
+
+    // frames 0..T-1 (mode 0), then the end expansion (mode 1)
+    for (int fr = 0; fr <= T && status == DSR_OK; fr++) {
+      const int mode = (fr == T) ? 1 : 0;
+      if (mode == 0 && useLdsRow) { for (int i = tid; i < nDist; i += kThreads) srow[i] = sc[(size_t) fr * nDist + i]; }
+      const float* row = useLdsRow ? srow : (sc + (size_t) fr * nDist);
+
+      // ---------------- phase A: per-token placement counts, wave-local exclusive scan
+      const int chunkT = ((n + kWaves * 64 - 1) / (kWaves * 64)) * 64;
+      {
+        int running = 0;
+        const int b0 = wave * chunkT, b1 = (b0 + chunkT < n) ? b0 + chunkT : n;
+        for (int base = b0; base < b1; base += 64) {
+          const int i = base + lane; int cnt = 0;
+          if (i < b1) {
+            const Tok t = cur[i]; const int nd = t.node & 0x7FFFFFFF;
+            if (mode == 0) {
+              const float s = __fadd_rn(t.ac, t.lm);
+              if (!((double) s > thresh)) cnt = G.xoff[nd + 1] - G.xoff[nd];       // beam (decoder.h:586-588)
+            } else cnt = (G.nodeFinal[nd] ? 1 : 0) + (G.eoff[nd + 1] - G.eoff[nd]);
+          }
+          const int incl = wave_incl_scan(cnt, lane);
+          if (i < b1) tokOff[i] = running + incl - cnt;
+          running += __shfl(incl, 63, 64);
+        }
+        if (lane == 0) s_waveTot[wave] = running;
+      }
+      __syncthreads();
+      int C = 0;
+      for (int w = 0; w < kWaves; w++) C += s_waveTot[w];
+      if (C > Dd.maxCand) { status = DSR_E_ALLOCATION; break; }
+      // ---------------- phase A2: absolute offsets + owner fill
+      for (int i = tid; i < n; i += kThreads) {
+        const int w = i / chunkT; int base = 0;
+        for (int q = 0; q < w; q++) base += s_waveTot[q];
+        const int off = base + tokOff[i];
+        const Tok t = cur[i]; const int nd = t.node & 0x7FFFFFFF; int cnt;
+        if (mode == 0) { const float s = __fadd_rn(t.ac, t.lm); cnt = ((double) s > thresh) ? 0 : (G.xoff[nd + 1] - G.xoff[nd]); }
+        else cnt = (G.nodeFinal[nd] ? 1 : 0) + (G.eoff[nd + 1] - G.eoff[nd]);
+        tokOff[i] = off;
+        for (int j = 0; j < cnt; j++) owner[off + j] = i;
+      }
+      __syncthreads();
+      // ---------------- phase B: one thread per placement
+      double locMin = HUGE_VAL;
+      for (int c = tid; c < C; c += kThreads) {
+        const int i = owner[c]; const Tok t = cur[i]; const int nd = t.node & 0x7FFFFFFF; const bool tokSil = t.node < 0;
+        const int j = c - tokOff[i];
+        double ac = (double) t.ac, lm; int dst, recId;
+        if (mode == 0) {
+          recId = G.xoff[nd] + j; const XRec x = G.xrec[recId];
+          const int plen = (int) (x.meta & 0xFFFFu);
+          double lmNode = (double) t.lm; uint32_t prevIn = tokSil ? Dd.silenceX : (Dd.silenceX + 1u);   // only equality with silenceX matters
+          bool prevNull = (t.bp == kNone) && (fr == 0);
+          if (plen) {
+            const int* pp = G.path + G.xpathOff[recId];
+            for (int h = 0; h < plen; h++) {                                   // intermediate epsilon tokens (decoder.h:979-983)
+              const int a = pp[h];
+              double l = __dadd_rn(lmNode, __dmul_rn(Dd.lmScale, (double) G.arcCost[a]));
+              if (G.arcOut[a] != 0) l = __dadd_rn(l, __dmul_rn(Dd.lmScale, Dd.lmPenalty));
+              if (0u == Dd.silenceX && (prevNull || prevIn != Dd.silenceX)) l = __dadd_rn(l, __dmul_rn(Dd.lmScale, Dd.silPenalty));
+              lmNode = (double) (float) l; prevIn = 0u; prevNull = false;
+            }
+          }
+          lm = __dadd_rn(lmNode, __dmul_rn(Dd.lmScale, (double) x.cost));
+          if (x.meta & 0x10000u) lm = __dadd_rn(lm, __dmul_rn(Dd.lmScale, Dd.lmPenalty));
+          if ((uint32_t) (x.dist + 1) == Dd.silenceX && (prevNull || prevIn != Dd.silenceX)) lm = __dadd_rn(lm, __dmul_rn(Dd.lmScale, Dd.silPenalty));
+          ac = __dadd_rn(ac, (double) row[x.dist]);
+          dst = x.dst;
+        } else {
+          const int hasSelf = G.nodeFinal[nd] ? 1 : 0;
+          if (hasSelf && j == 0) {                                             // _expandToEnd self placement (decoder.h:506-509)
+            const float lmf = (float) __dadd_rn((double) t.lm, __dmul_rn(Dd.lmScale, (double) G.nodeCost[nd]));
+            lm = (double) lmf; dst = nd; recId = (int) 0x7FFFFFFE;
+          } else {
+            recId = G.eoff[nd] + (j - hasSelf); const ERec e = G.erec[recId];
+            const int* pp = G.path + e.pathOff; double lmNode = (double) t.lm; double l = lmNode;
+            uint32_t prevIn = tokSil ? Dd.silenceX : (Dd.silenceX + 1u);
+            for (int h = 0; h < e.pathLen; h++) {                              // _expandNodeToEnd (decoder.h:992-1015)
+              const int a = pp[h];
+              l = __dadd_rn(lmNode, __dmul_rn(Dd.lmScale, (double) G.arcCost[a]));
+              if (G.arcOut[a] != 0) l = __dadd_rn(l, __dmul_rn(Dd.lmScale, Dd.lmPenalty));
+              if (0u == Dd.silenceX && prevIn != Dd.silenceX) l = __dadd_rn(l, __dmul_rn(Dd.lmScale, Dd.silPenalty));
+              lmNode = (double) (float) l; prevIn = 0u;
+            }
+            lm = __dadd_rn(l, __dmul_rn(Dd.lmScale, (double) G.nodeCost[e.lastSrc]));
+            dst = e.dst; recId = (int) ((uint32_t) recId | kEndBit);
+          }
+        }
+        const double ttl = __dadd_rn(ac, lm);
+        CandA a2; a2.ttl = ttl; a2.ac = (float) ac; a2.lm = (float) lm; cA[c] = a2;
+        atomicMin(&first[dst], (unsigned) c);
+        const int nx = atomicExch(&head[dst], c);
+        CandB b2; b2.dst = dst; b2.next = nx; b2.rec = recId; b2.win = -1; cB[c] = b2;
+        if (mode == 0 && ttl < locMin) locMin = ttl;                           // _topScore (emitting placements only)
+      }
+      locMin = wave_min_d(locMin);
+      if (lane == 0) s_waveMin[wave] = locMin;
+      __syncthreads();
+      topScore = HUGE_VAL;
+      for (int w = 0; w < kWaves; w++) { const double v = s_waveMin[w]; if (v < topScore) topScore = v; }
+      // ---------------- phase C1: fold per destination state (by its first-arrival thread), count new tokens
+      const int chunkC = ((C + kWaves * 64 - 1) / (kWaves * 64)) * 64;
+      {
+        int running = 0;
+        const int b0 = wave * chunkC, b1 = (b0 + chunkC < C) ? b0 + chunkC : C;
+        for (int base = b0; base < b1; base += 64) {
+          const int c = base + lane; bool isFirst = false;
+          if (c < b1) {
+            const int dst = cB[c].dst;
+            isFirst = (ld_u32(&first[dst]) == (unsigned) c);
+            if (isFirst) {
+              int w = c; CandA aw = cA[w];
+              double fw = (double) __fadd_rn(aw.ac, aw.lm);                   // incumbent's float score()
+              const int h0 = ld_i32(&head[dst]);
+              for (;;) {                                                       // next replacement = smallest later slot that beats it
+                int best = 0x7FFFFFFF;
+                for (int p = h0; p >= 0; p = cB[p].next) if (p > w && p < best && cA[p].ttl < fw) best = p;
+                if (best == 0x7FFFFFFF) break;
+                w = best; aw = cA[w]; fw = (double) __fadd_rn(aw.ac, aw.lm);
+              }
+              cB[c].win = w;
+            }
+          }
+          const unsigned long long bal = __ballot(isFirst);
+          if (isFirst) rank[c] = running + __popcll(bal & ((1ull << lane) - 1ull));
+          running += __popcll(bal);
+        }
+        if (lane == 0) s_waveTot[wave] = running;
+      }
+      __syncthreads();
+      int numNew = 0;
+      for (int w = 0; w < kWaves; w++) numNew += s_waveTot[w];
+      if (numNew > Dd.maxTok || arenaOff + numNew > Dd.arenaCap) { status = DSR_E_ALLOCATION; break; }
+      // ---------------- phase C2: write the new token list (reverse first-arrival order) + back pointers
+      {
+        int wbase = 0; for (int q = 0; q < wave; q++) wbase += s_waveTot[q];
+        const int b0 = wave * chunkC, b1 = (b0 + chunkC < C) ? b0 + chunkC : C;
+        for (int base = b0; base < b1; base += 64) {
+          const int c = base + lane;
+          if (c < b1) {
+            const CandB bc = cB[c];
+            if (bc.win >= 0) {
+              const int pos = numNew - 1 - (wbase + rank[c]);
+              const int w = bc.win; const CandA aw = cA[w]; const int recW = cB[w].rec; const int src = owner[w];
+              Tok nt; nt.ac = aw.ac; nt.lm = aw.lm; nt.bp = (uint32_t) (arenaOff + pos);
+              Bp bp;
+              if (mode == 0) {
+                const bool sil = ((uint32_t) (G.xrec[recW].dist + 1) == Dd.silenceX);
+                nt.node = bc.dst | (sil ? (int) 0x80000000 : 0);
+                bp.prev = cur[src].bp; bp.rec = (uint32_t) recW;
+              } else {
+                nt.node = bc.dst;
+                if (recW == (int) 0x7FFFFFFE) { const Bp o = arena[cur[src].bp]; bp = o; }     // replaces the token in its chain
+                else { bp.prev = cur[src].bp; bp.rec = (uint32_t) recW; }
+              }
+              nxt[pos] = nt; arena[arenaOff + pos] = bp;
+              st_u32(&first[bc.dst], 0xFFFFFFFFu); st_i32(&head[bc.dst], -1);
+            }
+          }
+        }
+      }
+      __syncthreads();
+      if (mode == 0) {
+        if (dump) {
+          long* cnt = Dd.dumpCount; const long o = cnt[0];
+          if (o + numNew <= Dd.dumpCap) {
+            for (int i = tid; i < numNew; i += kThreads) {
+              const Tok t = nxt[i]; Dd.dumpNode[o + i] = t.node & 0x7FFFFFFF; Dd.dumpAc[o + i] = t.ac; Dd.dumpLm[o + i] = t.lm;
+              Dd.dumpArc[o + i] = G.xarc[arena[t.bp].rec];
+            }
+          }
+          __syncthreads();
+          if (tid == 0) { Dd.dumpFrameOff[fr] = o; Dd.dumpFrameOff[fr + 1] = o + numNew; cnt[0] = o + numNew; cnt[1] = fr + 1; }
+        }
+        if (numNew == 0) { status = DSR_E_CONSISTENCY; break; }                // the reference never terminates from here
+        Tok* tmp = cur; cur = nxt; nxt = tmp; n = numNew; arenaOff += numNew;
+        activeHypos += numNew; if (numNew > maxActive) maxActive = numNew;
+        thresh = __dadd_rn(topScore, Dd.beam);
+      } else {
+        // ---------------- best token (decoder.h:639-685): list order, strict '<' on the float score
+        const Tok* lst = numNew > 0 ? nxt : cur; const int cntL = numNew > 0 ? numNew : n;
+        unsigned long long key = ~0ull;
+        for (int i = tid; i < cntL; i += kThreads) {
+          const Tok t = lst[i]; const float s = __fadd_rn(t.ac, t.lm);
+          if (s == s) { const unsigned long long k = ((unsigned long long) f2ord(s) << 32) | (unsigned) i; if (k < key) key = k; }
+        }
+        key = wave_min_u64(key);
+        if (lane == 0) s_waveKey[wave] = key;
+        __syncthreads();
+        if (tid == 0) {
+          unsigned long long k = ~0ull; for (int w = 0; w < kWaves; w++) if (s_waveKey[w] < k) k = s_waveKey[w];
+          dsr_decode_result r; memset(&r, 0, sizeof(r));
+          r.frames = T - 1; r.reachedFinal = numNew > 0 ? 1 : 0; r.activeHypos = activeHypos; r.maxActiveSeen = maxActive; r.status = DSR_OK;
+          if (k != ~0ull) {
+            const Tok bt = lst[(unsigned) (k & 0xFFFFFFFFu)];
+            r.ac = bt.ac; r.lm = bt.lm; r.score = __dadd_rn((double) bt.ac, (double) bt.lm);
+            // traceback (bestHypo, decoder.h:748-773): count, then fill first..last
+            int nA = 0;
+            for (uint32_t b = bt.bp; b != kNone; b = arena[b].prev) {
+              const uint32_t rc = arena[b].rec;
+              nA += (rc & kEndBit) ? G.erec[rc & ~kEndBit].pathLen : (int) (G.xrec[rc].meta & 0xFFFFu) + 1;
+            }
+            r.nArcs = nA;
+            int pos = nA; int nW = 0;
+            int* ao = arcsOut ? arcsOut + (size_t) u * maxPath : nullptr;
+            for (uint32_t b = bt.bp; b != kNone; b = arena[b].prev) {
+              const uint32_t rc = arena[b].rec;
+              if (rc & kEndBit) {
+                const ERec e = G.erec[rc & ~kEndBit];
+                for (int h = e.pathLen - 1; h >= 0; h--) { const int a = G.path[e.pathOff + h]; pos--; if (ao && pos < maxPath) ao[pos] = a; if (G.arcOut[a] != 0) nW++; }
+              } else {
+                const int a = G.xarc[rc]; pos--; if (ao && pos < maxPath) ao[pos] = a; if (G.arcOut[a] != 0) nW++;
+                const int pl = (int) (G.xrec[rc].meta & 0xFFFFu); const int po = G.xpathOff[rc];
+                for (int h = pl - 1; h >= 0; h--) { const int a2 = G.path[po + h]; pos--; if (ao && pos < maxPath) ao[pos] = a2; if (G.arcOut[a2] != 0) nW++; }
+              }
+            }
+            r.nWords = nW;
+            if (wordsOut && ao) {          // second walk over the arc list, in order
+              unsigned* wo = wordsOut + (size_t) u * maxPath; int q = 0;
+              const int lim = nA < maxPath ? nA : maxPath;
+              for (int i = 0; i < lim; i++) { const unsigned o = G.arcOut[ao[i]]; if (o != 0 && q < maxPath) wo[q++] = o; }
+            }
+            if (nA > maxPath && arcsOut) r.status = DSR_E_DIMENSION;
+          } else r.status = DSR_E_CONSISTENCY;
+          res[u] = r;
+        }
+        __syncthreads();
+      }
+    }   // frames
+
+    if (status != DSR_OK) {
+      // abort: leave the state tables clean for the next utterance of this slot
+      for (int i = tid; i < G.nNodes; i += kThreads) { st_u32(&first[i], 0xFFFFFFFFu); st_i32(&head[i], -1); }
+      if (tid == 0) { dsr_decode_result r; memset(&r, 0, sizeof(r)); r.status = status; r.frames = T - 1; res[u] = r; }
+    }
+  }
+}
+
+struct DecoderState {
+  dsr_decoder_cfg cfg; bool haveGraph = false; int nSlots = 0; int nNodes = 0;
+  WfstGraph::Csr csr; WfstGraph::Tables tab;
+  DevBuf<int> d_xoff, d_xarc, d_xpathOff, d_eoff, d_path, d_nodeFinal, d_queue;
+  DevBuf<XRec> d_xrec; DevBuf<ERec> d_erec; DevBuf<float> d_arcCost, d_nodeCost; DevBuf<uint32_t> d_arcOut, d_arcIn;
+  DevBuf<Tok> d_tok; DevBuf<int> d_tokOff, d_owner, d_rank, d_head; DevBuf<CandA> d_cA; DevBuf<CandB> d_cB; DevBuf<unsigned> d_first; DevBuf<Bp> d_arena;
+  DevBuf<dsr_decode_result> d_res; DevBuf<int> d_arcs; DevBuf<unsigned> d_words;
+  long arenaCap = 0; int initial = 0;
+  // dump
+  int dumpOn = 0; long dumpCap = 0; DevBuf<long> d_dumpFrameOff, d_dumpCount; DevBuf<int> d_dumpNode, d_dumpArc; DevBuf<float> d_dumpAc, d_dumpLm;
+  std::vector<int64_t> h_dumpFrameOff; std::vector<int32_t> h_dumpNode, h_dumpArc; std::vector<float> h_dumpAc, h_dumpLm; int64_t h_dumpFrames = 0;
+};
+
+}  // namespace dsr
+
+using namespace dsr;
+struct dsr_wfst : WfstGraph {};
+struct dsr_decoder : DecoderState {};
+
+extern "C" {
+
+dsr_status dsr_wfst_create(dsr_wfst** out) { return guard([&] { if (!out) throw Error(DSR_E_PARAMETER, "null argument"); *out = new dsr_wfst(); }); }
+void dsr_wfst_destroy(dsr_wfst* g) { delete g; }
+dsr_status dsr_wfst_read(dsr_wfst* g, const char* f, int binary) { return guard([&] { if (!g) throw Error(DSR_E_PARAMETER, "null argument"); g->read(f, binary != 0); }); }
+dsr_status dsr_wfst_write(const dsr_wfst* g, const char* f, int binary) { return guard([&] { if (!g) throw Error(DSR_E_PARAMETER, "null argument"); g->write(f, binary != 0); }); }
+dsr_status dsr_wfst_add_arc(dsr_wfst* g, unsigned s1, unsigned s2, unsigned in, unsigned out, float cost)
+{ return guard([&] { if (!g) throw Error(DSR_E_PARAMETER, "null argument"); g->addArc(s1, s2, in, out, cost, true); }); }
+dsr_status dsr_wfst_add_final(dsr_wfst* g, unsigned s, float cost) { return guard([&] { if (!g) throw Error(DSR_E_PARAMETER, "null argument"); g->addFinal(s, cost); }); }
+int dsr_wfst_num_nodes(const dsr_wfst* g) { return (int) g->nodes.size(); }
+int dsr_wfst_num_arcs(const dsr_wfst* g) { return (int) g->arcs.size(); }
+dsr_status dsr_wfst_export(const dsr_wfst* g, uint32_t* nodeState, int32_t* nodeFinal, float* nodeCost, int32_t* arcOff,
+                           int32_t* arcDst, uint32_t* arcIn, uint32_t* arcOut, float* arcCost)
+{
+  return guard([&] {
+    if (!g) throw Error(DSR_E_PARAMETER, "null argument");
+    const WfstGraph::Csr c = g->csr(); const size_t n = g->nodes.size();
+    for (size_t i = 0; i < n; i++) { if (nodeState) nodeState[i] = g->nodes[i].state; if (nodeFinal) nodeFinal[i] = g->nodes[i].final_; if (nodeCost) nodeCost[i] = g->nodes[i].cost; }
+    if (arcOff) for (size_t i = 0; i <= n; i++) arcOff[i] = c.off[i];
+    for (size_t a = 0; a < c.dst.size(); a++) { if (arcDst) arcDst[a] = c.dst[a]; if (arcIn) arcIn[a] = c.in[a]; if (arcOut) arcOut[a] = c.out[a]; if (arcCost) arcCost[a] = c.cost[a]; }
+  });
+}
+
+void dsr_decoder_default_cfg(dsr_decoder_cfg* c)
+{ memset(c, 0, sizeof(*c)); c->beam = 100.0; c->lmScale = 12.0; c->lmPenalty = 0.0; c->silPenalty = 0.0; c->silenceX = 0xFFFFFFFFu; }
+
+dsr_status dsr_decoder_create(const dsr_decoder_cfg* cfg, dsr_decoder** out)
+{
+  return guard([&] {
+    if (!cfg || !out) throw Error(DSR_E_PARAMETER, "null argument");
+    require_device();
+    dsr_decoder* d = new dsr_decoder(); d->cfg = *cfg;
+    if (d->cfg.maxActive <= 0) d->cfg.maxActive = 65536;
+    if (d->cfg.maxCandidates <= 0) d->cfg.maxCandidates = 8 * d->cfg.maxActive;
+    if (d->cfg.streams <= 0) {
+      hipDeviceProp_t prop; int dev = 0; DSR_HIP(hipGetDevice(&dev)); DSR_HIP(hipGetDeviceProperties(&prop, dev));
+      d->cfg.streams = prop.multiProcessorCount;
+    }
+    *out = d;
+  });
+}
+void dsr_decoder_destroy(dsr_decoder* d) { delete d; }
+
+dsr_status dsr_decoder_set(dsr_decoder* d, const dsr_wfst* g)
+{
+  return guard([&] {
+    if (!d || !g) throw Error(DSR_E_PARAMETER, "null argument");
+    if (g->initial < 0) throw Error(DSR_E_CONSISTENCY, "the transducer has no arcs");
+    d->csr = g->csr(); d->tab = g->tables(d->csr, (size_t) 1 << 28);
+    d->nNodes = (int) g->nodes.size(); d->initial = g->initial;
+    std::vector<int> nf(d->nNodes); std::vector<float> nc(d->nNodes);
+    for (int i = 0; i < d->nNodes; i++) { nf[i] = g->nodes[i].final_; nc[i] = g->nodes[i].cost; }
+    d->d_xoff.upload(d->tab.xoff); d->d_eoff.upload(d->tab.eoff); d->d_path.upload(d->tab.path);
+    if (d->tab.xrec.empty()) throw Error(DSR_E_CONSISTENCY, "the transducer has no emitting arcs");
+    d->d_xrec.upload(d->tab.xrec); d->d_xarc.upload(d->tab.xarc); d->d_xpathOff.upload(d->tab.xpathOff);
+    { std::vector<ERec> e = d->tab.erec; if (e.empty()) e.push_back(ERec{0, 0, 0, 0}); d->d_erec.upload(e); }
+    d->d_arcCost.upload(d->csr.cost); d->d_arcOut.upload(d->csr.out); d->d_arcIn.upload(d->csr.in);
+    d->d_nodeFinal.upload(nf); d->d_nodeCost.upload(nc);
+    d->haveGraph = true; d->nSlots = 0;    // scratch is (re)allocated by the first decode
+  });
+}
+dsr_status dsr_decoder_set_beam(dsr_decoder* d, double beam) { return guard([&] { if (!d) throw Error(DSR_E_PARAMETER, "null argument"); d->cfg.beam = beam; }); }
+
+dsr_status dsr_decoder_enable_dump(dsr_decoder* d, int en) { return guard([&] { if (!d) throw Error(DSR_E_PARAMETER, "null argument"); d->dumpOn = en; }); }
+
+static void ensure_scratch(dsr_decoder* d, int slots, int Tmax)
+{
+  const dsr_decoder_cfg& c = d->cfg;
+  long arena = c.arenaTokens > 0 ? (long) c.arenaTokens : (long) 8192 * (long) (Tmax + 2);
+  if (arena > 0x7FFFFFF0L) arena = 0x7FFFFFF0L;
+  if (slots <= d->nSlots && arena <= d->arenaCap) return;
+  if (slots < d->nSlots) slots = d->nSlots;
+  if (arena < d->arenaCap) arena = d->arenaCap;
+  const size_t S = (size_t) slots;
+  d->d_tok.reserve(S * 2 * c.maxActive); d->d_tokOff.reserve(S * (c.maxActive + 1));
+  d->d_owner.reserve(S * c.maxCandidates); d->d_rank.reserve(S * c.maxCandidates);
+  d->d_cA.reserve(S * c.maxCandidates); d->d_cB.reserve(S * c.maxCandidates);
+  d->d_first.reserve(S * d->nNodes); d->d_head.reserve(S * d->nNodes);
+  d->d_arena.reserve(S * (size_t) arena);
+  DSR_HIP(hipMemset(d->d_first.p, 0xFF, S * d->nNodes * sizeof(unsigned)));
+  DSR_HIP(hipMemset(d->d_head.p, 0xFF, S * d->nNodes * sizeof(int)));
+  d->d_queue.reserve(1);
+  d->nSlots = slots; d->arenaCap = arena;
+}
+
+dsr_status dsr_decoder_decode_batch(dsr_decoder* d, const float* score, const int32_t* nframes, int U, int Tmax, int nDist,
+                                    dsr_decode_result* res, int32_t* arcs_out, uint32_t* words_out, int maxPath, void* stream)
+{
+  return guard([&] {
+    if (!d || !score || !nframes || !res) throw Error(DSR_E_PARAMETER, "null argument");
+    if (!d->haveGraph) throw Error(DSR_E_INITIALIZATION, "call set() with a transducer first");
+    if (U <= 0) return;
+    hipStream_t st = (hipStream_t) stream;
+    // every input symbol must name a distribution (decoder.h:985: _dist->find(distX-1))
+    for (size_t a = 0; a < d->csr.in.size(); a++) if (d->csr.in[a] > (uint32_t) nDist) throw Error(DSR_E_INDEX, "arc input %u has no distribution (nDist=%d)", d->csr.in[a], nDist);
+    int slots = d->cfg.streams; if (slots > U) slots = U; if (d->dumpOn) slots = 1;
+    ensure_scratch(d, slots, Tmax);
+    d->d_res.reserve(U);
+    if (maxPath < 0) maxPath = 0;
+    if (arcs_out || words_out) { d->d_arcs.reserve((size_t) U * (maxPath > 0 ? maxPath : 1)); d->d_words.reserve((size_t) U * (maxPath > 0 ? maxPath : 1)); }
+    DSR_HIP(hipMemsetAsync(d->d_queue.p, 0, sizeof(int), st));
+    if (d->dumpOn) {
+      d->dumpCap = (long) d->cfg.maxActive * 64 < (long) 1 << 26 ? (long) 1 << 24 : (long) 1 << 26;
+      d->d_dumpFrameOff.reserve(Tmax + 2); d->d_dumpCount.reserve(2);
+      d->d_dumpNode.reserve(d->dumpCap); d->d_dumpArc.reserve(d->dumpCap); d->d_dumpAc.reserve(d->dumpCap); d->d_dumpLm.reserve(d->dumpCap);
+      DSR_HIP(hipMemsetAsync(d->d_dumpCount.p, 0, 2 * sizeof(long), st));
+    }
+    GraphDev G; G.nNodes = d->nNodes; G.initial = d->initial; G.xoff = d->d_xoff.p; G.xrec = d->d_xrec.p; G.xarc = d->d_xarc.p;
+    G.xpathOff = d->d_xpathOff.p; G.eoff = d->d_eoff.p; G.erec = d->d_erec.p; G.path = d->d_path.p; G.arcCost = d->d_arcCost.p;
+    G.arcOut = d->d_arcOut.p; G.arcIn = d->d_arcIn.p; G.nodeFinal = d->d_nodeFinal.p; G.nodeCost = d->d_nodeCost.p;
+    DecDev D; D.beam = d->cfg.beam; D.lmScale = d->cfg.lmScale; D.lmPenalty = d->cfg.lmPenalty; D.silPenalty = d->cfg.silPenalty;
+    D.silenceX = d->cfg.silenceX; D.maxTok = d->cfg.maxActive; D.maxCand = d->cfg.maxCandidates; D.arenaCap = d->arenaCap;
+    D.tok = d->d_tok.p; D.tokOff = d->d_tokOff.p; D.owner = d->d_owner.p; D.rank = d->d_rank.p; D.cA = d->d_cA.p; D.cB = d->d_cB.p;
+    D.first = d->d_first.p; D.head = d->d_head.p; D.arena = d->d_arena.p; D.queue = d->d_queue.p;
+    D.dumpOn = d->dumpOn; D.dumpCap = d->dumpCap; D.dumpFrameOff = d->d_dumpFrameOff.p; D.dumpNode = d->d_dumpNode.p; D.dumpAc = d->d_dumpAc.p;
+    D.dumpLm = d->d_dumpLm.p; D.dumpArc = d->d_dumpArc.p; D.dumpCount = d->d_dumpCount.p;
+    const int useLds = (size_t) nDist * sizeof(float) <= 96 * 1024;
+    const size_t lds = useLds ? (size_t) nDist * sizeof(float) : 16;
+    DSR_HIP(hipFuncSetAttribute((const void*) k_viterbi, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
+    hipLaunchKernelGGL(k_viterbi, dim3(slots), dim3(kThreads), lds, st, G, D, score, nframes, U, Tmax, nDist, d->d_res.p,
+                       (arcs_out || words_out) ? d->d_arcs.p : nullptr, (arcs_out || words_out) ? d->d_words.p : nullptr, maxPath, useLds);
+    DSR_HIP(hipGetLastError());
+    DSR_HIP(hipMemcpyAsync(res, d->d_res.p, sizeof(dsr_decode_result) * U, hipMemcpyDeviceToHost, st));
+    if (arcs_out) DSR_HIP(hipMemcpyAsync(arcs_out, d->d_arcs.p, sizeof(int) * (size_t) U * maxPath, hipMemcpyDeviceToHost, st));
+    if (words_out) DSR_HIP(hipMemcpyAsync(words_out, d->d_words.p, sizeof(unsigned) * (size_t) U * maxPath, hipMemcpyDeviceToHost, st));
+    DSR_HIP(hipStreamSynchronize(st));
+    if (d->dumpOn) {
+      long cnt[2]; DSR_HIP(hipMemcpy(cnt, d->d_dumpCount.p, sizeof(cnt), hipMemcpyDeviceToHost));
+      const long N = cnt[0] < d->dumpCap ? cnt[0] : d->dumpCap; d->h_dumpFrames = cnt[1];
+      std::vector<long> fo(cnt[1] + 1); if (cnt[1] > 0) DSR_HIP(hipMemcpy(fo.data(), d->d_dumpFrameOff.p, sizeof(long) * (cnt[1] + 1), hipMemcpyDeviceToHost));
+      d->h_dumpFrameOff.assign(fo.begin(), fo.end());
+      d->h_dumpNode.resize(N); d->h_dumpArc.resize(N); d->h_dumpAc.resize(N); d->h_dumpLm.resize(N);
+      if (N > 0) {
+        DSR_HIP(hipMemcpy(d->h_dumpNode.data(), d->d_dumpNode.p, sizeof(int) * N, hipMemcpyDeviceToHost));
+        DSR_HIP(hipMemcpy(d->h_dumpArc.data(), d->d_dumpArc.p, sizeof(int) * N, hipMemcpyDeviceToHost));
+        DSR_HIP(hipMemcpy(d->h_dumpAc.data(), d->d_dumpAc.p, sizeof(float) * N, hipMemcpyDeviceToHost));
+        DSR_HIP(hipMemcpy(d->h_dumpLm.data(), d->d_dumpLm.p, sizeof(float) * N, hipMemcpyDeviceToHost));
+      }
+    }
+  });
+}
+
+dsr_status dsr_decoder_get_dump(dsr_decoder* d, int64_t* nFrames, const int64_t** frameOff, const int32_t** node,
+                                const float** ac, const float** lm, const int32_t** arc)
+{
+  return guard([&] {
+    if (!d) throw Error(DSR_E_PARAMETER, "null argument");
+    if (nFrames) *nFrames = d->h_dumpFrames;
+    if (frameOff) *frameOff = d->h_dumpFrameOff.data();
+    if (node) *node = d->h_dumpNode.data(); if (arc) *arc = d->h_dumpArc.data();
+    if (ac) *ac = d->h_dumpAc.data(); if (lm) *lm = d->h_dumpLm.data();
+  });
+}
+
+}  // extern "C"

@@ -1,0 +1,420 @@
+"""ctypes binding of libdsr_hip.so (include/dsr.h).
+
+This is plumbing: device memory and streams come from torch (ROCm), every compute call goes
+through the C-ABI with raw device pointers.  There is no CPU path here; if the shared library or
+a HIP device is missing the call raises.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIBPATH = os.path.join(os.path.dirname(_HERE), "lib", "libdsr_hip.so")
+_lib = None
+
+vp, i32, i64, f32, f64, u32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_double, C.c_uint32
+
+ERROR_NAMES = ["OK", "JERROR", "JALLOCATION", "JARITHMETIC", "JCONSISTENCY", "JDIMENSION", "JINDEX", "JINITIALIZATION",
+               "JIO", "JITERATOR", "JPYTHON", "JKEY", "JNUMERIC", "JPARAMETER", "JPARSE", "JTYPE"]
+E_ITERATOR, E_IO, E_INDEX, E_DIMENSION = 9, 8, 6, 5
+
+
+class DsrError(Exception):
+    """j_error (btk/common/jexception.h:57-70): carries the reference's error_type as .code."""
+
+    def __init__(self, status, msg):
+        super().__init__("%s: %s" % (ERROR_NAMES[status] if 0 <= status < len(ERROR_NAMES) else status, msg))
+        self.status = status
+        self.code = status - 1
+
+
+class MfccCfg(C.Structure):
+    _fields_ = [("blockLen", C.c_int), ("shiftLen", C.c_int), ("padZeros", C.c_int), ("mu", f64), ("fftLen", C.c_int),
+                ("powN", C.c_int), ("vtlnRatio", f64), ("vtlnEdge", f64), ("vtlnVersion", C.c_int), ("rate", f32), ("low", f32),
+                ("up", f32), ("filterN", C.c_int), ("melVersion", C.c_int), ("logM", f64), ("logA", f64), ("sphinxFlooring", C.c_int),
+                ("ncep", C.c_int), ("dctType", C.c_int), ("cmnMode", C.c_int), ("devNormFactor", f64), ("delta", C.c_int),
+                ("outDim", C.c_int)]
+
+
+class DecoderCfg(C.Structure):
+    _fields_ = [("beam", f64), ("lmScale", f64), ("lmPenalty", f64), ("silPenalty", f64), ("silenceX", u32),
+                ("maxActive", C.c_int), ("maxCandidates", C.c_int), ("arenaTokens", i64), ("streams", C.c_int)]
+
+
+class DecodeResult(C.Structure):
+    _fields_ = [("score", f64), ("ac", f32), ("lm", f32), ("frames", i32), ("reachedFinal", i32), ("nArcs", i32),
+                ("nWords", i32), ("status", i32), ("maxActiveSeen", i32), ("activeHypos", i64)]
+
+
+def load():
+    """Load the library.  torch is imported first so that its HIP runtime (same SONAME) is the one bound."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    import torch  # noqa: F401  (binds libamdhip64.so.7 before our library asks for it)
+    if not os.path.exists(_LIBPATH):
+        raise ImportError("libdsr_hip.so is not built: run `python -c 'import __graft_entry__ as g; g.build()'` (%s)" % _LIBPATH)
+    L = C.CDLL(_LIBPATH)
+    L.dsr_last_error.restype = C.c_char_p
+    L.dsr_version.restype = C.c_char_p
+    sig = {
+        "dsr_fb_create": [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp],
+        "dsr_fb_destroy": [vp], "dsr_fb_analysis_frames": [vp, C.c_int], "dsr_fb_synthesis_blocks": [vp, C.c_int],
+        "dsr_fb_processing_delay": [vp], "dsr_fb_block_len": [vp],
+        "dsr_fb_analysis": [vp, vp, vp, C.c_int, C.c_int, i64, C.c_int, vp, vp],
+        "dsr_fb_synthesis": [vp, vp, vp, C.c_int, C.c_int, i64, vp, vp],
+        "dsr_bf_create": [C.c_int, C.c_int, C.c_int, vp], "dsr_bf_destroy": [vp], "dsr_bf_fft_len": [vp], "dsr_bf_chan_n": [vp],
+        "dsr_bf_calc_array_manifold": [vp, f64, vp], "dsr_calc_delays_polar2": [f32, f32, vp, C.c_int, vp],
+        "dsr_bf_set_diffuse_noise_model": [vp, vp, f64, f64], "dsr_bf_divide_nondiagonal": [vp, f32],
+        "dsr_bf_diagonal_loading": [vp, f32], "dsr_bf_set_noise_matrix": [vp, C.c_int, vp],
+        "dsr_bf_calc_mvdr_weights": [vp, f64, f64], "dsr_bf_calc_gsc_weights": [vp, f64, vp],
+        "dsr_bf_set_active_weights": [vp, C.c_int, vp], "dsr_bf_zero_active_weights": [vp], "dsr_bf_select": [vp, C.c_int],
+        "dsr_bf_get": [vp, C.c_int, vp, C.c_size_t], "dsr_bf_apply": [vp, vp, C.c_int, C.c_int, vp, vp],
+        "dsr_mfcc_default_cfg": [vp], "dsr_mfcc_create": [vp, vp, vp], "dsr_mfcc_destroy": [vp], "dsr_mfcc_frames": [vp, C.c_int],
+        "dsr_mfcc_out_dim": [vp], "dsr_mfcc_run": [vp, vp, vp, C.c_int, i64, C.c_int, C.c_int, vp, vp],
+        "dsr_gmm_create": [C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, vp], "dsr_gmm_load": [C.c_char_p, C.c_char_p, vp],
+        "dsr_gmm_save": [vp, C.c_char_p, C.c_char_p], "dsr_gmm_destroy": [vp], "dsr_gmm_num_dists": [vp], "dsr_gmm_dim": [vp],
+        "dsr_gmm_score": [vp, vp, i64, C.c_int, vp, vp, vp],
+        "dsr_wfst_create": [vp], "dsr_wfst_destroy": [vp], "dsr_wfst_read": [vp, C.c_char_p, C.c_int],
+        "dsr_wfst_write": [vp, C.c_char_p, C.c_int], "dsr_wfst_add_arc": [vp, C.c_uint, C.c_uint, C.c_uint, C.c_uint, f32],
+        "dsr_wfst_add_final": [vp, C.c_uint, f32], "dsr_wfst_num_nodes": [vp], "dsr_wfst_num_arcs": [vp],
+        "dsr_wfst_export": [vp] * 9,
+        "dsr_decoder_default_cfg": [vp], "dsr_decoder_create": [vp, vp], "dsr_decoder_destroy": [vp], "dsr_decoder_set": [vp, vp],
+        "dsr_decoder_set_beam": [vp, f64], "dsr_decoder_enable_dump": [vp, C.c_int],
+        "dsr_decoder_decode_batch": [vp, vp, vp, C.c_int, C.c_int, C.c_int, vp, vp, vp, C.c_int, vp],
+        "dsr_decoder_get_dump": [vp] * 7,
+        "dsr_pipe_create": [vp, vp, vp, vp, vp, vp, C.c_int, vp], "dsr_pipe_destroy": [vp],
+        "dsr_pipe_run": [vp, vp, vp, vp, C.c_int, C.c_int, i64, vp, vp, vp, C.c_int, vp],
+        "dsr_pipe_stage_ms": [vp, vp], "dsr_pipe_intermediate": [vp, C.c_int, vp, vp],
+        "dsr_memcpy_dtoh": [vp, vp, C.c_size_t, vp],
+        "dsr_device_count": [vp], "dsr_set_device": [C.c_int], "dsr_stream_synchronize": [vp],
+    }
+    for name, args in sig.items():
+        getattr(L, name).argtypes = args
+    _lib = L
+    return L
+
+
+def check(status):
+    if status != 0:
+        raise DsrError(status, (_lib.dsr_last_error() or b"").decode(errors="replace"))
+
+
+def cur_stream():
+    import torch
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _np(a, dt):
+    return np.ascontiguousarray(a, dtype=dt)
+
+
+def _ptr(a):
+    return a.ctypes.data_as(vp)
+
+
+def _dev(t):
+    return C.c_void_p(t.data_ptr())
+
+
+# ----------------------------------------------------------------------------------------------
+class FilterBank:
+    """OverSampledDFTAnalysisBank / OverSampledDFTSynthesisBank plan (btk/modulated/modulated.h:291-360)."""
+
+    def __init__(self, prototype, M, m, r, synthesis=False, delayCompensationType=0, gainFactor=1):
+        L = load()
+        p = _np(prototype, np.float64)
+        if p.size != M * m:
+            raise DsrError(4, "Prototype sizes do not match (%d vs. %d)." % (p.size, M * m))   # modulated.cc:268-270
+        self.h = vp()
+        check(L.dsr_fb_create(_ptr(p), M, m, r, int(synthesis), delayCompensationType, gainFactor, C.byref(self.h)))
+        self.M, self.m, self.r, self.D, self.synthesis = M, m, r, M >> r, synthesis
+        self.pd = L.dsr_fb_processing_delay(self.h)
+
+    def __del__(self):
+        if _lib is not None and getattr(self, "h", None):
+            _lib.dsr_fb_destroy(self.h)
+
+    def frames(self, nsamp):
+        return _lib.dsr_fb_analysis_frames(self.h, int(nsamp))
+
+    def blocks(self, nframes):
+        return _lib.dsr_fb_synthesis_blocks(self.h, int(nframes))
+
+    def analysis(self, x, nsamp=None):
+        """x: cuda float32 [U][C][N] -> complex64 [U][C][Tmax][M/2+1]"""
+        import torch
+        U, Cn, N = x.shape
+        if nsamp is None:
+            nsamp = torch.full((U,), N, dtype=torch.int32, device=x.device)
+        Tmax = max(1, max(self.frames(int(n)) for n in nsamp.tolist()))
+        X = torch.empty((U, Cn, Tmax, self.M // 2 + 1, 2), dtype=torch.float32, device=x.device)
+        check(_lib.dsr_fb_analysis(self.h, _dev(x), _dev(nsamp), U, Cn, N, Tmax, _dev(X), cur_stream()))
+        return torch.view_as_complex(X)
+
+    def synthesis_run(self, Y, nframes=None):
+        """Y: cuda complex64 [U][Tmax][M/2+1] -> float32 [U][nblocks*D]"""
+        import torch
+        U, Tmax, F = Y.shape
+        if nframes is None:
+            nframes = torch.full((U,), Tmax, dtype=torch.int32, device=Y.device)
+        nb = max(1, max(self.blocks(int(n)) for n in nframes.tolist()))
+        y = torch.zeros((U, nb * self.D), dtype=torch.float32, device=Y.device)
+        Yr = torch.view_as_real(Y.contiguous())
+        check(_lib.dsr_fb_synthesis(self.h, _dev(Yr), _dev(nframes), U, Tmax, nb * self.D, _dev(y), cur_stream()))
+        return y
+
+
+class Beamformer:
+    """beamformerWeights + SubbandDS/GSC/MVDR weight design and apply (btk/beamformer/beamformer.h)."""
+
+    def __init__(self, fftLen, chanN, halfBandShift=False):
+        L = load()
+        self.h = vp(); self.M, self.C = fftLen, chanN
+        check(L.dsr_bf_create(fftLen, chanN, int(halfBandShift), C.byref(self.h)))
+
+    def __del__(self):
+        if _lib is not None and getattr(self, "h", None):
+            _lib.dsr_bf_destroy(self.h)
+
+    def calcArrayManifoldVectors(self, sampleRate, delays):
+        d = _np(delays, np.float64)
+        if d.size != self.C:
+            raise DsrError(5, "Number of delays does not match number of channels (%d vs. %d)." % (d.size, self.C))
+        check(_lib.dsr_bf_calc_array_manifold(self.h, sampleRate, _ptr(d)))
+
+    def setDiffuseNoiseModel(self, micPositions, sampleRate, sspeed=343740.0):
+        mp = _np(micPositions, np.float64)
+        check(_lib.dsr_bf_set_diffuse_noise_model(self.h, _ptr(mp), sampleRate, sspeed))
+
+    def divideAllNonDiagonalElements(self, myu):
+        check(_lib.dsr_bf_divide_nondiagonal(self.h, myu))
+
+    def setAllLevelsOfDiagonalLoading(self, w):
+        check(_lib.dsr_bf_diagonal_loading(self.h, w))
+
+    def setNoiseSpatialSpectralMatrix(self, fbinX, Rnn):
+        R = _np(Rnn, np.complex128)
+        check(_lib.dsr_bf_set_noise_matrix(self.h, fbinX, _ptr(R)))
+
+    def calcMVDRWeights(self, sampleRate, dThreshold=1.0e-8):
+        check(_lib.dsr_bf_calc_mvdr_weights(self.h, sampleRate, dThreshold))
+
+    def calcGSCWeights(self, sampleRate, delays):
+        d = _np(delays, np.float64)
+        check(_lib.dsr_bf_calc_gsc_weights(self.h, sampleRate, _ptr(d)))
+
+    def setActiveWeights_f(self, fbinX, packedWeight):
+        w = _np(packedWeight, np.float64)
+        if w.size != 2 * (self.C - 1):
+            raise DsrError(5, "the size of an active weight vector must be %d but it is %d" % (2 * (self.C - 1), w.size))
+        check(_lib.dsr_bf_set_active_weights(self.h, fbinX, _ptr(w)))
+
+    def zeroActiveWeights(self):
+        check(_lib.dsr_bf_zero_active_weights(self.h))
+
+    def select(self, mode):
+        check(_lib.dsr_bf_select(self.h, {"ds": 0, "mvdr": 1, "gsc": 2, "gsc_norm": 3}.get(mode, mode)))
+
+    def get(self, kind):
+        F = self.M // 2 + 1
+        shape = {0: (self.M, self.C), 1: (F, self.C), 2: (F, self.C, self.C), 3: (self.M, self.C, self.C - 1), 4: (F, self.C)}[kind]
+        out = np.zeros(shape, np.complex128)
+        check(_lib.dsr_bf_get(self.h, kind, _ptr(out), out.size * 2))
+        return out
+
+    def apply(self, X):
+        """X: cuda complex64 [U][C][T][F] -> [U][T][F]"""
+        import torch
+        U, Cn, T, F = X.shape
+        Y = torch.empty((U, T, F, 2), dtype=torch.float32, device=X.device)
+        check(_lib.dsr_bf_apply(self.h, _dev(torch.view_as_real(X.contiguous())), U, T, _dev(Y), cur_stream()))
+        return torch.view_as_complex(Y)
+
+
+def calcDelaysPolar2(azimuth, elevation, micPositions):
+    load()
+    mp = _np(micPositions, np.float64); d = np.zeros(mp.shape[0], np.float64)
+    check(_lib.dsr_calc_delays_polar2(azimuth, elevation, _ptr(mp), mp.shape[0], _ptr(d)))
+    return d
+
+
+class Mfcc:
+    def __init__(self, lda=None, **kw):
+        L = load()
+        self.cfg = MfccCfg(); L.dsr_mfcc_default_cfg(C.byref(self.cfg))
+        for k, v in kw.items():
+            setattr(self.cfg, k, v)
+        if lda is None and "outDim" not in kw:
+            self.cfg.outDim = 0
+        a = _np(lda, np.float32) if lda is not None else None
+        self.h = vp()
+        check(L.dsr_mfcc_create(C.byref(self.cfg), _ptr(a) if a is not None else None, C.byref(self.h)))
+        self.outDim = L.dsr_mfcc_out_dim(self.h)
+
+    def __del__(self):
+        if _lib is not None and getattr(self, "h", None):
+            _lib.dsr_mfcc_destroy(self.h)
+
+    def frames(self, nsamp):
+        return _lib.dsr_mfcc_frames(self.h, int(nsamp))
+
+    def run(self, y, nsamp=None, stage=0):
+        """y: cuda float32 [U][N] -> float32 [U][Tmax][dim]"""
+        import torch
+        U, N = y.shape
+        if nsamp is None:
+            nsamp = torch.full((U,), N, dtype=torch.int32, device=y.device)
+        c = self.cfg
+        raw = lambda n: ((n + c.shiftLen - 1) // c.shiftLen) if c.padZeros else max(0, -(-(n - c.blockLen) // c.shiftLen))
+        Tmax = max(1, max(raw(int(n)) for n in nsamp.tolist()))
+        dim = {0: self.outDim, 1: c.ncep, 2: c.ncep, 3: c.filterN, 4: c.powN}[stage]
+        out = torch.zeros((U, Tmax, dim), dtype=torch.float32, device=y.device)
+        check(_lib.dsr_mfcc_run(self.h, _dev(y), _dev(nsamp), U, N, Tmax, stage, _dev(out), cur_stream()))
+        return out
+
+
+class Gmm:
+    def __init__(self, refN=None, mean=None, ivar=None, det=None, val=None, scale=None, files=None):
+        L = load(); self.h = vp()
+        if files is not None:
+            check(L.dsr_gmm_load(files[0].encode(), files[1].encode(), C.byref(self.h)))
+        else:
+            r = _np(refN, np.int32); m = _np(mean, np.float32); iv = _np(ivar, np.float32); d = _np(det, np.float32); v = _np(val, np.float32)
+            s = _np(scale, np.float32) if scale is not None else None
+            check(L.dsr_gmm_create(len(r), m.shape[1], _ptr(r), _ptr(m), _ptr(iv), _ptr(d), _ptr(v), _ptr(s) if s is not None else None, C.byref(self.h)))
+        self.K = L.dsr_gmm_num_dists(self.h); self.D = L.dsr_gmm_dim(self.h)
+
+    def __del__(self):
+        if _lib is not None and getattr(self, "h", None):
+            _lib.dsr_gmm_destroy(self.h)
+
+    def save(self, cbFile, dsFile):
+        check(_lib.dsr_gmm_save(self.h, cbFile.encode(), dsFile.encode()))
+
+    def score(self, x, mode=0, want_argmin=True):
+        """x: cuda float32 [N][D] -> (score [N][K] float32, argmin [N][K] uint8)"""
+        import torch
+        N = x.shape[0]
+        sc = torch.empty((N, self.K), dtype=torch.float32, device=x.device)
+        am = torch.zeros((N, self.K), dtype=torch.uint8, device=x.device) if want_argmin and mode != 1 else None
+        check(_lib.dsr_gmm_score(self.h, _dev(x), N, mode, _dev(sc), _dev(am) if am is not None else None, cur_stream()))
+        return sc, am
+
+
+class Wfst:
+    """WFSTFlyWeight (asr/decoder/wfstFlyWeight.h:47-119)."""
+
+    def __init__(self):
+        L = load(); self.h = vp(); check(L.dsr_wfst_create(C.byref(self.h)))
+
+    def __del__(self):
+        if _lib is not None and getattr(self, "h", None):
+            _lib.dsr_wfst_destroy(self.h)
+
+    def read(self, fileName, binary=False):
+        check(_lib.dsr_wfst_read(self.h, fileName.encode(), int(binary)))
+
+    def write(self, fileName, binary=True):
+        check(_lib.dsr_wfst_write(self.h, fileName.encode(), int(binary)))
+
+    def add_arc(self, s1, s2, i, o, cost=0.0):
+        check(_lib.dsr_wfst_add_arc(self.h, s1, s2, i, o, cost))
+
+    def add_final(self, s, cost=0.0):
+        check(_lib.dsr_wfst_add_final(self.h, s, cost))
+
+    def export(self):
+        n = _lib.dsr_wfst_num_nodes(self.h); a = _lib.dsr_wfst_num_arcs(self.h)
+        d = dict(nodeState=np.zeros(n, np.uint32), nodeFinal=np.zeros(n, np.int32), nodeCost=np.zeros(n, np.float32),
+                 arcOff=np.zeros(n + 1, np.int32), arcDst=np.zeros(max(a, 1), np.int32), arcIn=np.zeros(max(a, 1), np.uint32),
+                 arcOut=np.zeros(max(a, 1), np.uint32), arcCost=np.zeros(max(a, 1), np.float32))
+        check(_lib.dsr_wfst_export(self.h, *[_ptr(d[k]) for k in ("nodeState", "nodeFinal", "nodeCost", "arcOff", "arcDst", "arcIn", "arcOut", "arcCost")]))
+        for k in ("arcDst", "arcIn", "arcOut", "arcCost"):
+            d[k] = d[k][:a]
+        return d
+
+
+class Decoder:
+    """DecoderFlyWeight (asr/decoder/decoder.i:147-199) for batches of score matrices."""
+
+    def __init__(self, beam=100.0, lmScale=12.0, lmPenalty=0.0, silPenalty=0.0, silenceX=0xFFFFFFFF, maxActive=0,
+                 maxCandidates=0, arenaTokens=0, streams=0):
+        L = load(); c = DecoderCfg(); L.dsr_decoder_default_cfg(C.byref(c))
+        c.beam, c.lmScale, c.lmPenalty, c.silPenalty, c.silenceX = beam, lmScale, lmPenalty, silPenalty, silenceX
+        c.maxActive, c.maxCandidates, c.arenaTokens, c.streams = maxActive, maxCandidates, arenaTokens, streams
+        self.h = vp(); check(L.dsr_decoder_create(C.byref(c), C.byref(self.h))); self._g = None
+
+    def __del__(self):
+        if _lib is not None and getattr(self, "h", None):
+            _lib.dsr_decoder_destroy(self.h)
+
+    def set(self, wfst):
+        check(_lib.dsr_decoder_set(self.h, wfst.h)); self._g = wfst
+
+    def setBeam(self, beam):
+        check(_lib.dsr_decoder_set_beam(self.h, beam))
+
+    def enable_dump(self, on=True):
+        check(_lib.dsr_decoder_enable_dump(self.h, int(on)))
+
+    def decode_batch(self, scores, nframes=None, maxPath=None):
+        """scores: cuda float32 [U][T][nDist].  Returns list of dicts."""
+        import torch
+        U, T, nDist = scores.shape
+        if nframes is None:
+            nframes = torch.full((U,), T, dtype=torch.int32, device=scores.device)
+        if maxPath is None:
+            maxPath = 4 * T + 64
+        res = (DecodeResult * U)()
+        arcs = np.zeros((U, maxPath), np.int32); words = np.zeros((U, maxPath), np.uint32)
+        check(_lib.dsr_decoder_decode_batch(self.h, _dev(scores), _dev(nframes), U, T, nDist, C.byref(res), _ptr(arcs), _ptr(words), maxPath, cur_stream()))
+        out = []
+        for u in range(U):
+            r = res[u]
+            out.append(dict(status=r.status, score=r.score, ac=r.ac, lm=r.lm, frames=r.frames, reachedFinal=bool(r.reachedFinal),
+                            arcs=arcs[u, :min(r.nArcs, maxPath)].copy(), words=words[u, :min(r.nWords, maxPath)].copy(),
+                            activeHypos=r.activeHypos, maxActive=r.maxActiveSeen))
+        return out
+
+    def get_dump(self):
+        n = i64(); fo = C.POINTER(i64)(); nd = C.POINTER(i32)(); ac = C.POINTER(f32)(); lm = C.POINTER(f32)(); arc = C.POINTER(i32)()
+        check(_lib.dsr_decoder_get_dump(self.h, C.byref(n), C.byref(fo), C.byref(nd), C.byref(ac), C.byref(lm), C.byref(arc)))
+        nf = n.value
+        off = np.array([fo[i] for i in range(nf + 1)], np.int64) if nf > 0 else np.zeros(1, np.int64)
+        N = int(off[-1])
+        g = lambda p, dt: np.ctypeslib.as_array(p, (N,)).astype(dt).copy() if N > 0 else np.zeros(0, dt)
+        return dict(frameOff=off, node=g(nd, np.int32), ac=g(ac, np.float32), lm=g(lm, np.float32), arc=g(arc, np.int32))
+
+
+class Pipe:
+    def __init__(self, ana, syn, bf, mfcc, gmm, dec, gmmMode=0):
+        L = load(); self.h = vp(); self._keep = (ana, syn, bf, mfcc, gmm, dec)
+        check(L.dsr_pipe_create(ana.h, syn.h, bf.h, mfcc.h, gmm.h, dec.h, gmmMode, C.byref(self.h)))
+
+    def __del__(self):
+        if _lib is not None and getattr(self, "h", None):
+            _lib.dsr_pipe_destroy(self.h)
+
+    def run(self, x, nsamp_dev, nsamp_host, maxPath=4096, want_paths=True):
+        U, Cn, N = x.shape
+        res = (DecodeResult * U)()
+        ns = _np(nsamp_host, np.int32)
+        arcs = np.zeros((U, maxPath), np.int32) if want_paths else None
+        words = np.zeros((U, maxPath), np.uint32) if want_paths else None
+        check(_lib.dsr_pipe_run(self.h, _dev(x), _dev(nsamp_dev), _ptr(ns), U, Cn, N, C.byref(res),
+                                _ptr(arcs) if want_paths else None, _ptr(words) if want_paths else None, maxPath, cur_stream()))
+        return res, arcs, words
+
+    def stage_ms(self):
+        ms = (f32 * 6)(); check(_lib.dsr_pipe_stage_ms(self.h, ms)); return list(ms)
+
+    def intermediate(self, which):
+        p = vp(); n = i64(); check(_lib.dsr_pipe_intermediate(self.h, which, C.byref(p), C.byref(n))); return p.value, n.value
+
+    def intermediate_host(self, which, dtype=np.float32):
+        p, n = self.intermediate(which)
+        out = np.zeros(n // np.dtype(dtype).itemsize, dtype)
+        check(_lib.dsr_memcpy_dtoh(_ptr(out), vp(p), n, cur_stream()))
+        return out

@@ -1,0 +1,296 @@
+/*
+ * include/dsr.h -- C-ABI of libdsr_hip.so: the MI355X (gfx950) implementation of the
+ * BTK -> ASR front-end-to-decode hot path of mmdagent/distantspeechrecognition-mirror.
+ *
+ * Boundary rules
+ *   - extern "C", opaque handles, plain pointers and sizes; no C++/torch types.
+ *   - "dev" pointers are device (HBM) addresses owned by the caller; "host" pointers are
+ *     ordinary host memory.  `stream` is a hipStream_t passed as void* (NULL = default).
+ *   - every function returns a dsr_status: 0 = OK, otherwise 1 + the reference's
+ *     error_type (btk/common/jexception.h:41-57), so JITERATOR ("end of stream",
+ *     which the reference signals by exception) is DSR_E_ITERATOR.  The text of the
+ *     last error on the calling thread is returned by dsr_last_error().
+ *   - the library has no CPU fallback: without a usable HIP device every compute
+ *     entry point fails with DSR_E_INITIALIZATION.
+ *
+ * Each entry point names the reference interface it replaces (file:line under
+ * /root/reference).  INTEGRATION.md shows the SWIG/ctypes stubs a maintainer would add.
+ */
+#ifndef DSR_H
+#define DSR_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef int dsr_status;
+enum {
+  DSR_OK = 0,
+  DSR_E_ERROR = 1,          /* JERROR          */
+  DSR_E_ALLOCATION = 2,     /* JALLOCATION     */
+  DSR_E_ARITHMETIC = 3,     /* JARITHMETIC     */
+  DSR_E_CONSISTENCY = 4,    /* JCONSISTENCY    */
+  DSR_E_DIMENSION = 5,      /* JDIMENSION      */
+  DSR_E_INDEX = 6,          /* JINDEX          */
+  DSR_E_INITIALIZATION = 7, /* JINITIALIZATION */
+  DSR_E_IO = 8,             /* JIO             */
+  DSR_E_ITERATOR = 9,       /* JITERATOR: end of stream */
+  DSR_E_PYTHON = 10,        /* JPYTHON         */
+  DSR_E_KEY = 11,           /* JKEY            */
+  DSR_E_NUMERIC = 12,       /* JNUMERIC        */
+  DSR_E_PARAMETER = 13,     /* JPARAMETER      */
+  DSR_E_PARSE = 14,         /* JPARSE          */
+  DSR_E_TYPE = 15           /* JTYPE           */
+};
+
+const char* dsr_last_error(void);
+const char* dsr_version(void);
+/* number of HIP devices visible; selects `device` for the calling thread */
+dsr_status dsr_device_count(int* n);
+dsr_status dsr_set_device(int device);
+dsr_status dsr_stream_synchronize(void* stream);
+/* utility for callers without their own HIP binding: synchronous device -> host copy */
+dsr_status dsr_memcpy_dtoh(void* dst_host, const void* src_dev, size_t bytes, void* stream);
+
+/* =====================================================================================
+ * 1. Modulated (uniform DFT) filter banks
+ *    replaces OverSampledDFTAnalysisBank / OverSampledDFTSynthesisBank
+ *    (btk/modulated/modulated.h:291-321, modulated.cc:360-516, 521-674)
+ * ===================================================================================== */
+typedef struct dsr_fb dsr_fb;
+/* prototype: m*M taps (host, double, copied as the reference copies it, modulated.cc:275-276).
+   delayCompensationType 0/1/2 (modulated.cc:279-296), gainFactor as modulated.cc:444-448,660-661.
+   M must be a power of two in [16, 2048] and D = M >> r >= 1. */
+dsr_status dsr_fb_create(const double* prototype, int M, int m, int r, int synthesis,
+                         int delayCompensationType, int gainFactor, dsr_fb** out);
+void       dsr_fb_destroy(dsr_fb*);
+/* frame bookkeeping of the reference (modulated.cc:461-516, 626-664) */
+int dsr_fb_analysis_frames(const dsr_fb*, int nsamp);       /* ceil(n/D)-laN+processingDelay */
+int dsr_fb_synthesis_blocks(const dsr_fb*, int nframes);    /* nframes-processingDelay (>=0) */
+int dsr_fb_processing_delay(const dsr_fb*);
+int dsr_fb_block_len(const dsr_fb*);                        /* D = M >> r */
+/* Batched analysis over U utterances x C channels.
+ *   x_dev     [U][C][sampStride] fp32 samples (SampleFeature with blockLen=shiftLen=D, padZeros)
+ *   nsamp_dev [U] int32 valid samples per utterance
+ *   X_dev     [U][C][Tmax][M/2+1] complex64 (re,im); frames t >= T_u are zero filled.
+ * Only bins 0..M/2 are stored: the input is real, bin M-f is conj(bin f) (beamformer.cc:2609-2631
+ * consumes exactly these). */
+dsr_status dsr_fb_analysis(const dsr_fb*, const float* x_dev, const int32_t* nsamp_dev, int U, int C,
+                           int64_t sampStride, int Tmax, float* X_dev, void* stream);
+/* Batched synthesis.
+ *   Y_dev      [U][Tmax][M/2+1] complex64, nframes_dev [U] valid frames
+ *   y_dev      [U][outStride] fp32: blocks 0..nframes-pd-1 of D samples; the rest zero filled */
+dsr_status dsr_fb_synthesis(const dsr_fb*, const float* Y_dev, const int32_t* nframes_dev, int U,
+                            int Tmax, int64_t outStride, float* y_dev, void* stream);
+
+/* =====================================================================================
+ * 2. Subband beamformers
+ *    replaces beamformerWeights / SubbandDS / SubbandGSC / SubbandMVDR
+ *    (btk/beamformer/beamformer.h:49-118,120-223,316-383; beamformer.cc:531-594,1137-1200,
+ *     1297-1447,2321-2635)
+ * ===================================================================================== */
+typedef struct dsr_bf dsr_bf;
+dsr_status dsr_bf_create(int fftLen, int chanN, int halfBandShift, dsr_bf** out);
+void       dsr_bf_destroy(dsr_bf*);
+int        dsr_bf_fft_len(const dsr_bf*);
+int        dsr_bf_chan_n(const dsr_bf*);
+/* calcArrayManifoldVectors (beamformer.cc:531-594): delays[chanN] seconds */
+dsr_status dsr_bf_calc_array_manifold(dsr_bf*, double sampleRate, const double* delays);
+/* calcDelaysPolar2 of the reference driver (btk/src/superdirectiveBeamformer.cc:118-137) */
+dsr_status dsr_calc_delays_polar2(float azimuth, float elevation, const double* micPos /*[C][3]*/,
+                                  int chanN, double* delays);
+/* SubbandMVDR::setDiffuseNoiseModel / divideAllNonDiagonalElements / setAllLevelsOfDiagonalLoading /
+   setNoiseSpatialSpectralMatrix / calcMVDRWeights (beamformer.cc:2392-2581, beamformer.h:362-378) */
+dsr_status dsr_bf_set_diffuse_noise_model(dsr_bf*, const double* micPos /*[C][3]*/, double sampleRate, double sspeed);
+dsr_status dsr_bf_divide_nondiagonal(dsr_bf*, float myu);
+dsr_status dsr_bf_diagonal_loading(dsr_bf*, float diagonalWeight);
+dsr_status dsr_bf_set_noise_matrix(dsr_bf*, int fbinX, const double* Rnn /*[C][C] complex*/);
+dsr_status dsr_bf_calc_mvdr_weights(dsr_bf*, double sampleRate, double dThreshold);
+/* SubbandGSC: calcGSCWeights (blocking matrices), setActiveWeights_f, zeroActiveWeights
+   (beamformer.cc:1373-1447, 761-799, 398-479) */
+dsr_status dsr_bf_calc_gsc_weights(dsr_bf*, double sampleRate, const double* delays);
+dsr_status dsr_bf_set_active_weights(dsr_bf*, int fbinX, const double* packedWeight /*2*(C-1)*/);
+dsr_status dsr_bf_zero_active_weights(dsr_bf*);
+/* which weight set `apply` uses: 0 = delay-and-sum wq, 1 = MVDR, 2 = GSC (wq - B wa), 3 = GSC normalised */
+dsr_status dsr_bf_select(dsr_bf*, int mode);
+/* read back host copies: kind 0 = wq [fftLen][C], 1 = mvdr [fftLen/2+1][C], 2 = R [fftLen/2+1][C][C],
+   3 = blocking matrix [fftLen][C][C-1], 4 = effective weights in use [fftLen/2+1][C]; complex double */
+dsr_status dsr_bf_get(const dsr_bf*, int kind, double* out, size_t outDoubles);
+/* Y[u][t][f] = w_f^H X[u][:][t][f], f = 0..M/2 (SubbandDS::next / SubbandMVDR::next / SubbandGSC::next) */
+dsr_status dsr_bf_apply(dsr_bf*, const float* X_dev, int U, int Tmax, float* Y_dev, void* stream);
+
+/* =====================================================================================
+ * 3. MFCC feature chain
+ *    replaces SampleFeature(block framing) -> PreemphasisFeature -> HammingFeature -> FFTFeature ->
+ *    SpectralPowerFeature -> VTLNFeature -> MelFeature -> LogFeature -> CepstralFeature ->
+ *    StorageFeature -> MeanSubtractionFeature -> AdjacentFeature -> LinearTransformFeature
+ *    (btk/feature/feature.cc:610-659,1154-1355,1705-2298,2398-2503,2530-2987)
+ * ===================================================================================== */
+typedef struct {
+  int blockLen, shiftLen, padZeros;   /* SampleFeature (feature.i:526-528): 320,160,false */
+  double mu;                          /* PreemphasisFeature: 0.95; <0 disables the operator */
+  int fftLen, powN;                   /* 512, 257 */
+  double vtlnRatio, vtlnEdge; int vtlnVersion;   /* 1.0,1.0,1; version 0 disables VTLN */
+  float rate, low, up; int filterN, melVersion;  /* 16000,0,0(->rate/2),30,1 */
+  double logM, logA; int sphinxFlooring;         /* 1,1,0 */
+  int ncep, dctType;                  /* 13, 1 */
+  int cmnMode; double devNormFactor;  /* 0 none, 1 batch, 2 run-on (feature.cc:2573-2744) */
+  int delta;                          /* AdjacentFeature: 7 (0 disables) */
+  int outDim;                         /* LinearTransformFeature rows; 0 disables */
+} dsr_mfcc_cfg;
+void dsr_mfcc_default_cfg(dsr_mfcc_cfg*);
+typedef struct dsr_mfcc dsr_mfcc;
+/* lda: [outDim][(2delta+1)*ncep] row major fp32 (host) or NULL when outDim == 0 */
+dsr_status dsr_mfcc_create(const dsr_mfcc_cfg*, const float* lda, dsr_mfcc** out);
+void       dsr_mfcc_destroy(dsr_mfcc*);
+int dsr_mfcc_frames(const dsr_mfcc*, int nsamp);   /* frames the chain yields for nsamp samples */
+int dsr_mfcc_out_dim(const dsr_mfcc*);
+/* y_dev [U][sampStride] fp32, nsamp_dev [U]; feat_dev [U][Tmax][outDim] fp32 (rows >= T_u zero).
+   stage: 0 = final, 1 = cepstra before CMN, 2 = after CMN, 3 = log-mel, 4 = power (as float) */
+dsr_status dsr_mfcc_run(dsr_mfcc*, const float* y_dev, const int32_t* nsamp_dev, int U, int64_t sampStride,
+                        int Tmax, int stage, float* feat_dev, void* stream);
+
+/* =====================================================================================
+ * 4. Diagonal-covariance GMM scoring
+ *    replaces CodebookSetBasic / DistribSetBasic and Distrib::score
+ *    (asr/gaussian/codebookBasic.cc:258-309,431-554,645-766,906-960; distribBasic.cc:32-41,103-166)
+ * ===================================================================================== */
+typedef struct dsr_gmm dsr_gmm;
+/* K codebooks; refN[k] Gaussians (<= 256, codebookBasic.h:41); mean/ivar [G][dimN]; det [G];
+   val [G] = -log w of the (1:1) distribution; scale[K] or NULL (=1).  All host pointers. */
+dsr_status dsr_gmm_create(int K, int dimN, const int32_t* refN, const float* mean, const float* ivar,
+                          const float* det, const float* val, const float* scale, dsr_gmm** out);
+/* big-endian model files written by CodebookSetBasic::save / DistribSetBasic::save */
+dsr_status dsr_gmm_load(const char* codebookFile, const char* distribFile, dsr_gmm** out);
+dsr_status dsr_gmm_save(const dsr_gmm*, const char* codebookFile, const char* distribFile);
+void       dsr_gmm_destroy(dsr_gmm*);
+int dsr_gmm_num_dists(const dsr_gmm*);
+int dsr_gmm_dim(const dsr_gmm*);
+/* x_dev [N][dimN] fp32 -> score_dev [N][K] fp32 (cost), argmin_dev [N][K] u8 or NULL.
+   mode 0: _scoreOpt nearest Gaussian, bit-exact reference order; mode 1: _scoreAll log-sum;
+   mode 2: _scoreOpt through the fp32-MFMA candidate search + exact re-score (same bits as mode 0) */
+dsr_status dsr_gmm_score(dsr_gmm*, const float* x_dev, int64_t N, int mode, float* score_dev,
+                         uint8_t* argmin_dev, void* stream);
+
+/* =====================================================================================
+ * 5. Static decoding graph + Viterbi token passing
+ *    replaces WFSTFlyWeight (asr/decoder/wfstFlyWeight.h:47-252, .cc:63-139,299-463) and
+ *    DecoderFlyWeight / _Decoder (asr/decoder/decoder.h:325-1102,1127-1139; decoder.i:147-199)
+ * ===================================================================================== */
+typedef struct dsr_wfst dsr_wfst;
+dsr_status dsr_wfst_create(dsr_wfst** out);
+void       dsr_wfst_destroy(dsr_wfst*);
+dsr_status dsr_wfst_read(dsr_wfst*, const char* fileName, int binary);    /* WFSTFlyWeight::read */
+dsr_status dsr_wfst_write(const dsr_wfst*, const char* fileName, int binary);
+dsr_status dsr_wfst_add_arc(dsr_wfst*, unsigned s1, unsigned s2, unsigned input, unsigned output, float cost);
+dsr_status dsr_wfst_add_final(dsr_wfst*, unsigned state, float cost);
+int dsr_wfst_num_nodes(const dsr_wfst*);
+int dsr_wfst_num_arcs(const dsr_wfst*);
+/* iteration-order export (node 0 = initial; arcs CSR in the order Node::Iterator visits them) */
+dsr_status dsr_wfst_export(const dsr_wfst*, uint32_t* nodeState, int32_t* nodeFinal, float* nodeCost,
+                           int32_t* arcOff, int32_t* arcDst, uint32_t* arcIn, uint32_t* arcOut, float* arcCost);
+
+typedef struct {
+  double beam, lmScale, lmPenalty, silPenalty;   /* decoder.i:191-199: 100, 12, 0, 0 */
+  uint32_t silenceX;        /* input-lexicon index of silSymbol (decoder.h:740-745) */
+  int maxActive;            /* token capacity per frame  (0 = default 65536)  */
+  int maxCandidates;        /* placements per frame      (0 = default 8*maxActive) */
+  int64_t arenaTokens;      /* back-pointer records per utterance (0 = default 64 * frames * 1024) */
+  int streams;              /* concurrent utterance slots (0 = default 2 per CU) */
+} dsr_decoder_cfg;
+void dsr_decoder_default_cfg(dsr_decoder_cfg*);
+typedef struct dsr_decoder dsr_decoder;
+dsr_status dsr_decoder_create(const dsr_decoder_cfg*, dsr_decoder** out);
+void       dsr_decoder_destroy(dsr_decoder*);
+dsr_status dsr_decoder_set(dsr_decoder*, const dsr_wfst*);               /* DecoderFlyWeight::set */
+dsr_status dsr_decoder_set_beam(dsr_decoder*, double beam);
+typedef struct {
+  double  score;        /* decode() return value: double(ac)+double(lm) of the best token */
+  float   ac, lm;
+  int32_t frames;       /* _frameX after decode (= T-1) */
+  int32_t reachedFinal; /* traceBackSucceeded() */
+  int32_t nArcs;        /* arcs on the best path incl. epsilon arcs */
+  int32_t nWords;       /* output symbols != 0 */
+  int32_t status;       /* per-utterance dsr_status (capacity overflow => DSR_E_ALLOCATION) */
+  int32_t maxActiveSeen;
+  int64_t activeHypos;  /* sum over frames of |_next| (decoder.h:413) */
+} dsr_decode_result;
+/* Batched decode.  score_dev [U][Tmax][nDist] fp32 costs (row t = Distrib::score(t)), nframes_dev [U].
+ * Host outputs: res[U]; arcs_out [U][maxPath] (export arc ids, first..last), words_out [U][maxPath]
+ * (bestHypo output ids).  arcs_out/words_out may be NULL. */
+dsr_status dsr_decoder_decode_batch(dsr_decoder*, const float* score_dev, const int32_t* nframes_dev, int U,
+                                    int Tmax, int nDist, dsr_decode_result* res, int32_t* arcs_out,
+                                    uint32_t* words_out, int maxPath, void* stream);
+/* debug/parity: per-frame token list (list order) of utterance 0 of the last decode with
+   cfg.streams == 1 and dumpFrames enabled through dsr_decoder_enable_dump(). */
+dsr_status dsr_decoder_enable_dump(dsr_decoder*, int enable);
+dsr_status dsr_decoder_get_dump(dsr_decoder*, int64_t* nFrames, const int64_t** frameOff, const int32_t** node,
+                                const float** ac, const float** lm, const int32_t** arc);
+
+/* =====================================================================================
+ * 6. Whole pipe: 8-ch analysis -> MVDR -> synthesis -> MFCC -> GMM -> Viterbi
+ *    (the call sequence of SURVEY.md Appendix C.2-C.4 for a batch of utterances)
+ * ===================================================================================== */
+typedef struct dsr_pipe dsr_pipe;
+dsr_status dsr_pipe_create(const dsr_fb* analysis, const dsr_fb* synthesis, dsr_bf* bf, dsr_mfcc* mfcc,
+                           dsr_gmm* gmm, dsr_decoder* dec, int gmmMode, dsr_pipe** out);
+void       dsr_pipe_destroy(dsr_pipe*);
+/* x_dev [U][C][sampStride]; results as dsr_decoder_decode_batch.  Intermediates live in a workspace
+   the pipe grows on demand (never inside a timed region after the first call of a given shape). */
+dsr_status dsr_pipe_run(dsr_pipe*, const float* x_dev, const int32_t* nsamp_dev, const int32_t* nsamp_host,
+                        int U, int C, int64_t sampStride, dsr_decode_result* res, int32_t* arcs_out,
+                        uint32_t* words_out, int maxPath, void* stream);
+/* per-stage device time of the last run in milliseconds: [analysis, beamform, synthesis, mfcc, gmm, viterbi] */
+dsr_status dsr_pipe_stage_ms(const dsr_pipe*, float ms[6]);
+/* device pointers to the intermediates of the last run (borrowed): 0 X, 1 Y, 2 y, 3 feat, 4 scores */
+dsr_status dsr_pipe_intermediate(const dsr_pipe*, int which, void** dev, int64_t* bytes);
+
+/* =====================================================================================
+ * 7. Stream/feature-operator API  (FeatureStream<Type,item>::next/reset/size/name/current/isEnd,
+ *    btk/stream/stream.h:36-75).  Operators are reference counted handles that hold their
+ *    upstream(s); next() returns a pointer to the operator's own output buffer (host memory),
+ *    valid until the next call, exactly as the reference's _vector.
+ * ===================================================================================== */
+typedef struct dsr_stream dsr_stream;
+enum { DSR_T_CHAR = 0, DSR_T_SHORT = 1, DSR_T_FLOAT = 2, DSR_T_DOUBLE = 3, DSR_T_COMPLEX = 4 };
+dsr_status dsr_stream_next(dsr_stream*, int frameX /* -5 = next */, const void** data, size_t* n);
+dsr_status dsr_stream_current(dsr_stream*, const void** data, size_t* n);
+dsr_status dsr_stream_reset(dsr_stream*);
+int          dsr_stream_size(const dsr_stream*);
+int          dsr_stream_type(const dsr_stream*);
+int          dsr_stream_frameX(const dsr_stream*);
+int          dsr_stream_is_end(const dsr_stream*);
+const char*  dsr_stream_name(const dsr_stream*);
+void         dsr_stream_retain(dsr_stream*);
+void         dsr_stream_release(dsr_stream*);
+/* sources */
+dsr_status dsr_sample_feature_create(int blockLen, int shiftLen, int padZeros, const char* name, dsr_stream** out);
+dsr_status dsr_sample_feature_set_samples(dsr_stream*, const float* samples, size_t n, unsigned sampleRate);
+/* operators (ctor argument order as the reference headers) */
+dsr_status dsr_analysis_bank_create(dsr_stream* samp, const double* prototype, int M, int m, int r,
+                                    int delayCompensationType, const char* name, dsr_stream** out);
+dsr_status dsr_synthesis_bank_create(dsr_stream* samp, const double* prototype, int M, int m, int r,
+                                     int delayCompensationType, int gainFactor, const char* name, dsr_stream** out);
+/* SubbandDS/GSC/MVDR as a stream: channels are analysis-bank streams (setChannel) */
+dsr_status dsr_subband_bf_create(dsr_bf* weights, const char* name, dsr_stream** out);
+dsr_status dsr_subband_bf_set_channel(dsr_stream* bf, dsr_stream* chan);
+dsr_status dsr_preemphasis_create(dsr_stream* samp, double mu, const char* name, dsr_stream** out);
+dsr_status dsr_hamming_create(dsr_stream* samp, const char* name, dsr_stream** out);
+dsr_status dsr_fft_create(dsr_stream* samp, int fftLen, const char* name, dsr_stream** out);
+dsr_status dsr_spectral_power_create(dsr_stream* fft, int powN, const char* name, dsr_stream** out);
+dsr_status dsr_vtln_create(dsr_stream* pow, int coeffN, double ratio, double edge, int version, const char* name, dsr_stream** out);
+dsr_status dsr_mel_create(dsr_stream* mag, int powN, float rate, float low, float up, int filterN, int version, const char* name, dsr_stream** out);
+dsr_status dsr_log_create(dsr_stream* mel, double m, double a, int sphinxFlooring, const char* name, dsr_stream** out);
+dsr_status dsr_cepstral_create(dsr_stream* mel, int ncep, int type, const char* name, dsr_stream** out);
+dsr_status dsr_storage_create(dsr_stream* src, const char* name, dsr_stream** out);
+dsr_status dsr_mean_subtraction_create(dsr_stream* src, double devNormFactor, int runon, const char* name, dsr_stream** out);
+dsr_status dsr_adjacent_create(dsr_stream* single, int delta, const char* name, dsr_stream** out);
+dsr_status dsr_linear_transform_create(dsr_stream* src, int sz, const char* name, dsr_stream** out);
+dsr_status dsr_linear_transform_set(dsr_stream*, const float* matrix /*[sz][srcSize]*/);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DSR_H */

@@ -1,0 +1,356 @@
+"""GPU parity tests: the HIP path (through the C-ABI) against the CPU oracle on the same seeded inputs.
+
+Tolerances: filterbank/beamformer complex64 vs the reference's complex128 -- relative 1e-5 of
+the frame RMS; MFCC -- abs 1e-4; GMM nearest-Gaussian scores and every WFST index/score -- bit exact.
+"""
+import numpy as np
+import pytest
+
+from tests import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _rel_rms(a, b, axis=-1):
+    num = np.sqrt(np.mean(np.abs(a - b) ** 2, axis=axis))
+    den = np.sqrt(np.mean(np.abs(b) ** 2, axis=axis)) + 1e-30
+    return num / den
+
+
+# ------------------------------------------------------------------------------------------- filter banks
+@pytest.mark.parametrize("pname,dct", [("M256-m4-r1", 0), ("M256-m4-r1", 2), ("M512-m2-r2", 0), ("M512-m2-r2", 1),
+                                       ("M512-m2-r3", 2)])
+def test_analysis_bank(dsr, oracle, cuda, headset, protos, pname, dct):
+    import torch
+    M, m, r, h, g = protos[pname]
+    rng = np.random.default_rng(5)
+    lens = [20000, 12345, 777, 1]                     # ragged, incl. shorter than one prototype / one sample
+    U, Cn, N = len(lens), 2, max(lens)
+    x = np.zeros((U, Cn, N), np.float32)
+    for u, n in enumerate(lens):
+        x[u, 0, :n] = headset[1000:1000 + n]
+        x[u, 1, :n] = rng.standard_normal(n) * 1000
+    fb = dsr.FilterBank(h, M, m, r, False, dct)
+    X = fb.analysis(torch.from_numpy(x).to(cuda), torch.tensor(lens, dtype=torch.int32, device=cuda)).cpu().numpy()
+    for u, n in enumerate(lens):
+        for c in range(Cn):
+            ref = oracle.analysis_bank(x[u, c, :n], h, M, m, r, dct)
+            T = ref.shape[0]
+            assert T == fb.frames(n)
+            got = X[u, c, :T]
+            scale = np.sqrt(np.mean(np.abs(ref[:, :M // 2 + 1]) ** 2)) + 1e-30
+            err = np.abs(got - ref[:, :M // 2 + 1]).max() / scale
+            assert err < 2e-5, (u, c, err)
+            assert np.all(X[u, c, T:] == 0)
+
+
+@pytest.mark.parametrize("pname,dct", [("M256-m4-r1", 0), ("M256-m4-r1", 2), ("M512-m2-r2", 1), ("M512-m2-r3", 0)])
+def test_synthesis_bank(dsr, oracle, cuda, headset, protos, pname, dct):
+    import torch
+    M, m, r, h, g = protos[pname]
+    lens = [16000, 5000]
+    Xs = [oracle.analysis_bank(headset[3000:3000 + n], h, M, m, r, dct) for n in lens]
+    Tmax = max(x.shape[0] for x in Xs)
+    Y = np.zeros((len(lens), Tmax, M // 2 + 1), np.complex64)
+    for u, x in enumerate(Xs):
+        Y[u, :x.shape[0]] = x[:, :M // 2 + 1]
+        Y[u, :, 0] += 0.5j * np.abs(Y[u, :, 0])       # imaginary DC/Nyquist parts must be ignored (modulated.cc:606-607)
+    fb = dsr.FilterBank(g, M, m, r, True, dct)
+    nfr = torch.tensor([x.shape[0] for x in Xs], dtype=torch.int32, device=cuda)
+    y = fb.synthesis_run(torch.from_numpy(Y).to(cuda), nfr).cpu().numpy()
+    for u, x in enumerate(Xs):
+        Yfull = np.zeros((x.shape[0], M), np.complex128)
+        Yfull[:, :M // 2 + 1] = Y[u, :x.shape[0]].astype(np.complex128)
+        Yfull[:, M // 2 + 1:] = np.conj(Yfull[:, 1:M // 2][:, ::-1])
+        ref = oracle.synthesis_bank(Yfull, g, M, m, r, dct)
+        assert len(ref) == fb.blocks(x.shape[0]) * (M >> r)
+        got = y[u, :len(ref)]
+        assert np.abs(got - ref).max() / (np.sqrt(np.mean(ref ** 2)) + 1e-30) < 2e-5
+        assert np.all(y[u, len(ref):] == 0)
+
+
+def test_filterbank_roundtrip_full_size(dsr, cuda, headset, protos):
+    """Size-independent property at BASELINE scale: analysis -> synthesis with the reference's own Nyquist(M)
+    prototypes and delayCompensationType=2 reconstructs the input (x D, zero delay)."""
+    import torch
+    M, m, r, h, g = protos["M512-m2-r3"]
+    D = M >> r
+    n = (len(headset) // D) * D
+    x = torch.from_numpy(np.tile(headset[:n], (4, 2, 1))).to(cuda)
+    a = dsr.FilterBank(h, M, m, r, False, 2); s = dsr.FilterBank(g, M, m, r, True, 2)
+    X = a.analysis(x)
+    y = s.synthesis_run(X[:, 0].contiguous()) * D
+    e = (y[:, 2000:n - 2000] - x[:, 0, 2000:n - 2000]).pow(2).mean().sqrt() / x[:, 0].pow(2).mean().sqrt()
+    assert e.item() < 1e-5
+
+
+# ------------------------------------------------------------------------------------------- beamformer
+def _mvdr_setup(dsr, oracle, M=256, Cn=8):
+    mp = synth.linear_array(Cn)
+    delays = dsr.calcDelaysPolar2(np.float32(np.deg2rad(30.0)), np.float32(np.pi / 2), mp)
+    d_ref = oracle.calc_delays_polar2(np.float32(np.deg2rad(30.0)), np.float32(np.pi / 2), mp)
+    assert np.array_equal(delays, d_ref)
+    bf = dsr.Beamformer(M, Cn)
+    bf.calcArrayManifoldVectors(16000.0, delays)
+    bf.setDiffuseNoiseModel(mp, 16000.0, 343740.0)
+    bf.divideAllNonDiagonalElements(0.01)
+    bf.calcMVDRWeights(16000.0, 1e-8)
+    wq = oracle.calc_mainlobe(16000.0, delays, M)
+    R = oracle.diffuse_noise_model(mp, M, 16000.0, 343740.0, mu=0.01)
+    w = oracle.mvdr_weights(wq, R, 1e-8)
+    return bf, delays, wq, R, w
+
+
+def test_beamformer_weights(dsr, oracle, cuda):
+    bf, delays, wq, R, w = _mvdr_setup(dsr, oracle)
+    assert np.abs(bf.get(0) - wq).max() < 1e-15
+    assert np.abs(bf.get(2) - R).max() < 1e-15
+    got = bf.get(1)
+    # fp32 SVD on both sides, different sweeps: agree to fp32 conditioning
+    assert np.abs(got - w).max() / np.abs(w).max() < 2e-3
+    assert np.all(got[0] == 1.0)                       # DC bin weights are all ones (beamformer.cc:2413-2415)
+    # distortionless response d^H w = 1/C ... w^H d = 1/C for f>0
+    resp = np.einsum("fc,fc->f", np.conj(got[1:]), wq[1:129])
+    assert np.abs(resp - 1.0 / 8).max() < 1e-4
+
+
+@pytest.mark.parametrize("mode", ["ds", "mvdr", "gsc", "gsc_norm"])
+def test_beamformer_apply(dsr, oracle, cuda, mode):
+    import torch
+    M, Cn, T = 256, 8, 40
+    bf, delays, wq, R, w = _mvdr_setup(dsr, oracle, M, Cn)
+    rng = np.random.default_rng(3)
+    X = (rng.standard_normal((2, Cn, T, M // 2 + 1)) + 1j * rng.standard_normal((2, Cn, T, M // 2 + 1))).astype(np.complex64)
+    if mode.startswith("gsc"):
+        bf.calcGSCWeights(16000.0, delays)
+        wa = (rng.standard_normal((M, Cn - 1)) + 1j * rng.standard_normal((M, Cn - 1))) * 0.05
+        for f in range(M):
+            bf.setActiveWeights_f(f, np.stack([wa[f].real, wa[f].imag], -1).reshape(-1))
+    bf.select(mode)
+    Y = bf.apply(torch.from_numpy(X).to(cuda)).cpu().numpy()
+    W = bf.get(4)                                       # weights in use (host double)
+    for u in range(2):
+        Xfull = np.zeros((Cn, T, M), np.complex128); Xfull[:, :, :M // 2 + 1] = X[u]
+        if mode == "ds":
+            ref = oracle.beamform_apply(Xfull, wq[:M // 2 + 1])
+        elif mode == "mvdr":
+            ref = oracle.beamform_apply(Xfull, W)       # same weights: isolates the apply kernel
+        else:
+            B = np.stack([oracle.blocking_matrix(wq[f])[0] for f in range(M // 2 + 1)])
+            ref = oracle.gsc_apply(Xfull, wq[:M // 2 + 1], B, wa[:M // 2 + 1], normalize=(mode == "gsc_norm"))
+        err = np.abs(Y[u] - ref[:, :M // 2 + 1]).max() / np.sqrt(np.mean(np.abs(ref) ** 2))
+        assert err < 2e-5, err
+
+
+# ------------------------------------------------------------------------------------------- MFCC
+@pytest.mark.parametrize("stage,tol", [(4, 1e-5), (3, 1e-5), (1, 1e-4), (2, 1e-4), (0, 1e-4)])
+def test_mfcc_chain(dsr, oracle, cuda, headset, stage, tol):
+    import torch
+    rng = np.random.default_rng(1234)
+    lda = (rng.standard_normal((39, 195)) / np.sqrt(195)).astype(np.float32)
+    lens = [len(headset), 16000, 4000, 1300]
+    y = np.zeros((len(lens), max(lens)), np.float32)
+    for u, n in enumerate(lens):
+        y[u, :n] = headset[:n]
+    mf = dsr.Mfcc(lda=lda)
+    out = mf.run(torch.from_numpy(y).to(cuda), torch.tensor(lens, dtype=torch.int32, device=cuda), stage=stage).cpu().numpy()
+    cfg = oracle.mfcc_cfg(lda=lda)
+    for u, n in enumerate(lens):
+        ref = oracle.mfcc_chain(y[u, :n], cfg, stage=stage)
+        T = ref.shape[0]
+        if stage == 0:
+            assert T == mf.frames(n)
+        got = out[u, :T]
+        if stage == 4:   # power spectrum: relative
+            assert (np.abs(got - ref) / (np.abs(ref) + 1e-3 * ref.max())).max() < tol
+        else:
+            assert np.abs(got - ref).max() < tol, (u, np.abs(got - ref).max())
+        assert np.all(out[u, T:] == 0)
+
+
+@pytest.mark.parametrize("kw", [dict(vtlnRatio=1.1, vtlnEdge=0.8), dict(vtlnRatio=0.9, vtlnEdge=0.8, vtlnVersion=2),
+                                dict(melVersion=2), dict(dctType=0), dict(dctType=2), dict(cmnMode=2, devNormFactor=3.0),
+                                dict(cmnMode=1, devNormFactor=3.0), dict(padZeros=1), dict(delta=1), dict(delta=5)])
+def test_mfcc_variants(dsr, oracle, cuda, headset, kw):
+    import torch
+    n = 24000
+    y = headset[5000:5000 + n].copy()
+    mf = dsr.Mfcc(**kw)
+    stage = 2 if "cmnMode" in kw else 0
+    out = mf.run(torch.from_numpy(y[None]).to(cuda), stage=stage).cpu().numpy()[0]
+    okw = {k: v for k, v in kw.items() if k != "cmnMode"}
+    cfg = oracle.mfcc_cfg(**okw)
+    if kw.get("cmnMode") == 2:
+        cep = oracle.mfcc_chain(y, cfg, stage=1)
+        ref = oracle.cmn_runon(cep, kw["devNormFactor"])
+    else:
+        ref = oracle.mfcc_chain(y, cfg, stage=stage)
+    T = ref.shape[0]
+    assert np.abs(out[:T] - ref).max() < 1e-4
+
+
+# ------------------------------------------------------------------------------------------- GMM
+@pytest.mark.parametrize("K,R,D,mode", [(8, 16, 39, 0), (256, 16, 39, 0), (5, 7, 13, 0), (3, 256, 39, 0), (64, 4, 39, 0),
+                                        (8, 16, 39, 1), (4, 1, 39, 1)])
+def test_gmm_scores(dsr, oracle, cuda, K, R, D, mode):
+    import torch
+    m = synth.gmm_model(K, R, D, seed=12)
+    rng = np.random.default_rng(11)
+    x = rng.standard_normal((1000, D)).astype(np.float32)
+    x[:10] *= 30.0                                       # far-away frames
+    gm = dsr.Gmm(**m)
+    sc, am = gm.score(torch.from_numpy(x).to(cuda), mode=mode)
+    cb = oracle.Codebooks(m["refN"], m["mean"], m["ivar"], m["det"])
+    if mode == 0:
+        ref, arg = oracle.gmm_score_opt(cb, m["val"], x)
+        assert np.array_equal(sc.cpu().numpy().view(np.uint32), ref.view(np.uint32))      # bit exact
+        assert np.array_equal(am.cpu().numpy().astype(np.int32), arg)
+    else:
+        ref = oracle.gmm_score_all(cb, m["val"], x)
+        assert np.abs(sc.cpu().numpy() - ref).max() / np.abs(ref).max() < 1e-6
+
+
+def test_gmm_file_roundtrip(dsr, oracle, cuda, tmp_path):
+    m = synth.gmm_model(6, 16, 39, seed=3)
+    gm = dsr.Gmm(**m)
+    cbf, dsf = str(tmp_path / "cb.bin"), str(tmp_path / "ds.bin")
+    gm.save(cbf, dsf)
+    cb, names = oracle.cbset_load(cbf)                   # the oracle's reader accepts our writer byte for byte
+    assert np.array_equal(cb.mean, m["mean"]) and np.array_equal(cb.ivar, m["ivar"]) and np.array_equal(cb.det, m["det"])
+    gm2 = dsr.Gmm(files=(cbf, dsf))
+    assert gm2.K == 6 and gm2.D == 39
+
+
+# ------------------------------------------------------------------------------------------- WFST + Viterbi
+def _graphs(dsr, oracle, arcs, fin):
+    go, gd = oracle.Wfst(), dsr.Wfst()
+    for a in arcs:
+        go.add_arc(*a); gd.add_arc(*a)
+    for s, c in fin:
+        go.add_final(s, c); gd.add_final(s, c)
+    return go, gd
+
+
+def _check_decode(ro, rd):
+    assert rd["status"] == 0
+    assert rd["frames"] == ro["frames"]
+    assert rd["reachedFinal"] == ro["reachedFinal"]
+    assert np.float32(rd["ac"]).view(np.uint32) == np.float32(ro["ac"]).view(np.uint32)
+    assert np.float32(rd["lm"]).view(np.uint32) == np.float32(ro["lm"]).view(np.uint32)
+    assert rd["score"] == ro["score"]
+    assert np.array_equal(rd["arcs"], ro["arcs"])
+    assert np.array_equal(rd["words"], ro["words"])
+    assert rd["activeHypos"] == ro["activeHypos"]
+
+
+@pytest.mark.parametrize("seed,S,nDist,T,beam,kw", [
+    (1, 200, 16, 50, 30.0, {}),
+    (2, 2000, 128, 120, 1e9, {}),
+    (3, 2000, 128, 120, 20.0, dict(lmPenalty=0.7)),
+    (4, 2000, 128, 120, 8.0, dict(silPenalty=1.5, silenceX=3)),
+    (5, 500, 32, 60, 50.0, dict(ties=True)),
+    (6, 300, 8, 40, 25.0, dict(eps_frac=0.35)),
+    (7, 400, 16, 30, 40.0, dict(nFinal=0)),
+])
+def test_viterbi_bit_exact(dsr, oracle, cuda, seed, S, nDist, T, beam, kw):
+    import torch
+    gkw = {k: kw[k] for k in ("ties", "eps_frac", "nFinal") if k in kw}
+    dkw = {k: kw[k] for k in ("lmPenalty", "silPenalty", "silenceX") if k in kw}
+    arcs, fin = synth.random_wfst(S, nDist, seed=seed, **gkw)
+    go, gd = _graphs(dsr, oracle, arcs, fin)
+    eo, ed = go.export(), gd.export()
+    for k in eo:
+        assert np.array_equal(eo[k], ed[k]), k            # identical node/arc numbering
+    rng = np.random.default_rng(100 + seed)
+    sc = rng.uniform(0, 10, (3, T, nDist)).astype(np.float32)
+    if kw.get("ties"):
+        sc = np.round(sc)                                  # integer scores: exact ties everywhere
+    nfr = [T, T - 7, 1]
+    dec = dsr.Decoder(beam=beam, lmScale=12.0, maxActive=8192, streams=2, **dkw)
+    dec.set(gd)
+    out = dec.decode_batch(torch.from_numpy(sc).to(cuda), torch.tensor(nfr, dtype=torch.int32, device=cuda))
+    for u in range(3):
+        ro = go.decode(sc[u, :nfr[u]], beam=beam, lmScale=12.0, **dkw)
+        assert ro["rc"] == 0
+        _check_decode(ro, out[u])
+
+
+def test_viterbi_token_lists(dsr, oracle, cuda):
+    """Every frame's active list: same states in the same list order with the same float scores."""
+    import torch
+    arcs, fin = synth.random_wfst(1500, 64, seed=9, ties=True)
+    go, gd = _graphs(dsr, oracle, arcs, fin)
+    rng = np.random.default_rng(77)
+    sc = np.round(rng.uniform(0, 6, (1, 80, 64))).astype(np.float32)
+    dec = dsr.Decoder(beam=15.0, lmScale=1.0, maxActive=8192, streams=1); dec.set(gd); dec.enable_dump(True)
+    out = dec.decode_batch(torch.from_numpy(sc).to(cuda))
+    ro = go.decode(sc[0], beam=15.0, lmScale=1.0, dump=True)
+    _check_decode(ro, out[0])
+    d = dec.get_dump()
+    assert np.array_equal(d["frameOff"], ro["dumpOff"])
+    assert np.array_equal(d["node"], ro["dumpNode"])
+    assert np.array_equal(d["arc"], ro["dumpArc"])
+    assert np.array_equal(d["ac"].view(np.uint32), ro["dumpAc"].view(np.uint32))
+    assert np.array_equal(d["lm"].view(np.uint32), ro["dumpLm"].view(np.uint32))
+
+
+def test_viterbi_errors(dsr, oracle, cuda):
+    import torch
+    arcs, fin = synth.random_wfst(100, 8, seed=1)
+    go, gd = _graphs(dsr, oracle, arcs, fin)
+    dec = dsr.Decoder(beam=30.0, maxActive=8192, streams=1); dec.set(gd)
+    sc = torch.zeros((1, 4, 8), device=cuda)
+    r = dec.decode_batch(sc, torch.tensor([0], dtype=torch.int32, device=cuda))
+    assert r[0]["status"] == 9                           # JITERATOR: no frames (decoder.h:691)
+    tiny = dsr.Decoder(beam=1e9, maxActive=4, streams=1); tiny.set(gd)
+    r = tiny.decode_batch(torch.rand((1, 20, 8), device=cuda))
+    assert r[0]["status"] == 2                           # capacity exceeded is reported, never silent
+    g2 = dsr.Wfst(); g2.add_arc(0, 1, 1, 0, 1.0); g2.add_arc(1, 2, 0, 0, 0.0); g2.add_arc(2, 1, 0, 0, 0.0)
+    with pytest.raises(dsr.DsrError):
+        dsr.Decoder().set(g2)                            # epsilon cycle
+
+
+# ------------------------------------------------------------------------------------------- whole pipe
+def test_full_pipe_small(dsr, oracle, cuda, protos):
+    """8-ch analysis -> MVDR -> synthesis -> MFCC -> GMM -> Viterbi for 3 ragged utterances against the chained oracle.
+    GMM+WFST are fed the device features on both sides (bit-exact check); the front end is checked to tolerance."""
+    import torch
+    M, m, r, h, g = protos["M256-m4-r1"]
+    Cn = 8
+    lens = [16000, 12000, 9000]
+    x = np.zeros((len(lens), Cn, max(lens)), np.float32)
+    for u, n in enumerate(lens):
+        x[u, :, :n] = synth.array_signal(n, Cn, seed=7 + u)
+    ana = dsr.FilterBank(h, M, m, r, False, 0); syn = dsr.FilterBank(g, M, m, r, True, 0)
+    bf, delays, wq, R, w = _mvdr_setup(dsr, oracle, M, Cn); bf.select("mvdr")
+    rng = np.random.default_rng(1234)
+    lda = (rng.standard_normal((39, 195)) / np.sqrt(195)).astype(np.float32)
+    mf = dsr.Mfcc(lda=lda)
+    K = 64
+    gm_m = synth.gmm_model(K, 16, 39, seed=12)
+    gm_m["mean"] *= 3.0
+    gm = dsr.Gmm(**gm_m)
+    arcs, fin = synth.random_wfst(3000, K, seed=21)
+    go, gd = _graphs(dsr, oracle, arcs, fin)
+    dec = dsr.Decoder(beam=60.0, lmScale=12.0, maxActive=16384, streams=4); dec.set(gd)
+    pipe = dsr.Pipe(ana, syn, bf, mf, gm, dec, gmmMode=0)
+    xd = torch.from_numpy(x).to(cuda); nd = torch.tensor(lens, dtype=torch.int32, device=cuda)
+    res, arcsO, wordsO = pipe.run(xd, nd, lens, maxPath=2048)
+    W = bf.get(4)
+    cfg = oracle.mfcc_cfg(lda=lda)
+    cb = oracle.Codebooks(gm_m["refN"], gm_m["mean"], gm_m["ivar"], gm_m["det"])
+    Tm = max(mf.frames(((n + 127) // 128) * 128) for n in lens)
+    feat_dev = pipe.intermediate_host(3)[: len(lens) * Tm * 39].reshape(len(lens), Tm, 39)
+    for u, n in enumerate(lens):
+        Xc = np.stack([oracle.analysis_bank(x[u, c, :n], h, M, m, r, 0) for c in range(Cn)])
+        Yo = oracle.beamform_apply(Xc, W)
+        yo = oracle.synthesis_bank(Yo, g, M, m, r, 0)
+        fo = oracle.mfcc_chain(yo, cfg)
+        T = fo.shape[0]
+        assert np.abs(feat_dev[u, :T] - fo).max() < 2e-3          # fp32 filterbank vs fp64 reference, after LDA
+        so, _ = oracle.gmm_score_opt(cb, gm_m["val"], feat_dev[u, :T])
+        ro = go.decode(so, beam=60.0, lmScale=12.0)
+        assert res[u].status == 0
+        assert res[u].score == ro["score"] and res[u].nArcs == len(ro["arcs"])
+        assert np.array_equal(arcsO[u, :res[u].nArcs], ro["arcs"])
+        assert np.array_equal(wordsO[u, :res[u].nWords], ro["words"])
