@@ -118,7 +118,7 @@ __global__ __launch_bounds__(kThreads) void k_viterbi(GraphDev G, DecDev Dd, con
     if (T <= 0) status = DSR_E_ITERATOR;         // no frame at all: the exception escapes decode() (decoder.h:691)
 
     Tok* cur = tokA; Tok* nxt = tokB;
-    int n = 1; long arenaOff = 0; long activeHypos = 0; int maxActive = 0;
+    int n = 1; long arenaOff = 0; long activeHypos = 0; long placements = 0; int maxActive = 0;
     double thresh = HUGE_VAL, topScore = HUGE_VAL;
     if (tid == 0) { Tok t0; t0.node = G.initial; t0.ac = 0.0f; t0.lm = 0.0f; t0.bp = kNone; cur[0] = t0; }
     __syncthreads();
@@ -153,6 +153,7 @@ __global__ __launch_bounds__(kThreads) void k_viterbi(GraphDev G, DecDev Dd, con
       int C = 0;
       for (int w = 0; w < kWaves; w++) C += s_waveTot[w];
       if (C > Dd.maxCand) { status = DSR_E_ALLOCATION; break; }
+      placements += C;
       // ---------------- phase A2: absolute offsets + owner fill
       for (int i = tid; i < n; i += kThreads) {
         const int w = i / chunkT; int base = 0;
@@ -239,7 +240,8 @@ __global__ __launch_bounds__(kThreads) void k_viterbi(GraphDev G, DecDev Dd, con
               const int h0 = ld_i32(&head[dst]);
               for (;;) {                                                       // next replacement = smallest later slot that beats it
                 int best = 0x7FFFFFFF;
-                for (int p = h0; p >= 0; p = cB[p].next) if (p > w && p < best && cA[p].ttl < fw) best = p;
+                int steps = 0;                                                 // the list has at most C nodes: never spin on a corrupt link
+                for (int p = h0; p >= 0 && steps <= C; p = cB[p].next, steps++) if (p > w && p < best && cA[p].ttl < fw) best = p;
                 if (best == 0x7FFFFFFF) break;
                 w = best; aw = cA[w]; fw = (double) __fadd_rn(aw.ac, aw.lm);
               }
@@ -315,7 +317,7 @@ __global__ __launch_bounds__(kThreads) void k_viterbi(GraphDev G, DecDev Dd, con
         if (tid == 0) {
           unsigned long long k = ~0ull; for (int w = 0; w < kWaves; w++) if (s_waveKey[w] < k) k = s_waveKey[w];
           dsr_decode_result r; memset(&r, 0, sizeof(r));
-          r.frames = T - 1; r.reachedFinal = numNew > 0 ? 1 : 0; r.activeHypos = activeHypos; r.maxActiveSeen = maxActive; r.status = DSR_OK;
+          r.frames = T - 1; r.reachedFinal = numNew > 0 ? 1 : 0; r.activeHypos = activeHypos; r.placements = placements; r.maxActiveSeen = maxActive; r.status = DSR_OK;
           if (k != ~0ull) {
             const Tok bt = lst[(unsigned) (k & 0xFFFFFFFFu)];
             r.ac = bt.ac; r.lm = bt.lm; r.score = __dadd_rn((double) bt.ac, (double) bt.lm);

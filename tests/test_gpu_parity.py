@@ -37,6 +37,9 @@ def test_analysis_bank(dsr, oracle, cuda, headset, protos, pname, dct):
             ref = oracle.analysis_bank(x[u, c, :n], h, M, m, r, dct)
             T = ref.shape[0]
             assert T == fb.frames(n)
+            assert np.all(X[u, c, T:] == 0)
+            if T == 0:                                # fewer blocks than the look-ahead: no frames at all
+                continue
             got = X[u, c, :T]
             scale = np.sqrt(np.mean(np.abs(ref[:, :M // 2 + 1]) ** 2)) + 1e-30
             err = np.abs(got - ref[:, :M // 2 + 1]).max() / scale
