@@ -1,0 +1,275 @@
+#!/usr/bin/env python3
+"""bench.py -- the reference's headline workload on MI355X: decoded audio hours per wall-second of the full
+8-ch analysis filterbank -> MVDR -> synthesis -> MFCC -> 4k-Gaussian GMM -> WFST Viterbi pipe (BASELINE.json
+configs[3]: 1k utterances x 10 s x 8 ch, M=256 m=4 r=1, 39-dim features, 1024 distributions x 4 Gaussians,
+WFST 50k states / ~200k arcs, lmScale 12, beam tuned to ~5k active tokens).
+
+One process per GPU; every rank decodes its own shard of utterances (weak scaling: --utts per GPU); the only
+exchange is the gather of the 1-best word sequences to rank 0 over RCCL.  Rank 0 prints ONE JSON line.
+
+  python bench.py --gpus 1 --steps 3 --warmup 1
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port P bench.py --gpus 8 ...
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+PKG = os.path.join(ROOT, "distantspeechrecognition-mirror_amd")
+for p in (ROOT, PKG):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec (6.3 TB/s achievable with a float4 copy)
+MFMA_F32_PEAK_TF = 157.3
+
+
+def make_input(torch, dev, U, C, nsamp, seed):
+    """Synthetic far-field array recordings, generated on the GPU: white Gaussian
+    source (sigma 3000) low-passed, per-channel fractional delay for a source at 30 deg on a 41 mm linear array,
+    plus independent N(0, 300^2) sensor noise.  int16-ranged fp32, layout [utt][chan][sample]."""
+    g = torch.Generator(device=dev); g.manual_seed(seed)
+    x = torch.empty((U, C, nsamp), dtype=torch.float32, device=dev)
+    pos = (torch.arange(C, device=dev, dtype=torch.float64) - (C - 1) / 2.0) * 41.0
+    tau = pos * np.cos(np.deg2rad(30.0)) / 343740.0 * 16000.0
+    n = nsamp + 64
+    f = torch.arange(n // 2 + 1, device=dev, dtype=torch.float64) / n
+    k = torch.hann_window(9, periodic=False, device=dev, dtype=torch.float32); k = k / k.sum()
+    chunk = 25
+    for u0 in range(0, U, chunk):
+        u1 = min(U, u0 + chunk)
+        src = torch.randn((u1 - u0, 1, n), generator=g, device=dev) * 3000.0
+        src = torch.nn.functional.conv1d(src, k.view(1, 1, -1), padding=4)[:, 0]
+        S = torch.fft.rfft(src.double())
+        for c in range(C):
+            d = torch.fft.irfft(S * torch.exp(-2j * np.pi * f * tau[c]), n=n)
+            x[u0:u1, c] = d[:, 32:32 + nsamp].float() + torch.randn((u1 - u0, nsamp), generator=g, device=dev) * 300.0
+    return x
+
+
+def build_models(dsr, synth, nDist, nStates):
+    hg = np.load(os.path.join(ROOT, "tests", "golden", "proto_M256-m4-r1.npy")); h, g = hg[0], hg[1]
+    M, m, r, Cn = 256, 4, 1, 8
+    ana = dsr.FilterBank(h, M, m, r, False, 0); syn = dsr.FilterBank(g, M, m, r, True, 0)
+    mp = synth.linear_array(Cn)
+    delays = dsr.calcDelaysPolar2(np.float32(np.deg2rad(30.0)), np.float32(np.pi / 2), mp)
+    bf = dsr.Beamformer(M, Cn); bf.calcArrayManifoldVectors(16000.0, delays); bf.setDiffuseNoiseModel(mp, 16000.0, 343740.0)
+    bf.divideAllNonDiagonalElements(0.01); bf.calcMVDRWeights(16000.0, 1e-8); bf.select("mvdr")
+    lda = (np.random.default_rng(1234).standard_normal((39, 195)) / np.sqrt(195)).astype(np.float32)
+    mf = dsr.Mfcc(lda=lda)
+    gm_m = synth.gmm_model(nDist, 4096 // nDist, 39, seed=12)
+    gm = dsr.Gmm(**gm_m)
+    arcs, fin = synth.random_wfst(nStates, nDist, seed=21, outdeg=4, eps_frac=0.1, out_frac=0.05, nWords=5000, nFinal=50)
+    gd = dsr.Wfst()
+    for a in arcs:
+        gd.add_arc(*a)
+    for s, c in fin:
+        gd.add_final(s, c)
+    return dict(h=h, g=g, M=M, m=m, r=r, C=Cn, ana=ana, syn=syn, bf=bf, lda=lda, mf=mf, gm_m=gm_m, gm=gm, arcs=arcs, fin=fin, gd=gd,
+                nArcs=len(arcs))
+
+
+def tune_beam(dsr, torch, mdl, scores, nfr, target=5000.0):
+    """Beam (in score units) that gives a mean of ~target active tokens per frame on a few utterances (untimed)."""
+    lo, hi, best = 1.0, 4000.0, None
+    for _ in range(9):
+        beam = float(np.sqrt(lo * hi))
+        dec = dsr.Decoder(beam=beam, lmScale=12.0, maxActive=65536, streams=scores.shape[0]); dec.set(mdl["gd"])
+        out = dec.decode_batch(scores, nfr, maxPath=16)
+        if any(o["status"] not in (0, 5) for o in out):
+            hi = beam; continue
+        act = np.mean([o["activeHypos"] / max(1, o["frames"] + 1) for o in out])
+        best = (beam, act)
+        if act > target:
+            hi = beam
+        else:
+            lo = beam
+        if abs(act - target) / target < 0.05:
+            break
+    return best
+
+
+def cpu_baseline(mdl, x_host, nsamp, beam, max_seconds=25.0):
+    """The oracle (plain C restatement of the reference, 1 thread, -O3 -march=native build when gcc is there) on a
+    bounded sample of the same workload: whole utterances through the same pipe."""
+    from oracle import oracle as O
+    try:
+        O.lib(native=True); nat = True
+    except Exception:
+        nat = False
+    L = O.lib(native=nat)
+    go = O.Wfst()
+    for a in mdl["arcs"]:
+        go.add_arc(*a)
+    for s, c in mdl["fin"]:
+        go.add_final(s, c)
+    cb = O.Codebooks(mdl["gm_m"]["refN"], mdl["gm_m"]["mean"], mdl["gm_m"]["ivar"], mdl["gm_m"]["det"])
+    W = mdl["bf"].get(4); cfg = O.mfcc_cfg(lda=mdl["lda"])
+    h, g, M, m, r, Cn = mdl["h"], mdl["g"], mdl["M"], mdl["m"], mdl["r"], mdl["C"]
+    done, t0, words = 0, time.time(), []
+    for u in range(x_host.shape[0]):
+        Xc = np.stack([O.analysis_bank(x_host[u, c, :nsamp], h, M, m, r, 0) for c in range(Cn)])
+        y = O.synthesis_bank(O.beamform_apply(Xc, W), g, M, m, r, 0)
+        f = O.mfcc_chain(y, cfg)
+        sc, _ = O.gmm_score_opt(cb, mdl["gm_m"]["val"], f, native=nat)
+        ro = go.decode(sc, beam=beam, lmScale=12.0)
+        words.append(ro.get("words"))
+        done += 1
+        if time.time() - t0 > max_seconds:
+            break
+    dt = time.time() - t0
+    return done, dt, words, nat
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--utts", type=int, default=1000, help="utterances per GPU per step")
+    ap.add_argument("--secs", type=float, default=10.0, help="seconds of audio per utterance")
+    ap.add_argument("--states", type=int, default=50000)
+    ap.add_argument("--dists", type=int, default=1024)
+    ap.add_argument("--beam", type=float, default=0.0, help="0 = tune to ~5k active tokens")
+    ap.add_argument("--gmm-mode", type=int, default=0)
+    ap.add_argument("--no-cpu", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1")); rank = int(os.environ.get("RANK", "0")); lrank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", lrank))
+    torch.cuda.set_device(lrank)
+    dev = torch.device("cuda", lrank)
+    import dsr._capi as dsr
+    from tests import synth
+    dsr.load()
+
+    U, Cn, nsamp = args.utts, 8, int(args.secs * 16000)
+    mdl = build_models(dsr, synth, args.dists, args.states)
+    x = make_input(torch, dev, U, Cn, nsamp, seed=7 + rank)
+    ns_host = np.full(U, nsamp, np.int32); ns_dev = torch.from_numpy(ns_host).to(dev)
+
+    # ---- untimed set-up: scores of a few utterances to tune the beam
+    probe = dsr.Decoder(beam=1.0, maxActive=1024, streams=1); probe.set(mdl["gd"])
+    pp = dsr.Pipe(mdl["ana"], mdl["syn"], mdl["bf"], mdl["mf"], mdl["gm"], probe, gmmMode=args.gmm_mode)
+    nprobe = min(4, U)
+    pp.run(x[:nprobe].contiguous(), ns_dev[:nprobe].contiguous(), ns_host[:nprobe], maxPath=16, want_paths=False)
+    Tm = mdl["mf"].frames(((nsamp + 127) // 128) * 128)
+    sc_host = pp.intermediate_host(4)[: nprobe * Tm * args.dists].reshape(nprobe, Tm, args.dists)
+    sc_probe = torch.from_numpy(sc_host).to(dev)
+    nfr_probe = torch.full((nprobe,), Tm, dtype=torch.int32, device=dev)
+    if args.beam > 0:
+        beam, act = args.beam, None
+    else:
+        beam, act = tune_beam(dsr, torch, mdl, sc_probe, nfr_probe)
+        if world > 1:   # every rank must use the same beam
+            b = torch.tensor([beam], dtype=torch.float64, device=dev); dist.broadcast(b, 0); beam = float(b.item())
+    del pp, probe
+    dec = dsr.Decoder(beam=beam, lmScale=12.0, maxActive=65536); dec.set(mdl["gd"])
+    pipe = dsr.Pipe(mdl["ana"], mdl["syn"], mdl["bf"], mdl["mf"], mdl["gm"], dec, gmmMode=args.gmm_mode)
+    maxPath = 2 * Tm + 64
+
+    def step():
+        res, arcs, words = pipe.run(x, ns_dev, ns_host, maxPath=maxPath, want_paths=True)
+        # the path's only exchange: gather the 1-best word sequences on rank 0 (RCCL over xGMI)
+        if world > 1:
+            nW = np.array([r.nWords for r in res], np.int32)
+            wmax = int(nW.max()) if len(nW) else 0
+            loc = torch.tensor([wmax], dtype=torch.int32, device=dev)
+            allmax = [torch.zeros_like(loc) for _ in range(world)]
+            dist.all_gather(allmax, loc)
+            wmax = max(int(t.item()) for t in allmax)
+            pad = torch.zeros((U, wmax + 1), dtype=torch.int32, device=dev)
+            pad[:, 0] = torch.from_numpy(nW).to(dev)
+            if wmax:
+                pad[:, 1:] = torch.from_numpy(words[:, :wmax].astype(np.int32)).to(dev)
+            out = [torch.zeros_like(pad) for _ in range(world)] if rank == 0 else None
+            dist.gather(pad, out, dst=0)
+        return res, words
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    sync(); t0 = time.time()
+    stage = np.zeros(6); placements = 0; active = 0; bad = 0; frames = 0
+    for _ in range(args.steps):
+        res, words = step()
+        stage += np.array(pipe.stage_ms())
+        placements += sum(r.placements for r in res); active += sum(r.activeHypos for r in res)
+        frames += sum(r.frames + 1 for r in res); bad += sum(1 for r in res if r.status != 0)
+    sync(); dt = time.time() - t0
+    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
+    ms_per_step = 1000.0 * dt / args.steps
+    audio_s = world * U * args.secs
+    hours_per_s = audio_s / 3600.0 / (dt / args.steps)
+
+    if rank == 0:
+        stage_ms = (stage / args.steps).tolist()
+        names = ["analysis", "beamform", "synthesis", "mfcc", "gmm", "viterbi"]
+        T_ana = mdl["ana"].frames(nsamp)
+        # algorithmic bytes / flops per launch (DESIGN.md "Measurement")
+        alg = {
+            "analysis": ("hbm", U * Cn * T_ana * 1544.0),                       # 512 B in + 1032 B out per channel-frame
+            "beamform": ("hbm", U * T_ana * (Cn + 1) * 129 * 8.0),
+            "synthesis": ("hbm", U * T_ana * (129 * 8.0 + 128 * 4.0)),
+            "mfcc": ("hbm", U * Tm * (160 * 4.0 + 39 * 4.0)),
+            "gmm": ("mfma" if args.gmm_mode == 2 else "valu", U * Tm * 4.0 * 39 * 4096),
+            "viterbi": ("hbm", placements / args.steps * 40.0),                 # 20 B arc + 4 B score + 16 B token per expanded arc
+        }
+        dom = int(np.argmax(stage_ms)); dn = names[dom]; kind, amount = alg[dn]
+        secs = stage_ms[dom] / 1000.0
+        if kind == "hbm":
+            roof = dict(kernel="k_" + dn, bound="hbm", achieved=amount / secs / 1e9, peak=HBM_PEAK_GBS, unit="GB/s")
+        else:
+            roof = dict(kernel="k_" + dn, bound="mfma", achieved=amount / secs / 1e12, peak=MFMA_F32_PEAK_TF, unit="TFLOP/s")
+        roof["frac"] = roof["achieved"] / roof["peak"]; roof["traffic"] = None
+        roof["launch_ms"] = stage_ms[dom]
+        stages = {}
+        for i, nm in enumerate(names):
+            k, a = alg[nm]; s = stage_ms[i] / 1000.0
+            stages[nm] = dict(ms=round(stage_ms[i], 3), bound=k,
+                              achieved=round(a / s / (1e9 if k == "hbm" else 1e12), 3) if s > 0 else None,
+                              unit="GB/s" if k == "hbm" else "TFLOP/s")
+        cpu = None
+        if not args.no_cpu:
+            ncpu = min(6, U)
+            done, cdt, cwords, nat = cpu_baseline(mdl, x[:ncpu].cpu().numpy(), nsamp, beam)
+            cpu = dict(value=done * args.secs / 3600.0 / cdt, unit="audio_hours_per_sec", cores=1, kind="port",
+                       sample="%d whole utterances (%.0f s x 8 ch) through the same pipe, oracle C restatement%s, %.1f s of CPU time"
+                              % (done, args.secs, " -O3 -march=native" if nat else "", cdt),
+                       xRT=done * args.secs / cdt)
+            # the same utterances decoded on the GPU give the same word sequences? (front end differs by fp32 rounding)
+            agree = sum(1 for u in range(done) if cwords[u] is not None and np.array_equal(cwords[u], words[u, :res[u].nWords]))
+            cpu["one_best_agree"] = "%d/%d" % (agree, done)
+        line = dict(metric="decoded_audio_hours_per_sec", value=hours_per_s, unit="audio_hours/s", n_gpus=world, steps=args.steps,
+                    warmup=args.warmup, ms_per_step=ms_per_step, higher_is_better=True, scaling="weak", vs_baseline=None,
+                    dtype="f32", data="synthetic",
+                    config=dict(workload="full pipe: %d utt/GPU x %.0f s x 8 ch, analysis M=256 m=4 r=1 -> MVDR -> synthesis -> MFCC(39) -> "
+                                         "GMM %d dists x %d Gaussians -> WFST %d states/%d arcs, lmScale 12, beam %.1f"
+                                         % (U, args.secs, args.dists, 4096 // args.dists, args.states, mdl["nArcs"], beam),
+                                utts_per_gpu=U, xRT=audio_s / (dt / args.steps), beam=beam,
+                                mean_active_tokens=active / max(1, frames), failed_utts=bad, gmm_mode=args.gmm_mode,
+                                parallelism="utterance-sharded x%d, RCCL gather of 1-best" % world),
+                    roofline=roof, stages=stages, cpu_baseline=cpu)
+        print(json.dumps(line))
+    if world > 1:
+        dist.barrier(); dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,298 @@
+"""CPU tests (-m "not gpu"): the oracle against everything the reference holds for this path.
+
+The reference ships no golden outputs, so the oracle is pinned by
+  * the perfect-reconstruction property of the reference's own Nyquist(M) prototypes on its own
+    Headset1.wav (tests/golden/, copied data files) -- pins analysis/synthesis index conventions,
+  * the reference's in-tree LINPACK csvdc (built from the reference sources into oracle/_ref, results
+    committed as tests/golden/linpack_csvdc.npz) -- pins the complex<float> pseudo-inverse,
+  * byte-level file-format round trips and closed-form properties.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from tests import synth
+from tests.conftest import GOLDEN
+
+
+# ------------------------------------------------------------------ filter banks
+@pytest.mark.parametrize("pname,tol", [("M256-m4-r1", 3e-3), ("M512-m2-r2", 2e-5), ("M512-m2-r3", 2e-7)])
+@pytest.mark.parametrize("dct", [1, 2])
+def test_filterbank_perfect_reconstruction(oracle, headset, protos, pname, tol, dct):
+    """btk/tools/filterbank/testNyquistFilterBankDesign.py:45-66: analysis -> synthesis, output scaled by D,
+    reproduces the input with zero delay when the delays are compensated (types 1 and 2)."""
+    M, m, r, h, g = protos[pname]
+    D = M >> r
+    x = headset[:24000]
+    X = oracle.analysis_bank(x, h, M, m, r, dct)
+    assert X.shape[0] == oracle.analysis_num_frames(len(x), M, m, r, dct)
+    y = oracle.synthesis_bank(X, g, M, m, r, dct) * D
+    n = min(len(x), len(y))
+    e = y[2000:n - 2000] - x[2000:n - 2000]
+    assert np.sqrt(np.mean(e ** 2)) / np.sqrt(np.mean(x ** 2)) < tol
+
+
+def test_filterbank_frame_counts(oracle, protos):
+    M, m, r, h, g = protos["M256-m4-r1"]
+    # type 0: ceil(N/D) + 2m-1 ; type 1: + mR-1 ; type 2: - laN + mR-1   (modulated.cc:279-296, 461-516)
+    assert oracle.analysis_num_frames(160000, 256, 4, 1, 0) == 1250 + 7
+    assert oracle.analysis_num_frames(160001, 256, 4, 1, 0) == 1251 + 7
+    assert oracle.analysis_num_frames(160000, 256, 4, 1, 1) == 1250 + 7
+    assert oracle.analysis_num_frames(160000, 256, 4, 1, 2) == 1250 - 3 + 7
+    assert oracle.analysis_num_frames(100, 256, 4, 1, 2) == 0         # fewer blocks than the look-ahead
+    X = oracle.analysis_bank(np.ones(1000, np.float32), h, M, m, r, 0)
+    assert np.abs(X[:, 1:128] - np.conj(X[:, :128:-1])).max() < 1e-9   # real input: Hermitian spectrum
+    # synthesis emits T - processingDelay blocks
+    y = oracle.synthesis_bank(X, g, M, m, r, 0)
+    assert len(y) == (X.shape[0] - 7) * 128
+
+
+def test_analysis_matches_closed_form(oracle, protos):
+    """X_t[f] = sum_l h[l] x[n_t - l] e^{+2 pi j f l / M}, n_t = (t+1) D - 1."""
+    M, m, r, h, g = protos["M512-m2-r2"]
+    D = M >> r
+    rng = np.random.default_rng(0)
+    x = rng.standard_normal(3000).astype(np.float32)
+    X = oracle.analysis_bank(x, h, M, m, r, 0)
+    xp = np.concatenate([np.zeros(m * M), x.astype(np.float64), np.zeros(40 * D)])
+    for t in (0, 3, 11, X.shape[0] - 1):
+        nt = (t + 1) * D - 1 + m * M
+        seg = xp[nt - np.arange(m * M)]
+        u = (h * seg).reshape(m, M).sum(0)
+        ref = np.fft.ifft(u) * M
+        assert np.abs(X[t] - ref).max() < 1e-9 * (1 + np.abs(ref).max())
+
+
+def test_normal_fft_bank(oracle):
+    x = np.random.default_rng(1).standard_normal(2000).astype(np.float32)
+    X = oracle.normal_fft_bank(x, 256, 1, winType=1)
+    assert X.shape == (2000 // 128 + 1 + 1, 256)
+
+
+# ------------------------------------------------------------------ beamformer
+def test_pseudoinverse_pinned_by_linpack(oracle):
+    z = np.load(os.path.join(GOLDEN, "linpack_csvdc.npz"))
+    for i in range(5):
+        A, P = z["A%d" % i], z["P%d" % i]
+        Po, ok = oracle.pseudoinverse(A)
+        assert ok
+        assert np.abs(Po - P).max() / np.abs(P).max() < 1e-4
+        # singular values agree with csvdc's
+        s = np.sort(np.abs(z["s%d" % i]))[::-1]
+        assert np.abs(np.sort(np.linalg.svd(A.astype(np.complex64), compute_uv=False))[::-1] - s).max() / s[0] < 1e-5
+
+
+def test_linpack_ref_live(oracle):
+    """When the reference sources are present (authoring container) run csvdc itself again."""
+    if oracle.build_ref() is None:
+        pytest.skip("/root/reference not present")
+    import ctypes as C
+    L = oracle.ref_linpack()
+    rng = np.random.default_rng(99)
+    n = 6
+    A = (rng.standard_normal((n, n)) + 1j * rng.standard_normal((n, n)))
+    a = np.asfortranarray(A.astype(np.complex64)); s = np.zeros(2 * n, np.complex64); e = np.zeros(2 * n, np.complex64)
+    u = np.zeros((n, n), np.complex64, order="F"); v = np.zeros((n, n), np.complex64, order="F")
+    vp = lambda q: q.ctypes.data_as(C.c_void_p)
+    assert L.ref_csvdc(vp(a), n, n, n, vp(s), vp(e), vp(u), n, vp(v), n, 11) == 0
+    P = (v * (1.0 / s[:n])[None, :]) @ np.conj(u.T)
+    Po, ok = oracle.pseudoinverse(A)
+    assert ok and np.abs(Po - P).max() / np.abs(P).max() < 1e-4
+
+
+def test_mvdr_weights_properties(oracle):
+    M, Cn = 256, 8
+    mp = synth.linear_array(Cn)
+    delays = oracle.calc_delays_polar2(np.float32(0.5), np.float32(np.pi / 2), mp)
+    wq = oracle.calc_mainlobe(16000.0, delays, M)
+    assert np.allclose(wq[0], 1.0 / Cn) and np.allclose(wq[M - 5], np.conj(wq[5]))
+    R = oracle.diffuse_noise_model(mp, M, 16000.0, 343740.0, mu=0.01)
+    assert np.allclose(R[:, np.arange(Cn), np.arange(Cn)], 1.0) and np.allclose(R, np.conj(np.swapaxes(R, 1, 2)))
+    w = oracle.mvdr_weights(wq, R)
+    assert np.all(w[0] == 1.0)                                             # beamformer.cc:2413-2415
+    resp = np.einsum("fc,fc->f", np.conj(w[1:]), wq[1:M // 2 + 1])
+    assert np.abs(resp - 1.0 / Cn).max() < 1e-4                            # w = invR d / (C d^H invR d)
+    # MVDR has lower diffuse-noise output power than delay-and-sum at every bin
+    pm = np.einsum("fc,fcd,fd->f", np.conj(w[1:]), R[1:], w[1:]).real
+    pd = np.einsum("fc,fcd,fd->f", np.conj(wq[1:129]), R[1:], wq[1:129]).real
+    assert np.all(pm <= pd * (1 + 1e-4))
+
+
+def test_blocking_matrix(oracle):
+    rng = np.random.default_rng(2)
+    d = rng.standard_normal(8) + 1j * rng.standard_normal(8)
+    B, ok = oracle.blocking_matrix(d)
+    assert ok and np.abs(np.conj(B.T) @ B - np.eye(7)).max() < 1e-12
+    # columns are orthogonal to conj(d):  B^H conj(d) = 0  (P = I - conj(d) d^T / |d|^2)
+    assert np.abs(np.conj(B.T) @ np.conj(d)).max() < 1e-12
+
+
+# ------------------------------------------------------------------ MFCC chain
+def test_mfcc_config1_shapes(oracle, headset):
+    """BASELINE config 1: Headset1.wav -> 39-dim stream; frame count of SampleFeature(320,160,padZeros=False)."""
+    lda = (np.random.default_rng(1234).standard_normal((39, 195)) / np.sqrt(195)).astype(np.float32)
+    f = oracle.mfcc_chain(headset, oracle.mfcc_cfg(lda=lda))
+    assert f.shape == (841, 39) and np.isfinite(f).all()
+    c = oracle.mfcc_chain(headset, oracle.mfcc_cfg(), stage=2)
+    assert np.abs(c.mean(0)).max() < 1e-3                                   # batch CMN
+    s = oracle.mfcc_chain(headset, oracle.mfcc_cfg(), stage=0)             # no LDA: spliced 195-dim
+    assert s.shape == (841, 195)
+    assert np.array_equal(s[0, :13], s[0, 13 * 7:13 * 8]) and np.array_equal(s[100, 13 * 7:13 * 8], c[100])
+    assert np.array_equal(s[-1, -13:], c[-1]) and np.array_equal(s[0, 13 * 8:13 * 9], c[1])
+
+
+def test_mfcc_operators_against_numpy(oracle, headset):
+    x = headset[8000:8000 + 4000]
+    blk = oracle.sample_blocks(x, 320, 160, False)
+    assert blk.shape[0] == 23 and np.array_equal(blk[3], x[480:800])
+    assert oracle.sample_blocks(x, 320, 160, True).shape[0] == 25
+    pw = oracle.mfcc_chain(x, oracle.mfcc_cfg(), stage=4)
+    # pre-emphasis carries its prior across the overlapping blocks (feature.cc:1164-1167)
+    t = 5
+    b = blk[t].astype(np.float64); prior = np.concatenate([[blk[t - 1][-1]], b[:-1]])
+    pre = (b - 0.95 * prior).astype(np.float32)
+    ham = ((0.54 - 0.46 * np.cos(2 * np.pi * np.arange(320) / 319.0)) * pre).astype(np.float32)
+    ref = np.abs(np.fft.rfft(ham.astype(np.float64), 512)) ** 2
+    assert np.abs(pw[t] - ref).max() / ref.max() < 1e-6
+    rows = oracle.melbank(257, 16000.0, 0.0, 0.0, 30, 1)
+    assert len(rows) == 30 and rows[0][0] == 0 and all(len(c) > 0 for _, c in rows)
+    assert rows[0][1][-1] < 0                                               # v1 quirk: last tap lies past the right edge
+    assert rows[-1][0] + len(rows[-1][1]) <= 257
+    r2 = oracle.melbank(257, 16000.0, 0.0, 0.0, 30, 2)
+    assert not np.array_equal(rows[10][1], r2[10][1])                       # v1 evaluates the triangle one bin late
+    Cm = oracle.cosine_matrix(13, 30, 1)
+    assert np.allclose(Cm[0], 1.0) and np.allclose(Cm[1, 0], np.cos(np.pi * 0.5 / 30))
+
+
+def test_vtln_identity_and_warp(oracle):
+    pw = np.abs(np.random.default_rng(3).standard_normal((4, 257))) + 1.0
+    out = oracle.vtln(pw, 1.0, 1.0, 1)
+    assert np.abs(out - pw).max() / pw.max() < 1e-9
+    w = oracle.vtln(pw, 1.1, 0.8, 1)
+    assert np.isfinite(w).all() and abs(w.sum() / pw.sum() - 1.0) < 0.05   # interval integration conserves mass
+    assert np.isfinite(oracle.vtln(pw, 0.9, 0.8, 2)).all()
+
+
+def test_blockconv_is_plain_framing(oracle):
+    x = np.arange(128 * 20, dtype=np.float32)
+    out = oracle.blockconv(x.reshape(20, 128), 320, 160)
+    assert out.shape[0] == (len(x) - 320) // 160 + 1
+    for t in (0, 1, 7, out.shape[0] - 1):
+        assert np.array_equal(out[t], x[160 * t:160 * t + 320])
+
+
+def test_cmn_and_adjacent(oracle):
+    x = np.random.default_rng(4).standard_normal((50, 13)).astype(np.float32)
+    y, mean, var = oracle.cmn_batch(x, 3.0)
+    assert np.abs(mean - x.mean(0)).max() < 1e-5 and np.abs(var - x.var(0)).max() < 1e-4
+    assert np.abs(y - (x - mean) / (3.0 * np.sqrt(var))).max() < 1e-5
+    r = oracle.cmn_runon(x, 0.0)
+    m = np.zeros(13, np.float32)
+    for t in range(3):
+        m = (np.float32(0.98) * m + (1.0 - np.float32(0.98)) * x[t]).astype(np.float32)
+    assert np.abs(r[2] - (x[2] - m)).max() < 1e-6
+    a = oracle.adjacent(x, 5)
+    assert a.shape == (50, 143) and np.array_equal(a[0, :13], x[0]) and np.array_equal(a[49, -13:], x[49])
+    assert np.array_equal(a[20, 5 * 13:6 * 13], x[20]) and np.array_equal(a[20, :13], x[15])
+    assert oracle.adjacent(x[:3], 5).shape[0] == 0                           # cannot be primed
+
+
+# ------------------------------------------------------------------ GMM
+def test_gmm_against_float64(oracle):
+    m = synth.gmm_model(8, 16, 39, seed=5)
+    cb = oracle.Codebooks(m["refN"], m["mean"], m["ivar"], m["det"])
+    x = np.random.default_rng(6).standard_normal((200, 39)).astype(np.float32)
+    sc, am = oracle.gmm_score_opt(cb, m["val"], x)
+    d = ((m["mean"][None].astype(np.float64) - x[:, None]) ** 2 * m["ivar"][None]).sum(-1) + 39 * np.log(2 * np.pi) + m["det"][None]
+    d = d.reshape(200, 8, 16)
+    assert np.array_equal(d.argmin(-1), am)
+    ref = 0.5 * d.min(-1) + m["val"].reshape(8, 16)[np.arange(8)[None], d.argmin(-1)]
+    assert np.abs(sc - ref).max() / np.abs(ref).max() < 1e-5
+    sa = oracle.gmm_score_all(cb, m["val"], x)
+    lse = -np.log(np.exp(-(0.5 * d + m["val"].reshape(1, 8, 16))).sum(-1))
+    assert np.abs(sa - lse).max() / np.abs(lse).max() < 1e-5
+    assert np.all(sa <= sc + 1e-4)                                          # full mixture is never worse than its best term
+
+
+def test_gmm_files_byte_exact(oracle, tmp_path):
+    m = synth.gmm_model(3, 4, 5, seed=7)
+    cb = oracle.Codebooks(m["refN"], m["mean"], m["ivar"], m["det"])
+    p = str(tmp_path / "cb.bin")
+    assert oracle.cbset_save(cb, ["a", "bb", "ccc"], p) == 0
+    raw = open(p, "rb").read()
+    assert raw[:4] == (64207531).to_bytes(4, "big") and raw[8:12] == (3).to_bytes(4, "big")   # big endian magic, count
+    assert raw[12:16] == b"\x00\x01a\x00"                                                      # int16 length + bytes + NUL
+    assert raw[-4:] == (123456789).to_bytes(4, "big")
+    cb2, names = oracle.cbset_load(p)
+    assert names == ["a", "bb", "ccc"] and np.array_equal(cb2.mean, cb.mean) and np.array_equal(cb2.det, cb.det)
+
+
+# ------------------------------------------------------------------ WFST + decoder
+def _brute_force_best(ex, scores, lmScale, finals_only=True):
+    """Exhaustive Viterbi in float64 over (frame, node) for graphs WITHOUT epsilon arcs."""
+    n = len(ex["nodeState"]); T = scores.shape[0]
+    best = np.full(n, np.inf); best[0] = 0.0
+    for t in range(T):
+        nb = np.full(n, np.inf)
+        for s in range(n):
+            if not np.isfinite(best[s]):
+                continue
+            for a in range(ex["arcOff"][s], ex["arcOff"][s + 1]):
+                v = best[s] + lmScale * ex["arcCost"][a] + scores[t, ex["arcIn"][a] - 1]
+                if v < nb[ex["arcDst"][a]]:
+                    nb[ex["arcDst"][a]] = v
+        best = nb
+    fin = best + np.where(ex["nodeFinal"] == 1, lmScale * ex["nodeCost"], np.inf)
+    return fin.min()
+
+
+def test_decoder_matches_exhaustive_viterbi(oracle):
+    arcs, fin = synth.random_wfst(60, 6, seed=3, eps_frac=0.0, nFinal=10)
+    g = oracle.Wfst()
+    for a in arcs:
+        g.add_arc(*a)
+    for s, c in fin:
+        g.add_final(s, c)
+    sc = np.random.default_rng(8).uniform(0, 10, (25, 6)).astype(np.float32)
+    r = g.decode(sc, beam=1e9, lmScale=2.0)
+    assert r["rc"] == 0 and r["reachedFinal"]
+    ref = _brute_force_best(g.export(), sc.astype(np.float64), 2.0)
+    assert abs(r["score"] - ref) / ref < 1e-5
+    assert len(r["arcs"]) == 25 and np.array_equal(r["arcFrames"], np.arange(25))
+
+
+def test_wfst_container_semantics(oracle, tmp_path):
+    g = oracle.Wfst()
+    g.add_arc(5, 6, 1, 0, 1.0); g.add_arc(5, 7, 2, 9, 2.0); g.add_arc(6, 5, 0, 0, 0.5); g.add_arc(7, 7, 0, 0, 0.0)
+    g.add_final(7, 0.25)
+    ex = g.export()
+    assert ex["nodeState"][0] == 5                                           # source of the first arc = initial node
+    assert list(ex["arcDst"][ex["arcOff"][0]:ex["arcOff"][1]]) == [2, 1]     # prepended: reverse file order
+    assert len(ex["arcDst"]) == 3                                            # eps:eps self loop dropped by the text reader
+    t, b = str(tmp_path / "g.txt"), str(tmp_path / "g.bin")
+    assert g.write(t, binary=False) == 0 and g.write(b, binary=True) == 0
+    raw = open(b, "rb").read()
+    assert raw[:4] == (6).to_bytes(4, "big") and raw[-4:] == (2147483647).to_bytes(4, "big")
+    for path, binary in ((t, False), (b, True)):
+        g2 = oracle.Wfst(); assert g2.read(path, binary) == 0
+        e2 = g2.export()
+        assert sorted(zip(e2["nodeState"][e2["arcDst"]], e2["arcIn"], e2["arcOut"])) == sorted(zip(ex["nodeState"][ex["arcDst"]], ex["arcIn"], ex["arcOut"]))
+    assert g.add_final(7, 0.0) != 0                                          # "Automaton already has final node"
+
+
+def test_decoder_edge_cases(oracle):
+    arcs, fin = synth.random_wfst(100, 8, seed=1)
+    g = oracle.Wfst()
+    for a in arcs:
+        g.add_arc(*a)
+    for s, c in fin:
+        g.add_final(s, c)
+    assert g.decode(np.zeros((0, 8), np.float32))["rc"] == -8                # no frames: the exception escapes decode()
+    sc = np.random.default_rng(2).uniform(0, 10, (30, 8)).astype(np.float32)
+    r1 = g.decode(sc, beam=1e9); r2 = g.decode(sc, beam=5.0)
+    assert r2["score"] >= r1["score"] and r2["activeHypos"] < r1["activeHypos"]
+    r3 = g.decode(sc, beam=1e9, lmPenalty=1.0)
+    assert r3["score"] >= r1["score"]
+    # tokens are floats: the stored total equals float(ac)+float(lm) in double
+    assert r1["score"] == float(np.float32(r1["ac"])) + float(np.float32(r1["lm"]))
