@@ -181,18 +181,8 @@ def main():
         res, arcs, words = pipe.run(x, ns_dev, ns_host, maxPath=maxPath, want_paths=True)
         # the path's only exchange: gather the 1-best word sequences on rank 0 (RCCL over xGMI)
         if world > 1:
-            nW = np.array([r.nWords for r in res], np.int32)
-            wmax = int(nW.max()) if len(nW) else 0
-            loc = torch.tensor([wmax], dtype=torch.int32, device=dev)
-            allmax = [torch.zeros_like(loc) for _ in range(world)]
-            dist.all_gather(allmax, loc)
-            wmax = max(int(t.item()) for t in allmax)
-            pad = torch.zeros((U, wmax + 1), dtype=torch.int32, device=dev)
-            pad[:, 0] = torch.from_numpy(nW).to(dev)
-            if wmax:
-                pad[:, 1:] = torch.from_numpy(words[:, :wmax].astype(np.int32)).to(dev)
-            out = [torch.zeros_like(pad) for _ in range(world)] if rank == 0 else None
-            dist.gather(pad, out, dst=0)
+            from dsr.dist import gather_one_best
+            gather_one_best(words, np.array([r.nWords for r in res], np.int32), world, rank, dev, dist)
         return res, words
 
     def sync():

@@ -14,6 +14,7 @@
 // Tables (Hamming, VTLN interval weights, mel triangles, DCT) are built on the host with the
 // reference's own formulas, including its quirks (mel v1 evaluates the triangle one bin late).
 #include "common.h"
+#include "ops.h"
 #include <cmath>
 
 namespace dsr {
@@ -193,7 +194,8 @@ __global__ void k_cmn(const float* __restrict__ cep, const int* __restrict__ Tar
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= U * N) return;
   const int u = idx / N, i = idx - u * N;
-  const int T = Tarr[u] < Tmax ? Tarr[u] : Tmax;
+  const int Tu = Tarr ? Tarr[u] : Tmax;
+  const int T = Tu < Tmax ? Tu : Tmax;
   const float* x = cep + (long) u * Tmax * N + i; float* o = out + (long) u * Tmax * N + i;
   if (mode == 1) {
     float m = 0.0f; double ttl = 0.0;
@@ -363,6 +365,36 @@ static void build_vtln(const dsr_mfcc_cfg& c, SparseRows& r, int& roundFloat)
   }
 }
 
+// ---- shared with the stream operators (ops.h)
+void build_vtln_rows(int N, double ratio, double edge, int version, SparseRowsD& r)
+{
+  dsr_mfcc_cfg c; memset(&c, 0, sizeof(c)); c.powN = N; c.vtlnRatio = ratio; c.vtlnEdge = edge; c.vtlnVersion = version;
+  SparseRows s; int rf = 0; build_vtln(c, s, rf);
+  r.start = s.start; r.count = s.count; r.off = s.off; r.coef = s.coef; r.div = s.div; r.roundFloat = rf;
+  if (r.coef.empty()) r.coef.push_back(0.0);
+}
+void build_mel_rows(int powN, float rate, float low, float up, int filterN, int version, SparseRowsF& r)
+{
+  dsr_mfcc_cfg c; memset(&c, 0, sizeof(c)); c.powN = powN; c.rate = rate; c.low = low; c.up = up; c.filterN = filterN; c.melVersion = version;
+  build_mel(c, r.start, r.count, r.off, r.coef, r.nReq);
+  if (r.coef.empty()) r.coef.push_back(0.f);
+}
+void build_dct(int ncep, int nmel, int type, std::vector<float>& dct)
+{
+  dct.assign((size_t) ncep * nmel, 0.f);
+  if (type == 0) {                                          // gslmatrix.cc:115-123
+    for (int k = 0; k < ncep; k++) { const double fac = k * M_PI / (double) (nmel - 1); float* q = &dct[(size_t) k * nmel];
+      *q++ = 1.0; for (int l = 1; l < nmel - 1; l++) *q++ = 2.0 * cos(fac * l); *q = cos(k * M_PI); }
+  } else if (type == 1) {                                   // :124-129
+    for (int k = 0; k < ncep; k++) { const double fac = k * M_PI / (double) nmel; for (int l = 0; l < nmel; l++) dct[(size_t) k * nmel + l] = cos(fac * (l + 0.5)); }
+  } else if (type == 2) {                                   // feature.cc:2466-2477
+    for (int k = 0; k < ncep; k++) { const double deltaF = M_PI * float(k) / nmel;
+      for (int f = 0; f < nmel; f++) { const double fr = deltaF * (f + 0.5); double cv = cos(fr) / nmel; if (f == 0) cv *= 0.5; dct[(size_t) k * nmel + f] = cv; } }
+  } else throw Error(DSR_E_INDEX, "Unknown DCT type");
+}
+void op_cmn(const float* in, int T, int N, int mode, double devNormFactor, float* out, hipStream_t st)
+{ if (T > 0) hipLaunchKernelGGL(k_cmn, dim3(cdiv(N, 64)), dim3(64), 0, st, in, (const int*) nullptr, 1, T, N, mode, devNormFactor, out); }
+
 }  // namespace dsr
 
 using namespace dsr;
@@ -409,16 +441,7 @@ dsr_status dsr_mfcc_create(const dsr_mfcc_cfg* cfg, const float* lda, dsr_mfcc**
     for (size_t i = 0; i < ms.size(); i++) if (ms[i] + mc[i] > c.powN) throw Error(DSR_E_CONSISTENCY, "mel filter %zu reads past the power spectrum", i);
     if (mco.empty()) mco.push_back(0.f);
     p->d_mStart.upload(ms); p->d_mCount.upload(mc); p->d_mOff.upload(mo); p->d_mCoef.upload(mco);
-    std::vector<float> dct((size_t) c.ncep * c.filterN);
-    if (c.dctType == 0) {                                          // gslmatrix.cc:115-123
-      for (int k = 0; k < c.ncep; k++) { const double fac = k * M_PI / (double) (c.filterN - 1); float* q = &dct[(size_t) k * c.filterN];
-        *q++ = 1.0; for (int l = 1; l < c.filterN - 1; l++) *q++ = 2.0 * cos(fac * l); *q = cos(k * M_PI); }
-    } else if (c.dctType == 1) {                                   // :124-129
-      for (int k = 0; k < c.ncep; k++) { const double fac = k * M_PI / (double) c.filterN; for (int l = 0; l < c.filterN; l++) dct[(size_t) k * c.filterN + l] = cos(fac * (l + 0.5)); }
-    } else if (c.dctType == 2) {                                   // feature.cc:2466-2477
-      for (int k = 0; k < c.ncep; k++) { const double deltaF = M_PI * float(k) / c.filterN;
-        for (int f = 0; f < c.filterN; f++) { const double fr = deltaF * (f + 0.5); double cv = cos(fr) / c.filterN; if (f == 0) cv *= 0.5; dct[(size_t) k * c.filterN + f] = cv; } }
-    } else throw Error(DSR_E_INDEX, "Unknown DCT type");
+    std::vector<float> dct; build_dct(c.ncep, c.filterN, c.dctType, dct);
     p->d_dct.upload(dct);
     if (c.outDim > 0) p->d_lda.upload(lda, (size_t) c.outDim * (2 * c.delta + 1) * c.ncep);
     *out = p;

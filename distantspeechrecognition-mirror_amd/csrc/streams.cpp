@@ -1,1 +1,330 @@
+// csrc/streams.cpp -- the stream/feature-operator API (include/dsr.h section 7).
+//
+// Mirrors FeatureStream<Type,item_type> (btk/stream/stream.h:36-75): reference-counted operators that
+// hold their upstream(s), `next(frameX)` / `reset()` / `size()` / `name()` / `current()` / `isEnd()`,
+// `frameX == -5` meaning "next", FrameResetX = -1, end of stream signalled as JITERATOR.
+//
+// The reference pulls one frame at a time through virtual calls; here an operator materialises its whole
+// utterance on the device at the first next() after a reset() (every source of the path holds the full
+// utterance in memory: SampleFeature::_samples, feature.cc:300-340) and then serves rows of its own
+// host-side output buffer.  Compute always runs on the GPU (k_ops.hip / k_filterbank.hip / k_beamform.hip).
 #include "common.h"
+#include "ops.h"
+#include <cmath>
+
+using namespace dsr;
+
+struct dsr_fb; struct dsr_bf;
+
+struct dsr_stream {
+  int refs = 1; std::string name; int size_ = 0; int type = DSR_T_FLOAT; int frameX = -1; bool endOfSamples = false;
+  std::vector<dsr_stream*> ups;
+  bool ready = false; int nFrames = 0;
+  DevBuf<unsigned char> dev; std::vector<unsigned char> host;
+  bool checkOrder = true;            // feature.cc operators throw jindex_error on out-of-order requests
+  bool randomAccess = false;         // StorageFeature
+  virtual ~dsr_stream() { for (size_t i = 0; i < ups.size(); i++) dsr_stream_release(ups[i]); }
+  size_t itemsize() const { return type == DSR_T_CHAR ? 1 : type == DSR_T_SHORT ? 2 : type == DSR_T_FLOAT ? 4 : type == DSR_T_DOUBLE ? 8 : 16; }
+  size_t rowBytes() const { return (size_t) size_ * itemsize(); }
+  virtual void compute() = 0;        // fills dev (nFrames rows)
+  virtual void reset() { frameX = -1; endOfSamples = false; ready = false; for (size_t i = 0; i < ups.size(); i++) ups[i]->reset(); }
+  void add_up(dsr_stream* u) { dsr_stream_retain(u); ups.push_back(u); }
+  void materialize() {
+    if (ready) return;
+    require_device();
+    for (size_t i = 0; i < ups.size(); i++) ups[i]->materialize();
+    compute();
+    host.assign((size_t) nFrames * rowBytes() + 16, 0);
+    if (nFrames > 0) { DSR_HIP(hipMemcpy(host.data(), dev.p, (size_t) nFrames * rowBytes(), hipMemcpyDeviceToHost)); }
+    ready = true;
+  }
+  const void* row(int t) const { return host.data() + (size_t) t * rowBytes(); }
+  virtual const void* next(int fx) {
+    if (fx == frameX && frameX >= 0) return row(frameX);
+    if (randomAccess && fx >= 0 && fx <= frameX) return row(fx);
+    if (checkOrder && fx >= 0 && fx - 1 != frameX) throw Error(DSR_E_INDEX, "Problem in Feature %s: %d != %d", name.c_str(), fx - 1, frameX);
+    materialize();
+    if (frameX + 1 >= nFrames) { endOfSamples = true; throw Error(DSR_E_ITERATOR, "end of samples!"); }
+    frameX++;
+    return row(frameX);
+  }
+  template <class T> T* d() { return reinterpret_cast<T*>(dev.p); }
+  void alloc(int T) { nFrames = T; dev.reserve((size_t) (T > 0 ? T : 1) * rowBytes()); }
+};
+
+namespace {
+
+hipStream_t S0 = nullptr;
+
+struct SampleSrc : dsr_stream {      // SampleFeature (feature.cc:222-689)
+  int blockLen, shiftLen, padZeros; std::vector<float> samples; DevBuf<float> dx;
+  void compute() override {
+    const int n = (int) samples.size(); int T;
+    if (padZeros) T = (n + shiftLen - 1) / shiftLen; else { long a = (long) n - blockLen; T = a > 0 ? (int) ((a + shiftLen - 1) / shiftLen) : 0; }
+    dx.upload(samples.data(), samples.size() ? samples.size() : 0); if (!dx.p) dx.reserve(1);
+    alloc(T); op_frames(dx.p, n, T, blockLen, shiftLen, d<float>(), S0);
+  }
+};
+struct FrameSrc : dsr_stream {       // PyFeatureStream-like source: the caller hands over all frames (pyStream.h:44-130)
+  std::vector<unsigned char> frames; int T = 0;
+  void compute() override { alloc(T); if (T > 0) DSR_HIP(hipMemcpy(dev.p, frames.data(), (size_t) T * rowBytes(), hipMemcpyHostToDevice)); }
+};
+struct Preemph : dsr_stream { double mu; void compute() override { alloc(ups[0]->nFrames); op_preemph(ups[0]->d<float>(), nFrames, size_, mu, d<float>(), S0); } };
+struct Hamming : dsr_stream {
+  DevBuf<double> w;
+  void compute() override {
+    alloc(ups[0]->nFrames);
+    if (ups[0]->type == DSR_T_SHORT) op_hamming_s(ups[0]->d<short>(), nFrames, size_, w.p, d<float>(), S0);
+    else op_hamming_f(ups[0]->d<float>(), nFrames, size_, w.p, d<float>(), S0);
+  }
+};
+struct FFTOp : dsr_stream { int L; DevBuf<double2> tw; void compute() override { alloc(ups[0]->nFrames); op_fft(ups[0]->d<float>(), nFrames, L, size_, tw.p, d<double2>(), S0); } };
+struct PowerOp : dsr_stream { int fftLen; void compute() override { alloc(ups[0]->nFrames); op_power(ups[0]->d<double2>(), nFrames, fftLen, size_, d<double>(), S0); } };
+struct VtlnOp : dsr_stream {
+  DevBuf<int> s, c, o; DevBuf<double> coef, div; int rf = 0;
+  void compute() override { alloc(ups[0]->nFrames); op_vtln(ups[0]->d<double>(), nFrames, size_, s.p, c.p, o.p, coef.p, div.p, rf, d<double>(), S0); }
+};
+struct MelOp : dsr_stream {
+  DevBuf<int> s, c, o; DevBuf<float> coef; int inN;
+  void compute() override { alloc(ups[0]->nFrames); op_mel(ups[0]->d<double>(), nFrames, inN, size_, s.p, c.p, o.p, coef.p, d<double>(), S0); }
+};
+struct LogOp : dsr_stream { double m, a; int sphinx; void compute() override { alloc(ups[0]->nFrames); op_log(ups[0]->d<double>(), (long) nFrames * size_, m, a, sphinx, d<float>(), S0); } };
+struct GemvOp : dsr_stream {         // CepstralFeature and LinearTransformFeature
+  DevBuf<float> A; std::vector<float> hA;
+  void compute() override { alloc(ups[0]->nFrames); op_sgemv(ups[0]->d<float>(), nFrames, ups[0]->size_, size_, A.p, d<float>(), S0); }
+};
+struct StorageOp : dsr_stream {      // StorageFeature (feature.cc:2992-3085)
+  void compute() override {
+    if (ups[0]->nFrames > 100000) throw Error(DSR_E_DIMENSION, "Frame %d is greater than maximum number %d.", ups[0]->nFrames, 100000);
+    alloc(ups[0]->nFrames); if (nFrames > 0) DSR_HIP(hipMemcpy(dev.p, ups[0]->dev.p, (size_t) nFrames * rowBytes(), hipMemcpyDeviceToDevice));
+  }
+};
+struct CmnOp : dsr_stream { int mode; double dnf; void compute() override { alloc(ups[0]->nFrames); op_cmn(ups[0]->d<float>(), nFrames, size_, mode, dnf, d<float>(), S0); } };
+struct AdjOp : dsr_stream {
+  int delta;
+  void compute() override { int T = ups[0]->nFrames; if (delta > 0 && T < delta) T = 0; alloc(T); op_adjacent(ups[0]->d<float>(), T, ups[0]->size_, delta, d<float>(), S0); }
+};
+struct AnalysisOp : dsr_stream {     // OverSampledDFTAnalysisBank
+  dsr_fb* fb = nullptr; int M, D; DevBuf<float> x; DevBuf<float2> X; DevBuf<int> ns;
+  ~AnalysisOp() override { if (fb) dsr_fb_destroy(fb); }
+  void compute() override {
+    // upstream delivers blocks of D samples (blockLen = shiftLen = D, padZeros): concatenate them again
+    dsr_stream* u = ups[0]; const int nblk = u->nFrames; const int n = nblk * D;
+    int T = dsr_fb_analysis_frames(fb, n); alloc(T);
+    x.reserve(n > 0 ? n : 1); if (n > 0) DSR_HIP(hipMemcpy(x.p, u->dev.p, (size_t) n * sizeof(float), hipMemcpyDeviceToDevice));
+    ns.upload(&n, 1);
+    if (T > 0) {
+      X.reserve((size_t) T * (M / 2 + 1));
+      dsr_status s = dsr_fb_analysis(fb, x.p, ns.p, 1, 1, n > 0 ? n : 1, T, (float*) X.p, S0); if (s) throw Error(s, "%s", dsr_last_error());
+      op_expand_bins(X.p, T, M / 2 + 1, M, d<double2>(), S0);
+    }
+  }
+};
+struct SynthesisOp : dsr_stream {    // OverSampledDFTSynthesisBank
+  dsr_fb* fb = nullptr; int M, D; DevBuf<float2> Y; DevBuf<int> nf;
+  ~SynthesisOp() override { if (fb) dsr_fb_destroy(fb); }
+  void compute() override {
+    dsr_stream* u = ups[0]; const int Tin = u->nFrames; const int nb = dsr_fb_synthesis_blocks(fb, Tin); alloc(nb);
+    if (nb <= 0) return;
+    Y.reserve((size_t) Tin * (M / 2 + 1)); op_pack_bins(u->d<double2>(), Tin, M / 2 + 1, M, Y.p, S0);
+    nf.upload(&Tin, 1);
+    dsr_status s = dsr_fb_synthesis(fb, (const float*) Y.p, nf.p, 1, Tin, (int64_t) nb * D, d<float>(), S0); if (s) throw Error(s, "%s", dsr_last_error());
+  }
+};
+struct BfOp : dsr_stream {           // SubbandDS / SubbandGSC / SubbandMVDR as a stream
+  dsr_bf* w; int M; DevBuf<float2> X, Y;
+  void compute() override {
+    const int C = (int) ups.size();
+    if (C == 0 || C != dsr_bf_chan_n(w)) throw Error(DSR_E_DIMENSION, "Number of channels (%d) does not match the weights (%d)", C, dsr_bf_chan_n(w));
+    int T = ups[0]->nFrames; for (int c = 1; c < C; c++) if (ups[c]->nFrames < T) T = ups[c]->nFrames;
+    alloc(T); if (T <= 0) return;
+    const int F = M / 2 + 1; X.reserve((size_t) C * T * F); Y.reserve((size_t) T * F);
+    for (int c = 0; c < C; c++) op_pack_bins(ups[c]->d<double2>(), T, F, M, X.p + (size_t) c * T * F, S0);
+    dsr_status s = dsr_bf_apply(w, (const float*) X.p, 1, T, (float*) Y.p, S0); if (s) throw Error(s, "%s", dsr_last_error());
+    op_expand_bins(Y.p, T, F, M, d<double2>(), S0);
+  }
+};
+
+template <class T> T* mk(const char* name, const char* dflt, int size, int type) { T* s = new T(); s->name = (name && *name) ? name : dflt; s->size_ = size; s->type = type; return s; }
+dsr_stream* need(dsr_stream* s, int type, const char* what) {
+  if (!s) throw Error(DSR_E_PARAMETER, "null upstream for %s", what);
+  if (s->type != type) throw Error(DSR_E_TYPE, "%s needs an upstream of element type %d, got %d", what, type, s->type);
+  return s;
+}
+
+}  // namespace
+
+extern "C" {
+
+void dsr_stream_retain(dsr_stream* s) { if (s) s->refs++; }
+void dsr_stream_release(dsr_stream* s) { if (s && --s->refs == 0) delete s; }
+int dsr_stream_size(const dsr_stream* s) { return s->size_; }
+int dsr_stream_type(const dsr_stream* s) { return s->type; }
+int dsr_stream_frameX(const dsr_stream* s) { return s->frameX; }
+int dsr_stream_is_end(const dsr_stream* s) { return s->endOfSamples ? 1 : 0; }
+const char* dsr_stream_name(const dsr_stream* s) { return s->name.c_str(); }
+
+dsr_status dsr_stream_next(dsr_stream* s, int frameX, const void** data, size_t* n)
+{ return guard([&] { if (!s || !data) throw Error(DSR_E_PARAMETER, "null argument"); *data = s->next(frameX); if (n) *n = (size_t) s->size_; }); }
+dsr_status dsr_stream_current(dsr_stream* s, const void** data, size_t* n)
+{
+  return guard([&] {
+    if (!s || !data) throw Error(DSR_E_PARAMETER, "null argument");
+    if (s->frameX < 0) throw Error(DSR_E_CONSISTENCY, "Frame index (%d) < 0.", s->frameX);      // stream.h:44-46
+    *data = s->next(s->frameX); if (n) *n = (size_t) s->size_;
+  });
+}
+dsr_status dsr_stream_reset(dsr_stream* s) { return guard([&] { if (!s) throw Error(DSR_E_PARAMETER, "null argument"); s->reset(); }); }
+
+dsr_status dsr_sample_feature_create(int blockLen, int shiftLen, int padZeros, const char* name, dsr_stream** out)
+{
+  return guard([&] {
+    if (!out || blockLen < 1 || shiftLen < 1) throw Error(DSR_E_PARAMETER, "bad argument");
+    SampleSrc* s = mk<SampleSrc>(name, "Sample", blockLen, DSR_T_FLOAT); s->blockLen = blockLen; s->shiftLen = shiftLen; s->padZeros = padZeros;
+    s->checkOrder = true; *out = s;
+  });
+}
+dsr_status dsr_sample_feature_set_samples(dsr_stream* s, const float* samples, size_t n, unsigned sampleRate)
+{
+  (void) sampleRate;
+  return guard([&] {
+    SampleSrc* q = dynamic_cast<SampleSrc*>(s); if (!q || (!samples && n)) throw Error(DSR_E_PARAMETER, "not a SampleFeature");
+    q->samples.assign(samples, samples + n); q->reset();                                       // setSamples() resets (feature.cc:688)
+  });
+}
+dsr_status dsr_frame_source_create(int type, int size, const char* name, dsr_stream** out)
+{
+  return guard([&] {
+    if (!out || size < 1 || type < 0 || type > DSR_T_COMPLEX) throw Error(DSR_E_PARAMETER, "bad argument");
+    FrameSrc* s = mk<FrameSrc>(name, "PyFeatureStream", size, type); s->checkOrder = false; *out = s;
+  });
+}
+dsr_status dsr_frame_source_set_frames(dsr_stream* s, const void* data, size_t nframes)
+{
+  return guard([&] {
+    FrameSrc* q = dynamic_cast<FrameSrc*>(s); if (!q || (!data && nframes)) throw Error(DSR_E_PARAMETER, "not a frame source");
+    q->frames.assign((const unsigned char*) data, (const unsigned char*) data + nframes * q->rowBytes()); q->T = (int) nframes; q->reset();
+  });
+}
+
+dsr_status dsr_analysis_bank_create(dsr_stream* samp, const double* prototype, int M, int m, int r, int dct, const char* name, dsr_stream** out)
+{
+  return guard([&] {
+    need(samp, DSR_T_FLOAT, "OverSampledDFTAnalysisBank"); if (!out || !prototype) throw Error(DSR_E_PARAMETER, "null argument");
+    const int D = M >> r;
+    if (samp->size_ != D) throw Error(DSR_E_DIMENSION, "Input block length (%d) != _D (%d)", samp->size_, D);      // modulated.cc:373-374
+    AnalysisOp* s = mk<AnalysisOp>(name, "OverSampledDFTAnalysisBank", M, DSR_T_COMPLEX); s->M = M; s->D = D; s->checkOrder = false;
+    dsr_status st = dsr_fb_create(prototype, M, m, r, 0, dct, 1, &s->fb); if (st) { delete s; throw Error(st, "%s", dsr_last_error()); }
+    s->add_up(samp); *out = s;
+  });
+}
+dsr_status dsr_synthesis_bank_create(dsr_stream* samp, const double* prototype, int M, int m, int r, int dct, int gain, const char* name, dsr_stream** out)
+{
+  return guard([&] {
+    need(samp, DSR_T_COMPLEX, "OverSampledDFTSynthesisBank"); if (!out || !prototype) throw Error(DSR_E_PARAMETER, "null argument");
+    if (samp->size_ != M) throw Error(DSR_E_DIMENSION, "Input size (%d) != M (%d)", samp->size_, M);
+    SynthesisOp* s = mk<SynthesisOp>(name, "OverSampledDFTSynthesisBank", M >> r, DSR_T_FLOAT); s->M = M; s->D = M >> r; s->checkOrder = false;
+    dsr_status st = dsr_fb_create(prototype, M, m, r, 1, dct, gain, &s->fb); if (st) { delete s; throw Error(st, "%s", dsr_last_error()); }
+    s->add_up(samp); *out = s;
+  });
+}
+dsr_status dsr_subband_bf_create(dsr_bf* weights, const char* name, dsr_stream** out)
+{
+  return guard([&] {
+    if (!weights || !out) throw Error(DSR_E_PARAMETER, "null argument");
+    BfOp* s = mk<BfOp>(name, "SubbandBeamformer", dsr_bf_fft_len(weights), DSR_T_COMPLEX); s->w = weights; s->M = dsr_bf_fft_len(weights); s->checkOrder = false; *out = s;
+  });
+}
+dsr_status dsr_subband_bf_set_channel(dsr_stream* bf, dsr_stream* chan)
+{
+  return guard([&] {
+    BfOp* q = dynamic_cast<BfOp*>(bf); if (!q) throw Error(DSR_E_PARAMETER, "not a subband beamformer");
+    need(chan, DSR_T_COMPLEX, "setChannel"); if (chan->size_ != q->M) throw Error(DSR_E_DIMENSION, "channel size %d != fftLen %d", chan->size_, q->M);
+    q->add_up(chan); q->ready = false;
+  });
+}
+dsr_status dsr_preemphasis_create(dsr_stream* samp, double mu, const char* name, dsr_stream** out)
+{ return guard([&] { need(samp, DSR_T_FLOAT, "PreemphasisFeature"); Preemph* s = mk<Preemph>(name, "Preemphasis", samp->size_, DSR_T_FLOAT); s->mu = mu; s->add_up(samp); *out = s; }); }
+dsr_status dsr_hamming_create(dsr_stream* samp, const char* name, dsr_stream** out)
+{
+  return guard([&] {
+    if (!samp || (samp->type != DSR_T_FLOAT && samp->type != DSR_T_SHORT)) throw Error(DSR_E_TYPE, "HammingFeature needs a float or short stream");
+    Hamming* s = mk<Hamming>(name, "Hamming", samp->size_, DSR_T_FLOAT);
+    std::vector<double> w(samp->size_); const double temp = 2. * M_PI / (double) (samp->size_ - 1);
+    for (int i = 0; i < samp->size_; i++) w[i] = 0.54 - 0.46 * cos(temp * i);
+    require_device(); s->w.upload(w); s->add_up(samp); *out = s;
+  });
+}
+dsr_status dsr_fft_create(dsr_stream* samp, int fftLen, const char* name, dsr_stream** out)
+{
+  return guard([&] {
+    need(samp, DSR_T_FLOAT, "FFTFeature");
+    if (!is_pow2((unsigned) fftLen) || fftLen < 2 || fftLen > 8192 || samp->size_ > fftLen) throw Error(DSR_E_DIMENSION, "fftLen=%d must be a power of two >= the window length %d", fftLen, samp->size_);
+    FFTOp* s = mk<FFTOp>(name, "FFT", fftLen, DSR_T_COMPLEX); s->L = samp->size_;
+    std::vector<double2> tw(fftLen); for (int k = 0; k < fftLen; k++) { const double a = 2.0 * M_PI * k / fftLen; tw[k] = make_double2(cos(a), sin(a)); }
+    require_device(); s->tw.upload(tw); s->add_up(samp); *out = s;
+  });
+}
+dsr_status dsr_spectral_power_create(dsr_stream* fft, int powN, const char* name, dsr_stream** out)
+{
+  return guard([&] {
+    need(fft, DSR_T_COMPLEX, "SpectralPowerFeature"); const int sz = powN == 0 ? fft->size_ : powN;
+    if (sz != fft->size_ && sz != fft->size_ / 2 + 1) throw Error(DSR_E_CONSISTENCY, "Number of power coefficients %d does not match FFT length %d.", sz, fft->size_);
+    PowerOp* s = mk<PowerOp>(name, "Power", sz, DSR_T_DOUBLE); s->fftLen = fft->size_; s->add_up(fft); *out = s;
+  });
+}
+dsr_status dsr_vtln_create(dsr_stream* pow, int coeffN, double ratio, double edge, int version, const char* name, dsr_stream** out)
+{
+  return guard([&] {
+    need(pow, DSR_T_DOUBLE, "VTLNFeature"); const int N = coeffN == 0 ? pow->size_ : coeffN;
+    if (N != pow->size_) throw Error(DSR_E_DIMENSION, "VTLN size %d != input size %d", N, pow->size_);
+    if (version != 1 && version != 2) throw Error(DSR_E_PARAMETER, "unknown version number (%d)", version);
+    VtlnOp* s = mk<VtlnOp>(name, "VTLN", N, DSR_T_DOUBLE); SparseRowsD r; build_vtln_rows(N, ratio, edge, version, r);
+    require_device(); s->s.upload(r.start); s->c.upload(r.count); s->o.upload(r.off); s->coef.upload(r.coef); s->div.upload(r.div); s->rf = r.roundFloat;
+    s->add_up(pow); *out = s;
+  });
+}
+dsr_status dsr_mel_create(dsr_stream* mag, int powN, float rate, float low, float up, int filterN, int version, const char* name, dsr_stream** out)
+{
+  return guard([&] {
+    need(mag, DSR_T_DOUBLE, "MelFeature"); const int P = powN == 0 ? mag->size_ : powN;
+    MelOp* s = mk<MelOp>(name, "MelFFT", filterN, DSR_T_DOUBLE); SparseRowsF r; build_mel_rows(P, rate, low, up, filterN, version, r);
+    if (mag->size_ < r.nReq) { delete s; throw Error(DSR_E_CONSISTENCY, "Matrix columns differ: %d and %d.", mag->size_, r.nReq); }
+    for (size_t i = 0; i < r.start.size(); i++) if (r.start[i] + r.count[i] > mag->size_) { delete s; throw Error(DSR_E_CONSISTENCY, "mel filter %zu reads past the input", i); }
+    require_device(); s->s.upload(r.start); s->c.upload(r.count); s->o.upload(r.off); s->coef.upload(r.coef); s->inN = mag->size_;
+    s->add_up(mag); *out = s;
+  });
+}
+dsr_status dsr_log_create(dsr_stream* mel, double m, double a, int sphinx, const char* name, dsr_stream** out)
+{ return guard([&] { need(mel, DSR_T_DOUBLE, "LogFeature"); LogOp* s = mk<LogOp>(name, "LogMel", mel->size_, DSR_T_FLOAT); s->m = m; s->a = a; s->sphinx = sphinx; s->add_up(mel); *out = s; }); }
+dsr_status dsr_cepstral_create(dsr_stream* mel, int ncep, int type, const char* name, dsr_stream** out)
+{
+  return guard([&] {
+    need(mel, DSR_T_FLOAT, "CepstralFeature");
+    GemvOp* s = mk<GemvOp>(name, "Cepstral", ncep, DSR_T_FLOAT); build_dct(ncep, mel->size_, type, s->hA);
+    require_device(); s->A.upload(s->hA); s->add_up(mel); *out = s;
+  });
+}
+dsr_status dsr_storage_create(dsr_stream* src, const char* name, dsr_stream** out)
+{ return guard([&] { need(src, DSR_T_FLOAT, "StorageFeature"); StorageOp* s = mk<StorageOp>(name, "Storage", src->size_, DSR_T_FLOAT); s->randomAccess = true; s->checkOrder = false; s->add_up(src); *out = s; }); }
+dsr_status dsr_mean_subtraction_create(dsr_stream* src, double dnf, int runon, const char* name, dsr_stream** out)
+{ return guard([&] { need(src, DSR_T_FLOAT, "MeanSubtractionFeature"); CmnOp* s = mk<CmnOp>(name, "Mean Subtraction", src->size_, DSR_T_FLOAT); s->mode = runon ? 2 : 1; s->dnf = dnf; s->add_up(src); *out = s; }); }
+dsr_status dsr_adjacent_create(dsr_stream* single, int delta, const char* name, dsr_stream** out)
+{ return guard([&] { need(single, DSR_T_FLOAT, "AdjacentFeature"); AdjOp* s = mk<AdjOp>(name, "Adjacent", (2 * delta + 1) * single->size_, DSR_T_FLOAT); s->delta = delta; s->add_up(single); *out = s; }); }
+dsr_status dsr_linear_transform_create(dsr_stream* src, int sz, const char* name, dsr_stream** out)
+{
+  return guard([&] {
+    need(src, DSR_T_FLOAT, "LinearTransformFeature"); if (sz < 1) throw Error(DSR_E_DIMENSION, "bad output size %d", sz);
+    GemvOp* s = mk<GemvOp>(name, "Transform", sz, DSR_T_FLOAT); s->hA.assign((size_t) sz * src->size_, 0.0f);     // calloc'd matrix (feature.cc:2936)
+    require_device(); s->A.upload(s->hA); s->add_up(src); *out = s;
+  });
+}
+dsr_status dsr_linear_transform_set(dsr_stream* s, const float* matrix)
+{
+  return guard([&] {
+    GemvOp* q = dynamic_cast<GemvOp*>(s); if (!q || !matrix) throw Error(DSR_E_PARAMETER, "not a linear transform");
+    q->hA.assign(matrix, matrix + q->hA.size()); q->A.upload(q->hA); q->ready = false;
+  });
+}
+
+}  // extern "C"

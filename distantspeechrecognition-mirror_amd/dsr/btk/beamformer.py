@@ -1,0 +1,82 @@
+"""btk.beamformer: SubbandDSPtr / SubbandGSCPtr / SubbandMVDRPtr (beamformer.i:298-323) as streams."""
+import numpy as np
+
+from .. import _capi as K
+from .stream import FeatureStreamPtr, lib, _new
+
+
+class _Subband(FeatureStreamPtr):
+    _MODE = 0
+
+    def __init__(self, fftLen=512, halfBandShift=False, nm="SubbandBeamformer"):
+        if halfBandShift and self._MODE == 1:
+            raise K.DsrError(2, "halfBandShift==true is not yet supported")            # beamformer.cc:2324-2327
+        self._fftLen, self._hbs, self._nm = fftLen, halfBandShift, nm
+        self._chans = []; self._w = None; FeatureStreamPtr.__init__(self, None)
+
+    def setChannel(self, chan):
+        self._chans.append(chan)
+
+    def chanN(self):
+        return len(self._chans)
+
+    def _weights(self):
+        if self._w is None:
+            self._w = K.Beamformer(self._fftLen, len(self._chans), self._hbs); self._w.select(self._MODE)
+            h, _ = _new(lib().dsr_subband_bf_create, self._w.h, self._nm.encode()); self._h = h
+            for c in self._chans:
+                K.check(lib().dsr_subband_bf_set_channel(self._h, c._h))
+        return self._w
+
+    def calcArrayManifoldVectors(self, sampleRate, delays):
+        self._weights().calcArrayManifoldVectors(sampleRate, delays)
+
+    def next(self, frameX=-5):
+        if self._w is None:
+            raise K.DsrError(1, "call calcArrayManifoldVectorsX() once")
+        return FeatureStreamPtr.next(self, frameX)
+
+    __next__ = next
+
+
+class SubbandDSPtr(_Subband):
+    _MODE = 0
+
+
+class SubbandGSCPtr(_Subband):
+    _MODE = 2
+
+    def calcGSCWeights(self, sampleRate, delaysT):
+        self._weights().calcGSCWeights(sampleRate, delaysT)
+
+    def setActiveWeights_f(self, fbinX, packedWeight):
+        self._weights().setActiveWeights_f(fbinX, packedWeight)
+
+    def zeroActiveWeights(self):
+        self._weights().zeroActiveWeights()
+
+
+class SubbandMVDRPtr(_Subband):
+    _MODE = 1
+
+    def setDiffuseNoiseModel(self, micPositions, sampleRate, sspeed=343740.0):
+        self._weights().setDiffuseNoiseModel(micPositions, sampleRate, sspeed); return True
+
+    def divideAllNonDiagonalElements(self, myu):
+        self._weights().divideAllNonDiagonalElements(myu)
+
+    def setAllLevelsOfDiagonalLoading(self, w):
+        self._weights().setAllLevelsOfDiagonalLoading(w)
+
+    def setNoiseSpatialSpectralMatrix(self, fbinX, Rnn):
+        self._weights().setNoiseSpatialSpectralMatrix(fbinX, Rnn); return True
+
+    def calcMVDRWeights(self, sampleRate, dThreshold=1.0e-8, calcInverseMatrix=True):
+        self._weights().calcMVDRWeights(sampleRate, dThreshold); return True
+
+    def getMVDRWeights(self, fbinX):
+        return self._weights().get(1)[fbinX]
+
+
+def calcDelaysPolar2(azimuth, elevation, micPositions):
+    return K.calcDelaysPolar2(np.float32(azimuth), np.float32(elevation), micPositions)

@@ -1,0 +1,162 @@
+"""btk.feature: the MFCC operator chain with the SWIG constructor signatures of btk/feature/feature.i."""
+import ctypes as C
+import wave
+
+import numpy as np
+
+from .. import _capi as K
+from .stream import FeatureStreamPtr, lib, _new
+
+
+def _b(s):
+    return s.encode() if isinstance(s, str) else s
+
+
+class SampleFeaturePtr(FeatureStreamPtr):
+    """feature.i:526-528.  read() takes 16-bit PCM WAV (libsndfile in the reference, feature.cc:243-393; samples are
+    kept un-normalised, i.e. at int16 scale, as with norm == 0)."""
+
+    def __init__(self, fn="", blockLen=320, shiftLen=160, padZeros=False, nm="Sample"):
+        h, _ = _new(lib().dsr_sample_feature_create, blockLen, shiftLen, int(padZeros), _b(nm)); FeatureStreamPtr.__init__(self, h)
+        self._rate = 16000
+        if fn != "":
+            self.read(fn)
+
+    def read(self, fn, samplerate=44100, chX=1, chN=1):
+        try:
+            w = wave.open(fn, "rb")
+        except (IOError, OSError, wave.Error) as e:
+            raise IOError("Could not open file %s: %s" % (fn, e))
+        if w.getsampwidth() != 2:
+            raise IOError("only 16-bit PCM is supported")
+        a = np.frombuffer(w.readframes(w.getnframes()), dtype="<i2").reshape(-1, w.getnchannels())
+        self._rate = w.getframerate()
+        self.setSamples(a[:, max(0, chX - 1)].astype(np.float32), self._rate)
+        return a.shape[0]
+
+    def setSamples(self, samples, sampleRate=16000):
+        a = np.ascontiguousarray(samples, dtype=np.float32)
+        K.check(lib().dsr_sample_feature_set_samples(self._h, a.ctypes.data_as(C.c_void_p), a.size, int(sampleRate)))
+
+    def getSampleRate(self):
+        return self._rate
+
+
+def _unary(create, dflt):
+    class Op(FeatureStreamPtr):
+        def __init__(self, src, *a, **kw):
+            nm = kw.pop("nm", dflt)
+            h, _ = _new(create, src._h, *self._args(src, *a, **kw), _b(nm)); FeatureStreamPtr.__init__(self, h, keep=(src,))
+    return Op
+
+
+class PreemphasisFeaturePtr(_unary(lambda *a: lib().dsr_preemphasis_create(*a), "Preemphasis")):
+    def _args(self, src, mu=0.95):
+        return (float(mu),)
+
+
+class HammingFeaturePtr(_unary(lambda *a: lib().dsr_hamming_create(*a), "Hamming")):
+    def _args(self, src):
+        return ()
+
+
+HammingFeatureShortPtr = HammingFeaturePtr
+
+
+class FFTFeaturePtr(_unary(lambda *a: lib().dsr_fft_create(*a), "FFT")):
+    def _args(self, src, fftLen=512):
+        return (int(fftLen),)
+
+
+class SpectralPowerFeaturePtr(_unary(lambda *a: lib().dsr_spectral_power_create(*a), "Power")):
+    def _args(self, src, powN=0):
+        return (int(powN),)
+
+
+PowerFeaturePtr = SpectralPowerFeaturePtr
+
+
+class VTLNFeaturePtr(_unary(lambda *a: lib().dsr_vtln_create(*a), "VTLN")):
+    def _args(self, src, coeffN=0, ratio=1.0, edge=1.0, version=1):
+        return (int(coeffN), float(ratio), float(edge), int(version))
+
+
+class MelFeaturePtr(_unary(lambda *a: lib().dsr_mel_create(*a), "MelFFT")):
+    def _args(self, src, powN=0, rate=16000.0, low=0.0, up=0.0, filterN=30, version=1):
+        return (int(powN), float(rate), float(low), float(up), int(filterN), int(version))
+
+
+class LogFeaturePtr(_unary(lambda *a: lib().dsr_log_create(*a), "LogMel")):
+    def _args(self, src, m=1.0, a=1.0, sphinxFlooring=False):
+        return (float(m), float(a), int(sphinxFlooring))
+
+
+class CepstralFeaturePtr(_unary(lambda *a: lib().dsr_cepstral_create(*a), "Cepstral")):
+    def _args(self, src, ncep=13, type=1):
+        return (int(ncep), int(type))
+
+
+class StorageFeaturePtr(_unary(lambda *a: lib().dsr_storage_create(*a), "Storage")):
+    def _args(self, src):
+        return ()
+
+    def evaluate(self):
+        self.reset(); n = 0
+        try:
+            while True:
+                self.next(n); n += 1
+        except StopIteration:
+            pass
+        return n - 1
+
+
+class MeanSubtractionFeaturePtr(_unary(lambda *a: lib().dsr_mean_subtraction_create(*a), "Mean Subtraction")):
+    def _args(self, src, weight=None, devNormFactor=0.0, runon=False):
+        if weight is not None:
+            raise K.DsrError(13, "per-frame weights are not supported")
+        return (float(devNormFactor), int(runon))
+
+
+class AdjacentFeaturePtr(_unary(lambda *a: lib().dsr_adjacent_create(*a), "Adjacent")):
+    def _args(self, src, delta=5):
+        return (int(delta),)
+
+
+class LinearTransformFeaturePtr(_unary(lambda *a: lib().dsr_linear_transform_create(*a), "Transform")):
+    def _args(self, src, sz=0):
+        self._shape = (int(sz), src.size()); return (int(sz),)
+
+    def setMatrix(self, m):
+        a = np.ascontiguousarray(m, dtype=np.float32)
+        if a.shape != self._shape:
+            raise K.DsrError(5, "Matrix (%d x %d) does not match (%d x %d)" % (a.shape + self._shape))
+        K.check(lib().dsr_linear_transform_set(self._h, a.ctypes.data_as(C.c_void_p)))
+
+    def identity(self):
+        if self._shape[0] != self._shape[1]:
+            raise K.DsrError(5, "Cannot set an (%d x %d) matrix to identity." % self._shape)
+        self.setMatrix(np.eye(self._shape[0], dtype=np.float32))
+
+    def load(self, fileName, old=False):
+        """GSL raw float matrix (native endian) or Janus 'FMAT' big-endian file (btk/matrix/gslmatrix.cc:27-96)."""
+        raw = open(fileName, "rb").read()
+        if raw[:4] == b"FMAT":
+            rows, cols = int.from_bytes(raw[4:8], "big"), int.from_bytes(raw[8:12], "big")
+            a = np.frombuffer(raw[16:16 + 4 * rows * cols], dtype=">f4").reshape(rows, cols).astype(np.float32)
+        else:
+            a = np.frombuffer(raw, dtype=np.float32)
+            a = a[: (a.size // self._shape[1]) * self._shape[1]].reshape(-1, self._shape[1])
+        self.setMatrix(a[: self._shape[0], : self._shape[1]])
+
+
+class FeatureSetPtr(object):
+    """feature.h:1486-1501: name -> stream registry the codebooks look their feature up in."""
+
+    def __init__(self, nm="FeatureSet"):
+        self._d = {}
+
+    def add(self, feat):
+        self._d[feat.name()] = feat
+
+    def feature(self, nm):
+        return self._d[nm]

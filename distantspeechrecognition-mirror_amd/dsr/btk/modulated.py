@@ -1,0 +1,26 @@
+"""btk.modulated: OverSampledDFTAnalysisBankPtr / OverSampledDFTSynthesisBankPtr (modulated.i:117-131,160-164)."""
+import ctypes as C
+
+import numpy as np
+
+from .stream import FeatureStreamPtr, lib, _new
+
+
+class OverSampledDFTAnalysisBankPtr(FeatureStreamPtr):
+    def __init__(self, samp, prototype, M, m, r, delayCompensationType=0, nm="OverSampledDFTAnalysisBank"):
+        p = np.ascontiguousarray(prototype, dtype=np.float64)
+        if p.size != M * m:
+            from .. import _capi as K
+            raise K.DsrError(4, "Prototype sizes do not match (%d vs. %d)." % (p.size, M * m))
+        h, _ = _new(lib().dsr_analysis_bank_create, samp._h, p.ctypes.data_as(C.c_void_p), M, m, r, delayCompensationType, nm.encode())
+        FeatureStreamPtr.__init__(self, h, keep=(samp,)); self._M = M
+
+    def fftLen(self):
+        return self._M
+
+
+class OverSampledDFTSynthesisBankPtr(FeatureStreamPtr):
+    def __init__(self, samp, prototype, M, m, r=0, delayCompensationType=0, gainFactor=1, nm="OverSampledDFTSynthesisBank"):
+        p = np.ascontiguousarray(prototype, dtype=np.float64)
+        h, _ = _new(lib().dsr_synthesis_bank_create, samp._h, p.ctypes.data_as(C.c_void_p), M, m, r, delayCompensationType, gainFactor, nm.encode())
+        FeatureStreamPtr.__init__(self, h, keep=(samp,))

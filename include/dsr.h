@@ -269,6 +269,10 @@ void         dsr_stream_release(dsr_stream*);
 /* sources */
 dsr_status dsr_sample_feature_create(int blockLen, int shiftLen, int padZeros, const char* name, dsr_stream** out);
 dsr_status dsr_sample_feature_set_samples(dsr_stream*, const float* samples, size_t n, unsigned sampleRate);
+/* PyFeatureStream equivalent (btk/stream/pyStream.h:44-130): a source whose frames the caller supplies;
+   type is DSR_T_SHORT / DSR_T_FLOAT / DSR_T_DOUBLE / DSR_T_COMPLEX, data = nframes rows of `size` items */
+dsr_status dsr_frame_source_create(int type, int size, const char* name, dsr_stream** out);
+dsr_status dsr_frame_source_set_frames(dsr_stream*, const void* data, size_t nframes);
 /* operators (ctor argument order as the reference headers) */
 dsr_status dsr_analysis_bank_create(dsr_stream* samp, const double* prototype, int M, int m, int r,
                                     int delayCompensationType, const char* name, dsr_stream** out);

@@ -1,0 +1,121 @@
+"""CPU tests of the drop-in boundary: the C-ABI library loads without a GPU, exports every symbol include/dsr.h
+declares, keeps the reference's error convention, refuses to compute without a HIP device (no CPU fallback), and the
+host-side containers (decoding graph, lexicon) behave like the reference's."""
+import ctypes as C
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+from tests.conftest import ROOT, PKG
+
+LIB = os.path.join(PKG, "lib", "libdsr_hip.so")
+
+
+def test_library_exports_every_declared_symbol():
+    assert os.path.exists(LIB), "run __graft_entry__.build() first"
+    hdr = open(os.path.join(ROOT, "include", "dsr.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(dsr_[a-z0-9_]+)\s*\(", hdr))
+    out = subprocess.check_output(["nm", "-D", "--defined-only", LIB]).decode()
+    exported = set(re.findall(r" T (dsr_[a-z0-9_]+)", out))
+    assert len(declared) > 80
+    assert declared - exported == set(), sorted(declared - exported)
+    L = C.CDLL(LIB)
+    for name in declared:
+        assert hasattr(L, name)
+
+
+def test_error_codes_mirror_error_type(dsr):
+    # btk/common/jexception.h:41-57: JERROR=0 ... JTYPE=14; status = 1 + error_type
+    names = ["JERROR", "JALLOCATION", "JARITHMETIC", "JCONSISTENCY", "JDIMENSION", "JINDEX", "JINITIALIZATION", "JIO",
+             "JITERATOR", "JPYTHON", "JKEY", "JNUMERIC", "JPARAMETER", "JPARSE", "JTYPE"]
+    assert dsr.ERROR_NAMES[1:] == names and dsr.E_ITERATOR == 1 + names.index("JITERATOR")
+    e = dsr.DsrError(9, "end of samples!")
+    assert e.code == names.index("JITERATOR")
+
+
+def test_no_cpu_fallback(dsr):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    n = C.c_int(-1)
+    assert dsr.load().dsr_device_count(C.byref(n)) == 0 and n.value == 0
+    with pytest.raises(dsr.DsrError) as e:
+        dsr.FilterBank(np.zeros(1024), 256, 4, 1)
+    assert e.value.status == 7 and "no CPU fallback" in str(e.value)      # JINITIALIZATION
+    with pytest.raises(dsr.DsrError):
+        dsr.Gmm(refN=[1], mean=np.zeros((1, 4)), ivar=np.ones((1, 4)), det=np.zeros(1), val=np.zeros(1))
+    with pytest.raises(dsr.DsrError):
+        dsr.Decoder()
+
+
+def test_argument_errors(dsr):
+    with pytest.raises(dsr.DsrError) as e:
+        dsr.FilterBank(np.zeros(1000), 256, 4, 1)
+    assert e.value.status == 4                                           # jconsistency_error "Prototype sizes do not match"
+    bf = dsr.Beamformer(256, 4)
+    with pytest.raises(dsr.DsrError) as e:
+        bf.calcArrayManifoldVectors(16000.0, [0.0, 0.0])
+    assert e.value.status == 5                                           # jdimension_error
+    with pytest.raises(dsr.DsrError) as e:
+        bf.calcMVDRWeights(16000.0)
+    assert e.value.status == 2                                           # jallocation_error "Set a spatial spectral matrix before..."
+    with pytest.raises(dsr.DsrError):
+        bf.divideAllNonDiagonalElements(0.01)
+
+
+def test_beamformer_design_is_host_side(dsr, oracle):
+    from tests import synth
+    mp = synth.linear_array(8)
+    d = dsr.calcDelaysPolar2(np.float32(0.3), np.float32(1.2), mp)
+    assert np.array_equal(d, oracle.calc_delays_polar2(np.float32(0.3), np.float32(1.2), mp))
+    bf = dsr.Beamformer(128, 8); bf.calcArrayManifoldVectors(16000.0, d); bf.setDiffuseNoiseModel(mp, 16000.0)
+    bf.setAllLevelsOfDiagonalLoading(0.01); bf.calcMVDRWeights(16000.0)
+    wq = oracle.calc_mainlobe(16000.0, d, 128); R = oracle.diffuse_noise_model(mp, 128, 16000.0, loading=0.01)
+    assert np.abs(bf.get(0) - wq).max() < 1e-15 and np.abs(bf.get(2) - R).max() < 1e-15
+    w = oracle.mvdr_weights(wq, R)
+    assert np.abs(bf.get(1) - w).max() / np.abs(w).max() < 2e-3
+    bf.calcGSCWeights(16000.0, d)
+    B = bf.get(3)
+    for f in (1, 17, 64):
+        Bo, ok = oracle.blocking_matrix(wq[f])
+        assert ok and np.abs(B[f] - Bo).max() < 1e-12
+
+
+def test_wfst_container_matches_oracle(dsr, oracle, tmp_path):
+    from tests import synth
+    arcs, fin = synth.random_wfst(300, 16, seed=11, eps_frac=0.2)
+    go, gd = oracle.Wfst(), dsr.Wfst()
+    for a in arcs:
+        go.add_arc(*a); gd.add_arc(*a)
+    for s, c in fin:
+        go.add_final(s, c); gd.add_final(s, c)
+    eo, ed = go.export(), gd.export()
+    for k in eo:
+        assert np.array_equal(eo[k], ed[k]), k
+    for binary in (False, True):
+        po, pd = str(tmp_path / ("o%d" % binary)), str(tmp_path / ("d%d" % binary))
+        go.write(po, binary); gd.write(pd, binary)
+        assert open(po, "rb").read() == open(pd, "rb").read()             # byte-identical files
+        g2 = dsr.Wfst(); g2.read(po, binary)
+        e2 = g2.export()
+        assert len(e2["arcDst"]) == len(eo["arcDst"]) and e2["nodeFinal"].sum() == eo["nodeFinal"].sum()
+    with pytest.raises(dsr.DsrError) as e:
+        gd.add_final(fin[0][0], 0.0)
+    assert e.value.status == 4                                            # "Automaton already has final node"
+    with pytest.raises(dsr.DsrError) as e:
+        dsr.Wfst().read(str(tmp_path / "missing"), False)
+    assert e.value.status == 8                                            # JIO
+
+
+def test_lexicon(tmp_path):
+    from dsr.asr.dictionary import LexiconPtr
+    import dsr._capi as K
+    lx = LexiconPtr("x", os.path.join(ROOT, "tests", "golden", "Lexicon.txt"))
+    assert lx.size() == 4 and lx.index("eps") == 0 and lx.symbol(3) == "#"
+    with pytest.raises(K.DsrError) as e:
+        lx.index("nope")
+    assert e.value.status == 11

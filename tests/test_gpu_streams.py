@@ -1,0 +1,187 @@
+"""GPU tests of the stream/feature-operator API, written the way the reference's own driver scripts use it
+(asr/test/featureStreamTest.py, btk/tools/filterbank/testNyquistFilterBankDesign.py,
+btk/src/superdirectiveBeamformer.cc, asr/test/decodeTest.py) and checked against the oracle."""
+import numpy as np
+import pytest
+
+from tests import synth
+
+pytestmark = pytest.mark.gpu
+
+
+class _Iter:
+    """The fake audio source of asr/test/featureStreamTest.py:8-35: a Python iterable with size()/reset()."""
+
+    def __init__(self, blocks):
+        self._b = blocks
+
+    def size(self):
+        return self._b.shape[1]
+
+    def reset(self):
+        pass
+
+    def __iter__(self):
+        return iter(self._b)
+
+
+def test_feature_stream_chain_like_featureStreamTest(dsr, oracle, cuda, headset):
+    from dsr.btk.stream import PyVectorShortFeatureStreamPtr
+    from dsr.btk.feature import (HammingFeaturePtr, FFTFeaturePtr, PowerFeaturePtr, MelFeaturePtr, LogFeaturePtr,
+                                 CepstralFeaturePtr, AdjacentFeaturePtr)
+    blocks = np.stack([headset[6000 + 160 * t:6000 + 160 * t + 320] for t in range(60)]).astype(np.int16)
+    src = PyVectorShortFeatureStreamPtr(_Iter(blocks))
+    ham = HammingFeaturePtr(src)
+    fft = FFTFeaturePtr(ham, fftLen=512)
+    pw = PowerFeaturePtr(fft, powN=257)
+    mel = MelFeaturePtr(pw, powN=257, filterN=30)
+    lg = LogFeaturePtr(mel)
+    cep = CepstralFeaturePtr(lg, ncep=13)
+    adj = AdjacentFeaturePtr(cep, delta=5)
+    assert (ham.size(), fft.size(), pw.size(), mel.size(), lg.size(), cep.size(), adj.size()) == (320, 512, 257, 30, 30, 13, 143)
+    assert cep.name() == "Cepstral" and adj.frameX() == -1
+    got = np.stack([np.array(v) for v in adj])                  # __iter__ = reset + next until StopIteration
+    assert adj.isEnd()
+    # oracle, operator by operator
+    o_ham = (0.54 - 0.46 * np.cos(2 * np.pi * np.arange(320) / 319.0)) * blocks.astype(np.float64)
+    hamf = o_ham.astype(np.float32)
+    spec = np.fft.fft(hamf.astype(np.float64), 512, axis=1)
+    o_pw = (spec.real ** 2 + spec.imag ** 2)[:, :257]
+    rows = oracle.melbank(257, 16000.0, 0.0, 0.0, 30, 1)
+    o_mel = np.stack([np.array([np.dot(o_pw[t, o:o + len(c)], c.astype(np.float64)) for o, c in rows]) for t in range(60)])
+    o_log = np.log10(o_mel + 1.0).astype(np.float32)
+    o_cep = oracle.sgemv_rows(oracle.cosine_matrix(13, 30, 1), o_log)
+    ref = oracle.adjacent(o_cep, 5)
+    assert got.shape == ref.shape and np.abs(got - ref).max() < 1e-4
+    # individual operator outputs and types
+    ham.reset(); v = ham.next(); assert v.dtype == np.float32 and np.array_equal(v, hamf[0])
+    f0 = fft.next(); assert f0.dtype == np.complex128 and np.abs(f0 - spec[0]).max() / np.abs(spec[0]).max() < 1e-12
+    assert np.abs(f0[512 - 7] - np.conj(f0[7])) == 0.0          # halfComplexUnpack mirror
+    p0 = pw.next(); assert p0.dtype == np.float64 and np.abs(p0 - o_pw[0]).max() / o_pw[0].max() < 1e-12
+    # protocol: same frame returns the cached vector, skipping a frame is a jindex_error, current() needs a frame
+    assert np.array_equal(pw.next(0), p0)
+    with pytest.raises(dsr.DsrError) as e:
+        pw.next(5)
+    assert e.value.status == 6                                   # JINDEX
+    lg.reset()
+    with pytest.raises(dsr.DsrError):
+        lg.current()                                             # "Frame index (-1) < 0." (stream.h:44-46)
+
+
+def test_full_mfcc_operator_chain_matches_fused_kernel(dsr, oracle, cuda, headset):
+    from dsr.btk.feature import (SampleFeaturePtr, PreemphasisFeaturePtr, HammingFeaturePtr, FFTFeaturePtr,
+                                 SpectralPowerFeaturePtr, VTLNFeaturePtr, MelFeaturePtr, LogFeaturePtr, CepstralFeaturePtr,
+                                 StorageFeaturePtr, MeanSubtractionFeaturePtr, AdjacentFeaturePtr, LinearTransformFeaturePtr)
+    import torch
+    x = headset[:40000]
+    lda = (np.random.default_rng(1234).standard_normal((39, 195)) / np.sqrt(195)).astype(np.float32)
+    s = SampleFeaturePtr(blockLen=320, shiftLen=160); s.setSamples(x, 16000)
+    chain = LinearTransformFeaturePtr(AdjacentFeaturePtr(MeanSubtractionFeaturePtr(StorageFeaturePtr(CepstralFeaturePtr(LogFeaturePtr(
+        MelFeaturePtr(VTLNFeaturePtr(SpectralPowerFeaturePtr(FFTFeaturePtr(HammingFeaturePtr(PreemphasisFeaturePtr(s, mu=0.95)), fftLen=512),
+                                                             powN=257), coeffN=257, ratio=1.0, edge=1.0, version=1),
+                      powN=257, filterN=30)), ncep=13))), delta=7), sz=39)
+    chain.setMatrix(lda)
+    got = np.stack([np.array(v) for v in chain])
+    ref = oracle.mfcc_chain(x, oracle.mfcc_cfg(lda=lda))
+    assert got.shape == ref.shape and np.abs(got - ref).max() < 1e-4
+    fused = dsr.Mfcc(lda=lda).run(torch.from_numpy(x[None]).to(cuda)).cpu().numpy()[0]
+    assert np.abs(got - fused[:got.shape[0]]).max() < 1e-5
+
+
+def test_filterbank_roundtrip_like_testNyquistFilterBankDesign(dsr, oracle, cuda, headset, protos):
+    from dsr.btk.feature import SampleFeaturePtr
+    from dsr.btk.modulated import OverSampledDFTAnalysisBankPtr, OverSampledDFTSynthesisBankPtr
+    from dsr.btk.stream import PyVectorComplexFeatureStreamPtr
+    M, m, r, h, g = protos["M512-m2-r2"]
+    D = M >> r
+    x = headset[:20000]
+    sampleFeature = SampleFeaturePtr(blockLen=D, shiftLen=D, padZeros=True)
+    analysisFB = OverSampledDFTAnalysisBankPtr(sampleFeature, prototype=h, M=M, m=m, r=r, delayCompensationType=2)
+    synthesisFB = OverSampledDFTSynthesisBankPtr(PyVectorComplexFeatureStreamPtr(analysisFB), prototype=g, M=M, m=m, r=r, delayCompensationType=2)
+    sampleFeature.setSamples(x, 16000)
+    wavebuffer = []
+    for b in synthesisFB:
+        wavebuffer.extend(np.array(b))
+    y = np.array(wavebuffer) * float(D)
+    n = min(len(x), len(y))
+    assert np.sqrt(np.mean((y[2000:n - 2000] - x[2000:n - 2000]) ** 2)) / np.sqrt(np.mean(x ** 2)) < 2e-5
+    # the analysis stream itself: M complex doubles per frame, full Hermitian vector
+    analysisFB.reset(); X0 = np.array(analysisFB.next())
+    ref = oracle.analysis_bank(x, h, M, m, r, 2)
+    assert X0.shape == (M,) and np.abs(X0 - ref[0]).max() / (np.abs(ref[0]).max() + 1e-9) < 2e-5
+    with pytest.raises(dsr.DsrError) as e:
+        OverSampledDFTAnalysisBankPtr(SampleFeaturePtr(blockLen=100, shiftLen=100, padZeros=True), prototype=h, M=M, m=m, r=r)
+    assert e.value.status == 5                                   # jdimension_error "Input block length != _D"
+
+
+def test_mvdr_driver_like_superdirectiveBeamformer(dsr, oracle, cuda, protos):
+    from dsr.btk.feature import SampleFeaturePtr
+    from dsr.btk.modulated import OverSampledDFTAnalysisBankPtr, OverSampledDFTSynthesisBankPtr
+    from dsr.btk.beamformer import SubbandMVDRPtr, calcDelaysPolar2
+    M, m, r, h, g = protos["M256-m4-r1"]
+    D, Cn, n = M >> r, 8, 12000
+    x = synth.array_signal(n, Cn, seed=3)
+    mp = synth.linear_array(Cn)
+    beamformer = SubbandMVDRPtr(fftLen=M, halfBandShift=False)
+    for c in range(Cn):
+        s = SampleFeaturePtr(blockLen=D, shiftLen=D, padZeros=True); s.setSamples(x[c], 16000)
+        beamformer.setChannel(OverSampledDFTAnalysisBankPtr(s, prototype=h, M=M, m=m, r=r))
+    delays = calcDelaysPolar2(np.deg2rad(30.0), np.pi / 2, mp)
+    beamformer.calcArrayManifoldVectors(16000.0, delays)
+    beamformer.setDiffuseNoiseModel(mp, 16000.0, 343740.0)
+    beamformer.divideAllNonDiagonalElements(0.01)
+    beamformer.calcMVDRWeights(16000.0, 1.0E-8)
+    synthesisFB = OverSampledDFTSynthesisBankPtr(beamformer, prototype=g, M=M, m=m, r=r)
+    out = np.concatenate([np.array(b) for b in synthesisFB])
+    W = beamformer._weights().get(4)
+    Xc = np.stack([oracle.analysis_bank(x[c], h, M, m, r, 0) for c in range(Cn)])
+    ref = oracle.synthesis_bank(oracle.beamform_apply(Xc, W), g, M, m, r, 0)
+    assert out.shape == ref.shape and np.abs(out - ref).max() / np.sqrt(np.mean(ref ** 2)) < 5e-5
+
+
+def test_decode_like_decodeTest(dsr, oracle, cuda, headset, tmp_path):
+    """asr/test/decodeTest.py shape: description files + binary model files + lexica + WFST file -> decode() / bestHypo()."""
+    from dsr.btk.feature import (SampleFeaturePtr, HammingFeaturePtr, FFTFeaturePtr, SpectralPowerFeaturePtr, MelFeaturePtr,
+                                 LogFeaturePtr, CepstralFeaturePtr, FeatureSetPtr)
+    from dsr.asr.dictionary import LexiconPtr
+    from dsr.asr.gaussian import CodebookSetBasicPtr, DistribSetBasicPtr
+    from dsr.asr.decoder import WFSTFlyWeightPtr, DecoderFlyWeightPtr
+    K, R, D = 24, 8, 13
+    m = synth.gmm_model(K, R, D, seed=5); m["mean"] *= 20.0
+    cbf, dsf = str(tmp_path / "cb.bin"), str(tmp_path / "ds.bin")
+    dsr.Gmm(**m).save(cbf, dsf)
+    open(tmp_path / "cb.desc", "w").write("; codebooks\n" + "".join("%-25s%-20s%-10d%-3d%-10s\n" % ("cb%d" % k, "Cepstral", R, D, "DIAGONAL") for k in range(K)))
+    open(tmp_path / "ds.desc", "w").write("".join("%-25s%-25s\n" % ("ds%d" % k, "cb%d" % k) for k in range(K)))
+    inlex = ["eps"] + ["ds%d" % k for k in range(K)]; inlex[4] = "SIL-m"
+    outlex = ["eps", "</s>"] + ["w%d" % i for i in range(50)]
+    open(tmp_path / "in.lex", "w").write("\n".join(inlex) + "\n"); open(tmp_path / "out.lex", "w").write("\n".join(outlex) + "\n")
+    arcs, fin = synth.random_wfst(400, K, seed=4, nWords=51, out_frac=0.2)
+    go = oracle.Wfst()
+    with open(tmp_path / "g.fsm", "w") as f:
+        for a in arcs:
+            f.write("%d %d %d %d %.9g\n" % a); go.add_arc(*a)
+        for s, c in fin:
+            f.write("%d %.9g\n" % (s, c)); go.add_final(s, c)
+    samp = SampleFeaturePtr(blockLen=320, shiftLen=160)
+    feat = CepstralFeaturePtr(LogFeaturePtr(MelFeaturePtr(SpectralPowerFeaturePtr(FFTFeaturePtr(HammingFeaturePtr(samp), fftLen=512), powN=257),
+                                                         powN=257, filterN=30)), ncep=13)
+    fs = FeatureSetPtr(); fs.add(feat)
+    cbs = CodebookSetBasicPtr(str(tmp_path / "cb.desc"), fs, cbf)
+    dss = DistribSetBasicPtr(cbs, str(tmp_path / "ds.desc"), dsf)
+    wfst = WFSTFlyWeightPtr(LexiconPtr("state"), LexiconPtr("in", str(tmp_path / "in.lex")), LexiconPtr("out", str(tmp_path / "out.lex")))
+    wfst.read(str(tmp_path / "g.fsm"), binary=False)
+    d = DecoderFlyWeightPtr(dss, beam=80.0, lmScale=12.0, silPenalty=0.5)
+    d.set(wfst)
+    samp.setSamples(headset[20000:36000], 16000)
+    score = d.decode(); hyp = d.bestHypo()
+    # oracle on the device features
+    X = np.stack([np.array(v) for v in feat])
+    cb = oracle.Codebooks(m["refN"], m["mean"], m["ivar"], m["det"])
+    so, _ = oracle.gmm_score_opt(cb, m["val"], X)
+    ro = go.decode(so, beam=80.0, lmScale=12.0, silPenalty=0.5, silenceX=4)
+    assert score == ro["score"] and np.array_equal(d.bestArcs(), ro["arcs"])
+    assert hyp == "".join(outlex[w] + " " for w in ro["words"])
+    bad = DecoderFlyWeightPtr(dss, silSymbol="NOPE")
+    with pytest.raises(dsr.DsrError) as e:
+        bad.set(wfst)
+    assert e.value.status == 11                                  # jkey_error
