@@ -1,0 +1,202 @@
+// host/dsr_streams.hpp -- header-only C++ facade over the C-ABI (include/dsr.h) with the reference's class names, ctor
+// argument order, pull protocol and exception types, so SWIG interface files written against btk/stream/stream.h,
+// btk/feature/feature.h, btk/modulated/modulated.h and btk/beamformer/beamformer.h keep compiling.
+#pragma once
+#include <complex>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <vector>
+#include "../../include/dsr.h"
+
+typedef std::string String;
+
+// ---- exceptions (btk/common/jexception.h:41-70)
+typedef enum { JERROR, JALLOCATION, JARITHMETIC, JCONSISTENCY, JDIMENSION, JINDEX, JINITIALIZATION, JIO, JITERATOR, JPYTHON,
+               JKEY, JNUMERIC, JPARAMETER, JPARSE, JTYPE } error_type;
+class j_error : public std::exception {
+ public:
+  j_error(error_type c, const std::string& w) : _what(w), code(c) {}
+  const char* what() const throw() { return _what.c_str(); }
+  error_type getCode() { return code; }
+ protected:
+  std::string _what; error_type code;
+};
+#define DSR_JERR(cls, val) class cls : public j_error { public: explicit cls(const std::string& w) : j_error(val, w) {} };
+DSR_JERR(jallocation_error, JALLOCATION) DSR_JERR(jarithmetic_error, JARITHMETIC) DSR_JERR(jconsistency_error, JCONSISTENCY)
+DSR_JERR(jdimension_error, JDIMENSION) DSR_JERR(jindex_error, JINDEX) DSR_JERR(jinitialization_error, JINITIALIZATION)
+DSR_JERR(jio_error, JIO) DSR_JERR(jiterator_error, JITERATOR) DSR_JERR(jkey_error, JKEY) DSR_JERR(jnumeric_error, JNUMERIC)
+DSR_JERR(jparameter_error, JPARAMETER) DSR_JERR(jparse_error, JPARSE) DSR_JERR(jtype_error, JTYPE)
+#undef DSR_JERR
+
+inline void dsr_throw(dsr_status s)
+{
+  if (s == DSR_OK) return;
+  const std::string w = dsr_last_error();
+  switch (s - 1) {
+    case JALLOCATION: throw jallocation_error(w); case JARITHMETIC: throw jarithmetic_error(w); case JCONSISTENCY: throw jconsistency_error(w);
+    case JDIMENSION: throw jdimension_error(w); case JINDEX: throw jindex_error(w); case JINITIALIZATION: throw jinitialization_error(w);
+    case JIO: throw jio_error(w); case JITERATOR: throw jiterator_error(w); case JKEY: throw jkey_error(w); case JNUMERIC: throw jnumeric_error(w);
+    case JPARAMETER: throw jparameter_error(w); case JPARSE: throw jparse_error(w); case JTYPE: throw jtype_error(w);
+    default: throw j_error(JERROR, w);
+  }
+}
+
+// ---- FeatureStream<item_type> (btk/stream/stream.h:36-75).  The reference's Type is a gsl_vector_X; here next() returns
+// a pointer to size() items of item_type living in the operator's own buffer.
+template <typename item_type>
+class FeatureStream {
+ public:
+  virtual ~FeatureStream() { if (_h) dsr_stream_release(_h); }
+  const String& name() const { return _name; }
+  unsigned size() const { return (unsigned) dsr_stream_size(_h); }
+  virtual const item_type* next(int frameX = -5) { const void* p = 0; size_t n = 0; dsr_throw(dsr_stream_next(_h, frameX, &p, &n)); return (const item_type*) p; }
+  const item_type* current() { const void* p = 0; size_t n = 0; dsr_throw(dsr_stream_current(_h, &p, &n)); return (const item_type*) p; }
+  bool isEnd() { return dsr_stream_is_end(_h) != 0; }
+  virtual void reset() { dsr_throw(dsr_stream_reset(_h)); }
+  virtual int frameX() const { return dsr_stream_frameX(_h); }
+  dsr_stream* handle() const { return _h; }
+ protected:
+  FeatureStream() : _h(0) {}
+  void adopt(dsr_stream* h) { _h = h; _name = dsr_stream_name(h); }
+  dsr_stream* _h; String _name;
+};
+typedef FeatureStream<short> VectorShortFeatureStream;
+typedef FeatureStream<float> VectorFloatFeatureStream;
+typedef FeatureStream<double> VectorFeatureStream;
+typedef FeatureStream<std::complex<double> > VectorComplexFeatureStream;
+typedef std::shared_ptr<VectorShortFeatureStream> VectorShortFeatureStreamPtr;
+typedef std::shared_ptr<VectorFloatFeatureStream> VectorFloatFeatureStreamPtr;
+typedef std::shared_ptr<VectorFeatureStream> VectorFeatureStreamPtr;
+typedef std::shared_ptr<VectorComplexFeatureStream> VectorComplexFeatureStreamPtr;
+
+#define DSR_OP(cls, base, create_call) { dsr_stream* h = 0; dsr_throw(create_call); this->adopt(h); }
+
+// ---- btk/feature/feature.h
+class SampleFeature : public VectorFloatFeatureStream {
+ public:
+  SampleFeature(const String& fn = "", unsigned blockLen = 320, unsigned shiftLen = 160, bool padZeros = false, const String& nm = "Sample")
+  { (void) fn; DSR_OP(SampleFeature, float, dsr_sample_feature_create((int) blockLen, (int) shiftLen, padZeros, nm.c_str(), &h)) }
+  void setSamples(const float* samples, size_t n, unsigned sampleRate) { dsr_throw(dsr_sample_feature_set_samples(_h, samples, n, sampleRate)); }
+};
+class PreemphasisFeature : public VectorFloatFeatureStream {
+ public: PreemphasisFeature(const VectorFloatFeatureStreamPtr& samp, double mu, const String& nm = "Preemphasis")
+  : _s(samp) { DSR_OP(PreemphasisFeature, float, dsr_preemphasis_create(samp->handle(), mu, nm.c_str(), &h)) }
+ private: VectorFloatFeatureStreamPtr _s;
+};
+class HammingFeature : public VectorFloatFeatureStream {
+ public: HammingFeature(const VectorFloatFeatureStreamPtr& samp, const String& nm = "Hamming")
+  : _s(samp) { DSR_OP(HammingFeature, float, dsr_hamming_create(samp->handle(), nm.c_str(), &h)) }
+ private: VectorFloatFeatureStreamPtr _s;
+};
+class FFTFeature : public VectorComplexFeatureStream {
+ public: FFTFeature(const VectorFloatFeatureStreamPtr& samp, unsigned fftLen, const String& nm = "FFT")
+  : _s(samp) { DSR_OP(FFTFeature, cplx, dsr_fft_create(samp->handle(), (int) fftLen, nm.c_str(), &h)) }
+ private: VectorFloatFeatureStreamPtr _s;
+};
+class SpectralPowerFeature : public VectorFeatureStream {
+ public: SpectralPowerFeature(const VectorComplexFeatureStreamPtr& fft, unsigned powN = 0, const String& nm = "Power")
+  : _s(fft) { DSR_OP(SpectralPowerFeature, double, dsr_spectral_power_create(fft->handle(), (int) powN, nm.c_str(), &h)) }
+ private: VectorComplexFeatureStreamPtr _s;
+};
+class VTLNFeature : public VectorFeatureStream {
+ public: VTLNFeature(const VectorFeatureStreamPtr& pow, unsigned coeffN = 0, double ratio = 1.0, double edge = 1.0, int version = 1, const String& nm = "VTLN")
+  : _s(pow) { DSR_OP(VTLNFeature, double, dsr_vtln_create(pow->handle(), (int) coeffN, ratio, edge, version, nm.c_str(), &h)) }
+ private: VectorFeatureStreamPtr _s;
+};
+class MelFeature : public VectorFeatureStream {
+ public: MelFeature(const VectorFeatureStreamPtr& mag, int powN = 0, float rate = 16000.0, float low = 0.0, float up = 0.0, unsigned filterN = 30, unsigned version = 1, const String& nm = "MelFFT")
+  : _s(mag) { DSR_OP(MelFeature, double, dsr_mel_create(mag->handle(), powN, rate, low, up, (int) filterN, (int) version, nm.c_str(), &h)) }
+ private: VectorFeatureStreamPtr _s;
+};
+class LogFeature : public VectorFloatFeatureStream {
+ public: LogFeature(const VectorFeatureStreamPtr& mel, double m = 1.0, double a = 1.0, bool sphinxFlooring = false, const String& nm = "LogMel")
+  : _s(mel) { DSR_OP(LogFeature, float, dsr_log_create(mel->handle(), m, a, sphinxFlooring, nm.c_str(), &h)) }
+ private: VectorFeatureStreamPtr _s;
+};
+class CepstralFeature : public VectorFloatFeatureStream {
+ public: CepstralFeature(const VectorFloatFeatureStreamPtr& mel, unsigned ncep = 13, int type = 1, const String& nm = "Cepstral")
+  : _s(mel) { DSR_OP(CepstralFeature, float, dsr_cepstral_create(mel->handle(), (int) ncep, type, nm.c_str(), &h)) }
+ private: VectorFloatFeatureStreamPtr _s;
+};
+class StorageFeature : public VectorFloatFeatureStream {
+ public: StorageFeature(const VectorFloatFeatureStreamPtr& src, const String& nm = "Storage")
+  : _s(src) { DSR_OP(StorageFeature, float, dsr_storage_create(src->handle(), nm.c_str(), &h)) }
+ private: VectorFloatFeatureStreamPtr _s;
+};
+class MeanSubtractionFeature : public VectorFloatFeatureStream {
+ public: MeanSubtractionFeature(const VectorFloatFeatureStreamPtr& src, double devNormFactor = 0.0, bool runon = false, const String& nm = "Mean Subtraction")
+  : _s(src) { DSR_OP(MeanSubtractionFeature, float, dsr_mean_subtraction_create(src->handle(), devNormFactor, runon, nm.c_str(), &h)) }
+ private: VectorFloatFeatureStreamPtr _s;
+};
+class AdjacentFeature : public VectorFloatFeatureStream {
+ public: AdjacentFeature(const VectorFloatFeatureStreamPtr& single, unsigned delta = 5, const String& nm = "Adjacent")
+  : _s(single) { DSR_OP(AdjacentFeature, float, dsr_adjacent_create(single->handle(), (int) delta, nm.c_str(), &h)) }
+ private: VectorFloatFeatureStreamPtr _s;
+};
+class LinearTransformFeature : public VectorFloatFeatureStream {
+ public: LinearTransformFeature(const VectorFloatFeatureStreamPtr& src, unsigned sz = 0, const String& nm = "Transform")
+  : _s(src) { DSR_OP(LinearTransformFeature, float, dsr_linear_transform_create(src->handle(), (int) sz, nm.c_str(), &h)) }
+  void setMatrix(const float* m) { dsr_throw(dsr_linear_transform_set(_h, m)); }
+ private: VectorFloatFeatureStreamPtr _s;
+};
+
+// ---- btk/modulated/modulated.h
+class OverSampledDFTAnalysisBank : public VectorComplexFeatureStream {
+ public:
+  OverSampledDFTAnalysisBank(VectorFloatFeatureStreamPtr& samp, const double* prototype, unsigned M, unsigned m, unsigned r,
+                             unsigned delayCompensationType = 0, const String& nm = "OverSampledDFTAnalysisBank")
+  : _s(samp), _M(M) { DSR_OP(OverSampledDFTAnalysisBank, cplx, dsr_analysis_bank_create(samp->handle(), prototype, (int) M, (int) m, (int) r, (int) delayCompensationType, nm.c_str(), &h)) }
+  unsigned fftLen() const { return _M; }
+ private: VectorFloatFeatureStreamPtr _s; unsigned _M;
+};
+class OverSampledDFTSynthesisBank : public VectorFloatFeatureStream {
+ public:
+  OverSampledDFTSynthesisBank(VectorComplexFeatureStreamPtr& samp, const double* prototype, unsigned M, unsigned m, unsigned r = 0,
+                              unsigned delayCompensationType = 0, int gainFactor = 1, const String& nm = "OverSampledDFTSynthesisBank")
+  : _s(samp) { DSR_OP(OverSampledDFTSynthesisBank, float, dsr_synthesis_bank_create(samp->handle(), prototype, (int) M, (int) m, (int) r, (int) delayCompensationType, gainFactor, nm.c_str(), &h)) }
+ private: VectorComplexFeatureStreamPtr _s;
+};
+
+// ---- btk/beamformer/beamformer.h: SubbandDS / SubbandGSC / SubbandMVDR
+class SubbandDS : public VectorComplexFeatureStream {
+ public:
+  SubbandDS(unsigned fftLen = 512, bool halfBandShift = false, const String& nm = "SubbandDS") : _fftLen(fftLen), _hbs(halfBandShift), _nm(nm), _w(0), _mode(0) {}
+  ~SubbandDS() { if (_w) dsr_bf_destroy(_w); }
+  void setChannel(VectorComplexFeatureStreamPtr& chan) { _channelList.push_back(chan); }
+  unsigned chanN() const { return (unsigned) _channelList.size(); }
+  void calcArrayManifoldVectors(double sampleRate, const double* delays) { dsr_throw(dsr_bf_calc_array_manifold(weights(), sampleRate, delays)); }
+  virtual const std::complex<double>* next(int frameX = -5) {
+    if (!_h) throw j_error(JERROR, "call calcArrayManifoldVectorsX() once");
+    return VectorComplexFeatureStream::next(frameX);
+  }
+ protected:
+  dsr_bf* weights() {
+    if (!_w) {
+      dsr_throw(dsr_bf_create((int) _fftLen, (int) chanN(), _hbs, &_w)); dsr_throw(dsr_bf_select(_w, _mode));
+      dsr_stream* h = 0; dsr_throw(dsr_subband_bf_create(_w, _nm.c_str(), &h)); adopt(h);
+      for (size_t i = 0; i < _channelList.size(); i++) dsr_throw(dsr_subband_bf_set_channel(_h, _channelList[i]->handle()));
+    }
+    return _w;
+  }
+  unsigned _fftLen; bool _hbs; String _nm; dsr_bf* _w; int _mode; std::vector<VectorComplexFeatureStreamPtr> _channelList;
+};
+class SubbandGSC : public SubbandDS {
+ public:
+  SubbandGSC(unsigned fftLen = 512, bool halfBandShift = false, const String& nm = "SubbandGSC") : SubbandDS(fftLen, halfBandShift, nm) { _mode = 2; }
+  void calcGSCWeights(double sampleRate, const double* delaysT) { dsr_throw(dsr_bf_calc_gsc_weights(weights(), sampleRate, delaysT)); }
+  void setActiveWeights_f(unsigned fbinX, const double* packedWeight) { dsr_throw(dsr_bf_set_active_weights(weights(), (int) fbinX, packedWeight)); }
+  void zeroActiveWeights() { dsr_throw(dsr_bf_zero_active_weights(weights())); }
+};
+class SubbandMVDR : public SubbandDS {
+ public:
+  SubbandMVDR(unsigned fftLen = 512, bool halfBandShift = false, const String& nm = "SubbandMVDR") : SubbandDS(fftLen, halfBandShift, nm) {
+    if (halfBandShift) throw jallocation_error("halfBandShift==true is not yet supported");
+    _mode = 1;
+  }
+  bool setDiffuseNoiseModel(const double* micPositions, double sampleRate, double sspeed = 343740.0) { dsr_throw(dsr_bf_set_diffuse_noise_model(weights(), micPositions, sampleRate, sspeed)); return true; }
+  void divideAllNonDiagonalElements(float myu) { dsr_throw(dsr_bf_divide_nondiagonal(weights(), myu)); }
+  void setAllLevelsOfDiagonalLoading(float w) { dsr_throw(dsr_bf_diagonal_loading(weights(), w)); }
+  bool calcMVDRWeights(double sampleRate, double dThreshold = 1.0E-8, bool calcInverseMatrix = true) { (void) calcInverseMatrix; dsr_throw(dsr_bf_calc_mvdr_weights(weights(), sampleRate, dThreshold)); return true; }
+};
+#undef DSR_OP

@@ -119,3 +119,22 @@ def test_lexicon(tmp_path):
     with pytest.raises(K.DsrError) as e:
         lx.index("nope")
     assert e.value.status == 11
+
+
+def test_cpp_facade_compiles_and_maps_errors(tmp_path):
+    """host/dsr_streams.hpp: the reference's class names over the C-ABI, plain g++ (no hipcc, no torch)."""
+    src = tmp_path / "t.cpp"
+    src.write_text('#include "dsr_streams.hpp"\n#include <cstdio>\nint main(){ try { VectorFloatFeatureStreamPtr s(new SampleFeature("",320,160));'
+                   ' VectorFloatFeatureStreamPtr p(new PreemphasisFeature(s,0.95)); VectorFloatFeatureStreamPtr h(new HammingFeature(p));'
+                   ' printf("%u %s %d\\n", p->size(), p->name().c_str(), p->frameX()); h->next(); }'
+                   ' catch (jinitialization_error& e) { printf("init %d\\n", (int) e.getCode()); return 0; }'
+                   ' catch (jiterator_error& e) { printf("iter %d\\n", (int) e.getCode()); return 0; } return 3; }\n')
+    exe = tmp_path / "t"
+    subprocess.check_call(["g++", "-std=c++11", "-I", os.path.join(PKG, "host"), str(src), "-o", str(exe), "-L", os.path.join(PKG, "lib"),
+                           "-ldsr_hip", "-Wl,-rpath," + os.path.join(PKG, "lib"), "-Wl,-rpath,/opt/rocm/lib"])
+    out = subprocess.run([str(exe)], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout + out.stderr
+    lines = out.stdout.split("\n")
+    # without a GPU the first device touch raises JINITIALIZATION (6); with one, an empty source ends with JITERATOR (8)
+    assert lines[0] in ("320 Preemphasis -1",) or lines[0].startswith("init")
+    assert any(l in ("init 6", "iter 8") for l in lines)

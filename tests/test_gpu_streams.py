@@ -49,7 +49,8 @@ def test_feature_stream_chain_like_featureStreamTest(dsr, oracle, cuda, headset)
     o_pw = (spec.real ** 2 + spec.imag ** 2)[:, :257]
     rows = oracle.melbank(257, 16000.0, 0.0, 0.0, 30, 1)
     o_mel = np.stack([np.array([np.dot(o_pw[t, o:o + len(c)], c.astype(np.float64)) for o, c in rows]) for t in range(60)])
-    o_log = np.log10(o_mel + 1.0).astype(np.float32)
+    v = o_mel + 1.0
+    o_log = np.log10(np.where(v <= 0.0, 1.0, v)).astype(np.float32)    # LogFeature: x+a <= 0 -> 1 (feature.cc:2418-2421)
     o_cep = oracle.sgemv_rows(oracle.cosine_matrix(13, 30, 1), o_log)
     ref = oracle.adjacent(o_cep, 5)
     assert got.shape == ref.shape and np.abs(got - ref).max() < 1e-4
