@@ -30,7 +30,7 @@ namespace dsr {
 
 struct Tok { int32_t node; float ac; float lm; uint32_t bp; };        // node bit31: edge input == silenceX
 struct CandA { double ttl; float ac; float lm; };
-struct CandB { int32_t dst; int32_t next; int32_t rec; int32_t win; };
+struct CandB { int32_t dst; int32_t next; int32_t rec; uint32_t prevBp; };   // rec bit30: the emitting arc's input is the silence symbol
 struct Bp { uint32_t prev; uint32_t rec; };
 
 static constexpr uint32_t kNone = 0xFFFFFFFFu;
@@ -50,7 +50,7 @@ struct DecDev {
   double beam, lmScale, lmPenalty, silPenalty; uint32_t silenceX;
   int maxTok, maxCand; long arenaCap;
   // per-slot scratch (slot s at base + s*stride)
-  Tok* tok; int* tokOff; int* owner; int* rank; CandA* cA; CandB* cB; unsigned* first; int* head; Bp* arena;
+  Tok* tok; int* tokOff; int* tokCnt; int* owner; int* rank; int* chead; CandA* cA; CandB* cB; unsigned* first; unsigned* tags; Bp* arena;
   int* queue;
   // dump (slot 0 only)
   int dumpOn; long dumpCap; long* dumpFrameOff; int* dumpNode; float* dumpAc; float* dumpLm; int* dumpArc; long* dumpCount;
@@ -85,23 +85,34 @@ __device__ __forceinline__ unsigned f2ord(float f) { const unsigned u = __float_
 __global__ __launch_bounds__(kThreads) void k_viterbi(GraphDev G, DecDev Dd, const float* __restrict__ scores,
                                                       const int* __restrict__ nframesArr, int U, int Tmax, int nDist,
                                                       dsr_decode_result* __restrict__ res, int* __restrict__ arcsOut,
-                                                      unsigned* __restrict__ wordsOut, int maxPath, int useLdsRow)
+                                                      unsigned* __restrict__ wordsOut, int maxPath, int useLdsRow, int hashN)
 {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   float* srow = reinterpret_cast<float*>(smem);                       // [nDist] when useLdsRow
+  // per-frame open-addressing table in LDS: destination state -> first-arrival slot (hashN buckets, 0 = unused).
+  // Global atomics execute at the memory side on gfx950 (no L2 residency); the LDS table keeps the recombination
+  // traffic on chip.  Frames with more placements than the table can take fall back to the tagged global table.
+  unsigned* hkey = reinterpret_cast<unsigned*>(srow + (useLdsRow ? ((nDist + 3) & ~3) : 4));
+  unsigned* hfirst = hkey + hashN;
   __shared__ int s_waveTot[kWaves];
   __shared__ double s_waveMin[kWaves];
   __shared__ unsigned long long s_waveKey[kWaves];
+  const int nthr = blockDim.x, nw = nthr >> 6;      // 256..1024 threads
   __shared__ int s_u;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int slot = blockIdx.x;
   Tok* tokA = Dd.tok + (size_t) slot * 2 * Dd.maxTok; Tok* tokB = tokA + Dd.maxTok;
   int* tokOff = Dd.tokOff + (size_t) slot * (Dd.maxTok + 1);
+  int* tokCnt = Dd.tokCnt + (size_t) slot * (Dd.maxTok + 1);
+  int* chead = Dd.chead + (size_t) slot * Dd.maxCand;
   int* owner = Dd.owner + (size_t) slot * Dd.maxCand;
   int* rank = Dd.rank + (size_t) slot * Dd.maxCand;
   CandA* cA = Dd.cA + (size_t) slot * Dd.maxCand; CandB* cB = Dd.cB + (size_t) slot * Dd.maxCand;
-  unsigned* first = Dd.first + (size_t) slot * G.nNodes; int* head = Dd.head + (size_t) slot * G.nNodes;
+  unsigned* first = Dd.first + (size_t) slot * G.nNodes;
+  // first[] holds (tag << 24 | slot); tags count DOWN so every entry of an older frame compares larger and never
+  // needs resetting; the table is wiped when the 8-bit tag runs out (and on the very first use of a slot)
+  unsigned tag = Dd.tags[slot];
   Bp* arena = Dd.arena + (size_t) slot * Dd.arenaCap;
 
   for (;;) {
@@ -120,17 +131,20 @@ __global__ __launch_bounds__(kThreads) void k_viterbi(GraphDev G, DecDev Dd, con
     Tok* cur = tokA; Tok* nxt = tokB;
     int n = 1; long arenaOff = 0; long activeHypos = 0; long placements = 0; int maxActive = 0;
     double thresh = HUGE_VAL, topScore = HUGE_VAL;
+    for (int i = tid; i < 2 * hashN; i += nthr) hkey[i] = (i < hashN) ? 0u : 0xFFFFFFFFu;
     if (tid == 0) { Tok t0; t0.node = G.initial; t0.ac = 0.0f; t0.lm = 0.0f; t0.bp = kNone; cur[0] = t0; }
     __syncthreads();
 
     // frames 0..T-1 (mode 0), then the end expansion (mode 1)
     for (int fr = 0; fr <= T && status == DSR_OK; fr++) {
       const int mode = (fr == T) ? 1 : 0;
-      if (mode == 0 && useLdsRow) { for (int i = tid; i < nDist; i += kThreads) srow[i] = sc[(size_t) fr * nDist + i]; }
+      if (tag <= 1u) { for (int i = tid; i < G.nNodes; i += nthr) first[i] = 0xFFFFFFFFu; tag = 255u; __syncthreads(); } else tag--;
+      const unsigned tagw = tag << 24;
+      if (mode == 0 && useLdsRow) { for (int i = tid; i < nDist; i += nthr) srow[i] = sc[(size_t) fr * nDist + i]; }
       const float* row = useLdsRow ? srow : (sc + (size_t) fr * nDist);
 
       // ---------------- phase A: per-token placement counts, wave-local exclusive scan
-      const int chunkT = ((n + kWaves * 64 - 1) / (kWaves * 64)) * 64;
+      const int chunkT = ((n + nw * 64 - 1) / (nw * 64)) * 64;
       {
         int running = 0;
         const int b0 = wave * chunkT, b1 = (b0 + chunkT < n) ? b0 + chunkT : n;
@@ -144,34 +158,34 @@ __global__ __launch_bounds__(kThreads) void k_viterbi(GraphDev G, DecDev Dd, con
             } else cnt = (G.nodeFinal[nd] ? 1 : 0) + (G.eoff[nd + 1] - G.eoff[nd]);
           }
           const int incl = wave_incl_scan(cnt, lane);
-          if (i < b1) tokOff[i] = running + incl - cnt;
+          if (i < b1) { tokOff[i] = running + incl - cnt; tokCnt[i] = cnt; }
           running += __shfl(incl, 63, 64);
         }
         if (lane == 0) s_waveTot[wave] = running;
       }
       __syncthreads();
       int C = 0;
-      for (int w = 0; w < kWaves; w++) C += s_waveTot[w];
+      for (int w = 0; w < nw; w++) C += s_waveTot[w];
       if (C > Dd.maxCand) { status = DSR_E_ALLOCATION; break; }
       placements += C;
+      const bool useHash = hashN > 0 && C <= (hashN >> 1) + (hashN >> 2);        // load factor <= 0.75 even if every placement is a new state
       // ---------------- phase A2: absolute offsets + owner fill
-      for (int i = tid; i < n; i += kThreads) {
+      for (int i = tid; i < n; i += nthr) {
+        const int cnt = tokCnt[i];
+        if (cnt == 0) continue;
         const int w = i / chunkT; int base = 0;
         for (int q = 0; q < w; q++) base += s_waveTot[q];
         const int off = base + tokOff[i];
-        const Tok t = cur[i]; const int nd = t.node & 0x7FFFFFFF; int cnt;
-        if (mode == 0) { const float s = __fadd_rn(t.ac, t.lm); cnt = ((double) s > thresh) ? 0 : (G.xoff[nd + 1] - G.xoff[nd]); }
-        else cnt = (G.nodeFinal[nd] ? 1 : 0) + (G.eoff[nd + 1] - G.eoff[nd]);
         tokOff[i] = off;
         for (int j = 0; j < cnt; j++) owner[off + j] = i;
       }
       __syncthreads();
       // ---------------- phase B: one thread per placement
       double locMin = HUGE_VAL;
-      for (int c = tid; c < C; c += kThreads) {
+      for (int c = tid; c < C; c += nthr) {
         const int i = owner[c]; const Tok t = cur[i]; const int nd = t.node & 0x7FFFFFFF; const bool tokSil = t.node < 0;
         const int j = c - tokOff[i];
-        double ac = (double) t.ac, lm; int dst, recId;
+        double ac = (double) t.ac, lm; int dst, recId; bool silArc = false;
         if (mode == 0) {
           recId = G.xoff[nd] + j; const XRec x = G.xrec[recId];
           const int plen = (int) (x.meta & 0xFFFFu);
@@ -191,7 +205,7 @@ __global__ __launch_bounds__(kThreads) void k_viterbi(GraphDev G, DecDev Dd, con
           if (x.meta & 0x10000u) lm = __dadd_rn(lm, __dmul_rn(Dd.lmScale, Dd.lmPenalty));
           if ((uint32_t) (x.dist + 1) == Dd.silenceX && (prevNull || prevIn != Dd.silenceX)) lm = __dadd_rn(lm, __dmul_rn(Dd.lmScale, Dd.silPenalty));
           ac = __dadd_rn(ac, (double) row[x.dist]);
-          dst = x.dst;
+          dst = x.dst; silArc = ((uint32_t) (x.dist + 1) == Dd.silenceX);
         } else {
           const int hasSelf = G.nodeFinal[nd] ? 1 : 0;
           if (hasSelf && j == 0) {                                             // _expandToEnd self placement (decoder.h:506-509)
@@ -214,30 +228,48 @@ __global__ __launch_bounds__(kThreads) void k_viterbi(GraphDev G, DecDev Dd, con
         }
         const double ttl = __dadd_rn(ac, lm);
         CandA a2; a2.ttl = ttl; a2.ac = (float) ac; a2.lm = (float) lm; cA[c] = a2;
-        atomicMin(&first[dst], (unsigned) c);
-        const int nx = atomicExch(&head[dst], c);
-        CandB b2; b2.dst = dst; b2.next = nx; b2.rec = recId; b2.win = -1; cB[c] = b2;
+        if (useHash) {
+          unsigned h = ((unsigned) dst * 2654435761u) >> 7 & (unsigned) (hashN - 1);
+          for (;;) {
+            const unsigned k = atomicCAS(&hkey[h], 0u, (unsigned) dst + 1u);
+            if (k == 0u || k == (unsigned) dst + 1u) break;
+            h = (h + 1u) & (unsigned) (hashN - 1);
+          }
+          atomicMin(&hfirst[h], (unsigned) c);
+          rank[c] = (int) h;
+        } else atomicMin(&first[dst], tagw | (unsigned) c);
+        chead[c] = -1;
+        if (silArc) recId |= 0x40000000;
+        CandB b2; b2.dst = dst; b2.next = -1; b2.rec = recId; b2.prevBp = t.bp; cB[c] = b2;
         if (mode == 0 && ttl < locMin) locMin = ttl;                           // _topScore (emitting placements only)
       }
       locMin = wave_min_d(locMin);
       if (lane == 0) s_waveMin[wave] = locMin;
       __syncthreads();
       topScore = HUGE_VAL;
-      for (int w = 0; w < kWaves; w++) { const double v = s_waveMin[w]; if (v < topScore) topScore = v; }
+      for (int w = 0; w < nw; w++) { const double v = s_waveMin[w]; if (v < topScore) topScore = v; }
+      // ---------------- phase C0: later arrivals hang themselves on their state's first-arrival placement
+      for (int c = tid; c < C; c += nthr) {
+        int f;
+        if (useHash) f = (int) hfirst[rank[c]];
+        else { const int dst = cB[c].dst; f = (int) (ld_u32(&first[dst]) & 0x00FFFFFFu); }
+        if (f != c) { const int nx = atomicExch(&chead[f], c); cB[c].next = nx; chead[c] = -2; }      // -2: not a first arrival
+      }
+      __syncthreads();
+      if (useHash) for (int i = tid; i < 2 * hashN; i += nthr) hkey[i] = (i < hashN) ? 0u : 0xFFFFFFFFu;   // ready for the next frame
       // ---------------- phase C1: fold per destination state (by its first-arrival thread), count new tokens
-      const int chunkC = ((C + kWaves * 64 - 1) / (kWaves * 64)) * 64;
+      const int chunkC = ((C + nw * 64 - 1) / (nw * 64)) * 64;
       {
         int running = 0;
         const int b0 = wave * chunkC, b1 = (b0 + chunkC < C) ? b0 + chunkC : C;
         for (int base = b0; base < b1; base += 64) {
           const int c = base + lane; bool isFirst = false;
           if (c < b1) {
-            const int dst = cB[c].dst;
-            isFirst = (ld_u32(&first[dst]) == (unsigned) c);
+            const int h0 = ld_i32(&chead[c]);
+            isFirst = (h0 != -2);
             if (isFirst) {
               int w = c; CandA aw = cA[w];
               double fw = (double) __fadd_rn(aw.ac, aw.lm);                   // incumbent's float score()
-              const int h0 = ld_i32(&head[dst]);
               for (;;) {                                                       // next replacement = smallest later slot that beats it
                 int best = 0x7FFFFFFF;
                 int steps = 0;                                                 // the list has at most C nodes: never spin on a corrupt link
@@ -245,7 +277,7 @@ __global__ __launch_bounds__(kThreads) void k_viterbi(GraphDev G, DecDev Dd, con
                 if (best == 0x7FFFFFFF) break;
                 w = best; aw = cA[w]; fw = (double) __fadd_rn(aw.ac, aw.lm);
               }
-              cB[c].win = w;
+              chead[c] = w;                                                    // winner of this state
             }
           }
           const unsigned long long bal = __ballot(isFirst);
@@ -256,7 +288,7 @@ __global__ __launch_bounds__(kThreads) void k_viterbi(GraphDev G, DecDev Dd, con
       }
       __syncthreads();
       int numNew = 0;
-      for (int w = 0; w < kWaves; w++) numNew += s_waveTot[w];
+      for (int w = 0; w < nw; w++) numNew += s_waveTot[w];
       if (numNew > Dd.maxTok || arenaOff + numNew > Dd.arenaCap) { status = DSR_E_ALLOCATION; break; }
       // ---------------- phase C2: write the new token list (reverse first-arrival order) + back pointers
       {
@@ -265,23 +297,22 @@ __global__ __launch_bounds__(kThreads) void k_viterbi(GraphDev G, DecDev Dd, con
         for (int base = b0; base < b1; base += 64) {
           const int c = base + lane;
           if (c < b1) {
-            const CandB bc = cB[c];
-            if (bc.win >= 0) {
+            const int w = chead[c];
+            if (w >= 0) {
+              const CandB bc = cB[c];
               const int pos = numNew - 1 - (wbase + rank[c]);
-              const int w = bc.win; const CandA aw = cA[w]; const int recW = cB[w].rec; const int src = owner[w];
+              const CandA aw = cA[w]; const CandB bw = (w == c) ? bc : cB[w]; const int recW = (bw.rec & 0x3FFFFFFF) | (bw.rec & (int) 0x80000000);
               Tok nt; nt.ac = aw.ac; nt.lm = aw.lm; nt.bp = (uint32_t) (arenaOff + pos);
               Bp bp;
               if (mode == 0) {
-                const bool sil = ((uint32_t) (G.xrec[recW].dist + 1) == Dd.silenceX);
-                nt.node = bc.dst | (sil ? (int) 0x80000000 : 0);
-                bp.prev = cur[src].bp; bp.rec = (uint32_t) recW;
+                nt.node = bc.dst | ((bw.rec & 0x40000000) ? (int) 0x80000000 : 0);
+                bp.prev = bw.prevBp; bp.rec = (uint32_t) recW;
               } else {
                 nt.node = bc.dst;
-                if (recW == (int) 0x7FFFFFFE) { const Bp o = arena[cur[src].bp]; bp = o; }     // replaces the token in its chain
-                else { bp.prev = cur[src].bp; bp.rec = (uint32_t) recW; }
+                if (bw.rec == (int) 0x7FFFFFFE) { const Bp o = arena[bw.prevBp]; bp = o; }     // replaces the token in its chain
+                else { bp.prev = bw.prevBp; bp.rec = (uint32_t) bw.rec; }
               }
               nxt[pos] = nt; arena[arenaOff + pos] = bp;
-              st_u32(&first[bc.dst], 0xFFFFFFFFu); st_i32(&head[bc.dst], -1);
             }
           }
         }
@@ -291,7 +322,7 @@ __global__ __launch_bounds__(kThreads) void k_viterbi(GraphDev G, DecDev Dd, con
         if (dump) {
           long* cnt = Dd.dumpCount; const long o = cnt[0];
           if (o + numNew <= Dd.dumpCap) {
-            for (int i = tid; i < numNew; i += kThreads) {
+            for (int i = tid; i < numNew; i += nthr) {
               const Tok t = nxt[i]; Dd.dumpNode[o + i] = t.node & 0x7FFFFFFF; Dd.dumpAc[o + i] = t.ac; Dd.dumpLm[o + i] = t.lm;
               Dd.dumpArc[o + i] = G.xarc[arena[t.bp].rec];
             }
@@ -307,7 +338,7 @@ __global__ __launch_bounds__(kThreads) void k_viterbi(GraphDev G, DecDev Dd, con
         // ---------------- best token (decoder.h:639-685): list order, strict '<' on the float score
         const Tok* lst = numNew > 0 ? nxt : cur; const int cntL = numNew > 0 ? numNew : n;
         unsigned long long key = ~0ull;
-        for (int i = tid; i < cntL; i += kThreads) {
+        for (int i = tid; i < cntL; i += nthr) {
           const Tok t = lst[i]; const float s = __fadd_rn(t.ac, t.lm);
           if (s == s) { const unsigned long long k = ((unsigned long long) f2ord(s) << 32) | (unsigned) i; if (k < key) key = k; }
         }
@@ -315,7 +346,7 @@ __global__ __launch_bounds__(kThreads) void k_viterbi(GraphDev G, DecDev Dd, con
         if (lane == 0) s_waveKey[wave] = key;
         __syncthreads();
         if (tid == 0) {
-          unsigned long long k = ~0ull; for (int w = 0; w < kWaves; w++) if (s_waveKey[w] < k) k = s_waveKey[w];
+          unsigned long long k = ~0ull; for (int w = 0; w < nw; w++) if (s_waveKey[w] < k) k = s_waveKey[w];
           dsr_decode_result r; memset(&r, 0, sizeof(r));
           r.frames = T - 1; r.reachedFinal = numNew > 0 ? 1 : 0; r.activeHypos = activeHypos; r.placements = placements; r.maxActiveSeen = maxActive; r.status = DSR_OK;
           if (k != ~0ull) {
@@ -356,11 +387,11 @@ __global__ __launch_bounds__(kThreads) void k_viterbi(GraphDev G, DecDev Dd, con
     }   // frames
 
     if (status != DSR_OK) {
-      // abort: leave the state tables clean for the next utterance of this slot
-      for (int i = tid; i < G.nNodes; i += kThreads) { st_u32(&first[i], 0xFFFFFFFFu); st_i32(&head[i], -1); }
+      // abort: the tagged state table needs no cleaning
       if (tid == 0) { dsr_decode_result r; memset(&r, 0, sizeof(r)); r.status = status; r.frames = T - 1; res[u] = r; }
     }
   }
+  if (tid == 0) Dd.tags[slot] = tag;
 }
 
 struct DecoderState {
@@ -368,9 +399,9 @@ struct DecoderState {
   WfstGraph::Csr csr; WfstGraph::Tables tab;
   DevBuf<int> d_xoff, d_xarc, d_xpathOff, d_eoff, d_path, d_nodeFinal, d_queue;
   DevBuf<XRec> d_xrec; DevBuf<ERec> d_erec; DevBuf<float> d_arcCost, d_nodeCost; DevBuf<uint32_t> d_arcOut, d_arcIn;
-  DevBuf<Tok> d_tok; DevBuf<int> d_tokOff, d_owner, d_rank, d_head; DevBuf<CandA> d_cA; DevBuf<CandB> d_cB; DevBuf<unsigned> d_first; DevBuf<Bp> d_arena;
+  DevBuf<Tok> d_tok; DevBuf<int> d_tokOff, d_tokCnt, d_owner, d_rank, d_chead; DevBuf<unsigned> d_tags; DevBuf<CandA> d_cA; DevBuf<CandB> d_cB; DevBuf<unsigned> d_first; DevBuf<Bp> d_arena;
   DevBuf<dsr_decode_result> d_res; DevBuf<int> d_arcs; DevBuf<unsigned> d_words;
-  long arenaCap = 0; int initial = 0;
+  long arenaCap = 0; int initial = 0; int threads = kThreads;
   // dump
   int dumpOn = 0; long dumpCap = 0; DevBuf<long> d_dumpFrameOff, d_dumpCount; DevBuf<int> d_dumpNode, d_dumpArc; DevBuf<float> d_dumpAc, d_dumpLm;
   std::vector<int64_t> h_dumpFrameOff; std::vector<int32_t> h_dumpNode, h_dumpArc; std::vector<float> h_dumpAc, h_dumpLm; int64_t h_dumpFrames = 0;
@@ -416,9 +447,12 @@ dsr_status dsr_decoder_create(const dsr_decoder_cfg* cfg, dsr_decoder** out)
     dsr_decoder* d = new dsr_decoder(); d->cfg = *cfg;
     if (d->cfg.maxActive <= 0) d->cfg.maxActive = 65536;
     if (d->cfg.maxCandidates <= 0) d->cfg.maxCandidates = 8 * d->cfg.maxActive;
+    if (d->cfg.maxCandidates >= (1 << 24)) throw Error(DSR_E_PARAMETER, "maxCandidates must be < 2^24");
+    if (const char* e = getenv("DSR_VITERBI_THREADS")) { const int t = atoi(e); if (t == 256 || t == 512 || t == 1024) d->threads = t; }
     if (d->cfg.streams <= 0) {
       hipDeviceProp_t prop; int dev = 0; DSR_HIP(hipGetDevice(&dev)); DSR_HIP(hipGetDeviceProperties(&prop, dev));
-      d->cfg.streams = prop.multiProcessorCount;
+      d->cfg.streams = prop.multiProcessorCount * (kThreads / d->threads);
+      if (const char* e = getenv("DSR_VITERBI_SLOTS")) { const int t = atoi(e); if (t > 0) d->cfg.streams = t; }
     }
     *out = d;
   });
@@ -459,10 +493,9 @@ static void ensure_scratch(dsr_decoder* d, int slots, int Tmax)
   d->d_tok.reserve(S * 2 * c.maxActive); d->d_tokOff.reserve(S * (c.maxActive + 1));
   d->d_owner.reserve(S * c.maxCandidates); d->d_rank.reserve(S * c.maxCandidates);
   d->d_cA.reserve(S * c.maxCandidates); d->d_cB.reserve(S * c.maxCandidates);
-  d->d_first.reserve(S * d->nNodes); d->d_head.reserve(S * d->nNodes);
+  d->d_first.reserve(S * d->nNodes); d->d_tokCnt.reserve(S * (c.maxActive + 1)); d->d_chead.reserve(S * c.maxCandidates);
+  d->d_tags.reserve(S); DSR_HIP(hipMemset(d->d_tags.p, 0, S * sizeof(unsigned)));          // tag 0 = wipe the table on first use
   d->d_arena.reserve(S * (size_t) arena);
-  DSR_HIP(hipMemset(d->d_first.p, 0xFF, S * d->nNodes * sizeof(unsigned)));
-  DSR_HIP(hipMemset(d->d_head.p, 0xFF, S * d->nNodes * sizeof(int)));
   d->d_queue.reserve(1);
   d->nSlots = slots; d->arenaCap = arena;
 }
@@ -495,14 +528,17 @@ dsr_status dsr_decoder_decode_batch(dsr_decoder* d, const float* score, const in
     DecDev D; D.beam = d->cfg.beam; D.lmScale = d->cfg.lmScale; D.lmPenalty = d->cfg.lmPenalty; D.silPenalty = d->cfg.silPenalty;
     D.silenceX = d->cfg.silenceX; D.maxTok = d->cfg.maxActive; D.maxCand = d->cfg.maxCandidates; D.arenaCap = d->arenaCap;
     D.tok = d->d_tok.p; D.tokOff = d->d_tokOff.p; D.owner = d->d_owner.p; D.rank = d->d_rank.p; D.cA = d->d_cA.p; D.cB = d->d_cB.p;
-    D.first = d->d_first.p; D.head = d->d_head.p; D.arena = d->d_arena.p; D.queue = d->d_queue.p;
+    D.first = d->d_first.p; D.tags = d->d_tags.p; D.tokCnt = d->d_tokCnt.p; D.chead = d->d_chead.p; D.arena = d->d_arena.p; D.queue = d->d_queue.p;
     D.dumpOn = d->dumpOn; D.dumpCap = d->dumpCap; D.dumpFrameOff = d->d_dumpFrameOff.p; D.dumpNode = d->d_dumpNode.p; D.dumpAc = d->d_dumpAc.p;
     D.dumpLm = d->d_dumpLm.p; D.dumpArc = d->d_dumpArc.p; D.dumpCount = d->d_dumpCount.p;
-    const int useLds = (size_t) nDist * sizeof(float) <= 96 * 1024;
-    const size_t lds = useLds ? (size_t) nDist * sizeof(float) : 16;
+    const int useLds = (size_t) nDist * sizeof(float) <= 64 * 1024;
+    const size_t rowB = useLds ? (size_t) ((nDist + 3) & ~3) * sizeof(float) : 16;
+    int hashN = 16384; while (hashN > 0 && rowB + (size_t) hashN * 8 > 150 * 1024) hashN >>= 1;
+    if (getenv("DSR_VITERBI_NOHASH")) hashN = 0;
+    const size_t lds = rowB + (size_t) hashN * 8;
     DSR_HIP(hipFuncSetAttribute((const void*) k_viterbi, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
-    hipLaunchKernelGGL(k_viterbi, dim3(slots), dim3(kThreads), lds, st, G, D, score, nframes, U, Tmax, nDist, d->d_res.p,
-                       (arcs_out || words_out) ? d->d_arcs.p : nullptr, (arcs_out || words_out) ? d->d_words.p : nullptr, maxPath, useLds);
+    hipLaunchKernelGGL(k_viterbi, dim3(slots), dim3(d->threads), lds, st, G, D, score, nframes, U, Tmax, nDist, d->d_res.p,
+                       (arcs_out || words_out) ? d->d_arcs.p : nullptr, (arcs_out || words_out) ? d->d_words.p : nullptr, maxPath, useLds, hashN);
     DSR_HIP(hipGetLastError());
     DSR_HIP(hipMemcpyAsync(res, d->d_res.p, sizeof(dsr_decode_result) * U, hipMemcpyDeviceToHost, st));
     if (arcs_out) DSR_HIP(hipMemcpyAsync(arcs_out, d->d_arcs.p, sizeof(int) * (size_t) U * maxPath, hipMemcpyDeviceToHost, st));

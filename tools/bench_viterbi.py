@@ -1,0 +1,43 @@
+#!/usr/bin/env python3
+"""Decoder-only micro benchmark: BASELINE config-4 graph (50k states / ~200k arcs, 1024 distributions) on random score
+matrices whose spread is chosen so that the tuned beam gives ~5k active tokens.  Prints ms per batch and us per frame."""
+import argparse, os, sys, time
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "distantspeechrecognition-mirror_amd"))
+import torch
+import dsr._capi as dsr
+from tests import synth
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--utts", type=int, default=256); ap.add_argument("--frames", type=int, default=200)
+ap.add_argument("--streams", type=str, default="0"); ap.add_argument("--beam", type=float, default=0.0)
+ap.add_argument("--reps", type=int, default=2)
+a = ap.parse_args()
+dsr.load(); dev = torch.device("cuda:0")
+arcs, fin = synth.random_wfst(50000, 1024, seed=21, outdeg=4, eps_frac=0.1, out_frac=0.05, nWords=5000, nFinal=50)
+g = dsr.Wfst()
+for x in arcs: g.add_arc(*x)
+for s, c in fin: g.add_final(s, c)
+gen = torch.Generator(device=dev); gen.manual_seed(5)
+# scores from the bench's own GMM (1024 x 4 Gaussians, 39-dim) on smooth random feature tracks
+gm = dsr.Gmm(**synth.gmm_model(1024, 4, 39, seed=12))
+f = torch.randn((a.utts, a.frames + 16, 39), generator=gen, device=dev)
+f = torch.nn.functional.avg_pool1d(f.transpose(1, 2), 9, 1).transpose(1, 2)[:, :a.frames].contiguous() * 3.0
+sc = gm.score(f.reshape(-1, 39), mode=0, want_argmin=False)[0].reshape(a.utts, a.frames, 1024)
+if a.beam <= 0:
+    import bench
+    a.beam, act = bench.tune_beam(dsr, torch, dict(gd=g), sc[:4].contiguous(), torch.full((4,), a.frames, dtype=torch.int32, device=dev))
+    print("tuned beam %.2f -> active %.0f" % (a.beam, act), flush=True)
+for st in [int(s) for s in a.streams.split(",")]:
+    dec = dsr.Decoder(beam=a.beam, lmScale=12.0, maxActive=65536, streams=st); dec.set(g)
+    out = dec.decode_batch(sc, maxPath=16)       # warm-up + allocation
+    torch.cuda.synchronize(); t0 = time.time()
+    for _ in range(a.reps):
+        out = dec.decode_batch(sc, maxPath=16)
+    torch.cuda.synchronize(); dt = (time.time() - t0) / a.reps
+    act = np.mean([o["activeHypos"] / a.frames for o in out]); pl = np.mean([o["placements"] / a.frames for o in out])
+    bad = sum(1 for o in out if o["status"] not in (0, 5))
+    print("streams=%d utts=%d frames=%d: %.1f ms/batch, %.1f us/frame/slot-round, active %.0f placements/frame %.0f failed %d" %
+          (st, a.utts, a.frames, dt * 1e3, dt * 1e6 / a.frames / max(1, -(-a.utts // (st if st else 256))), act, pl, bad), flush=True)
+    del dec
