@@ -142,6 +142,158 @@ __global__ __launch_bounds__(256) void k_analysis(const float* __restrict__ x, c
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Wave-per-frame analysis bank (the fast path for M >= 128 and compile-time taps MT).
+// One wavefront owns one frame at a time: lane l forms the polyphase sums of the adjacent outputs
+// (2e, 2e+1), e = l + 64 rho, i.e. the packed complex point z[e]; the length-N (= M/2) DFT runs as an
+// in-register radix-2 DIF: spans >= 64 pair registers of one lane, spans 32..1 exchange across lanes
+// (ds_bpermute / DPP, no LDS memory); one bit-reversed pass through a 1 KB wave-private LDS strip puts
+// the spectrum in natural order for the even/odd split.  No workgroup barrier after the window is staged,
+// prototype taps live in registers, rows of M/2+1 complex64 leave as contiguous 8-byte-per-lane stores.
+// LDS layout: [tw: M float2][win: winLen float][zb: waves x N float2]
+__device__ __forceinline__ void wave_lds_sync() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); }
+__device__ __forceinline__ float2 cmulf(float2 a, float2 b) { return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
+// lane exchange by a DPP control word (row-local: quad_perm / row_half_mirror / row_ror -- no LDS traffic)
+template <int CTRL> __device__ __forceinline__ float dpp_f(float v)
+{ return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true)); }
+__device__ __forceinline__ float bperm_f(float v, int byteAddr) { return __int_as_float(__builtin_amdgcn_ds_bpermute(byteAddr, __float_as_int(v))); }
+
+template <int M, int MT>
+__global__ __launch_bounds__(256) void k_analysis_w(const float* __restrict__ x, const int* __restrict__ nsampArr,
+                                                    const float* __restrict__ proto, const float2* __restrict__ twG,
+                                                    float2* __restrict__ X, int C, long sampStride, int Tmax,
+                                                    int r, int pd, int laN, int gain, int TF)
+{
+  constexpr int N = M / 2, R = N / 64, LOGN = (N == 64 ? 6 : N == 128 ? 7 : N == 256 ? 8 : N == 512 ? 9 : 10);
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int D = M >> r;
+  const int winLen = (TF - 1) * D + MT * M;
+  float2* tw = reinterpret_cast<float2*>(smem);
+  float* win = reinterpret_cast<float*>(tw + M);
+  const int tid = threadIdx.x, nthr = blockDim.x, lane = tid & 63, wave = tid >> 6, nwv = nthr >> 6;
+  float2* zb = reinterpret_cast<float2*>(win + ((winLen + 3) & ~3)) + wave * (N + N / 8);     // skewed: slot i lives at i + (i >> 3)
+  const int tile = blockIdx.x, c = blockIdx.y, u = blockIdx.z;
+  const int t0 = tile * TF;
+  const int nsamp = nsampArr[u];
+  const int nblk = (nsamp + D - 1) / D;
+  const int Tu = (nblk < laN) ? 0 : (nblk - laN + pd);
+  const float* xs = x + ((long) u * C + c) * sampStride;
+  float2* Xo = X + ((long) u * C + c) * (long) Tmax * (N + 1);
+
+  for (int i = tid; i < M; i += nthr) tw[i] = twG[i];
+  const long lo = (long) (t0 + laN + 1) * D - (long) MT * M;
+  for (int i = tid; i < winLen; i += nthr) {
+    const long n = lo + i;
+    win[i] = (n >= 0 && n < nsamp) ? xs[n] : 0.0f;
+  }
+  // Element <-> lane map.  The six cross-lane butterfly stages flip element-index bits 5..0; bit b is tied to the lane
+  // exchange xor{32,16,8,7,2,1}: the four row-local ones are single DPP controls (row_ror:8, row_half_mirror, quad_perm),
+  // so lane L holds element  el = (L0^L2) | (L1^L2)<<1 | L2<<2 | L3<<3 | L[5:4]<<4  of every 64-point group.
+  const int L2b = (lane >> 2) & 1;
+  const int el = ((lane ^ L2b) & 1) | ((((lane >> 1) ^ L2b) & 1) << 1) | (lane & 0x3C);
+  // prototype taps of this lane's outputs: h[(2e+j) + qM]
+  float hreg[R][2][MT];
+#pragma unroll
+  for (int rho = 0; rho < R; rho++)
+#pragma unroll
+    for (int q = 0; q < MT; q++) {
+      const float2 hp = *reinterpret_cast<const float2*>(proto + 2 * (el + 64 * rho) + q * M);
+      hreg[rho][0][q] = hp.x; hreg[rho][1][q] = hp.y;
+    }
+  __syncthreads();
+  // per-stage constants: upper-half lanes compute (other - mine) * W_{2 span}^{el mod span}, lower-half lanes mine + other,
+  // written as  (other + sg*mine) * wq  with  sg = -1/+1  and  wq = W / 1
+  float2 wq[6]; float sg[6];
+#pragma unroll
+  for (int s = 0; s < 6; s++) {
+    const int span = 32 >> s; const bool upper = (el & span) != 0;
+    wq[s] = upper ? tw[(el & (span - 1)) * (M / (2 * span))] : make_float2(1.f, 0.f);
+    sg[s] = upper ? -1.f : 1.f;
+  }
+  float2 twf[R];
+#pragma unroll
+  for (int rho = 0; rho < R; rho++) twf[rho] = tw[lane + 64 * rho];
+  const int ad32 = (lane ^ 32) << 2, ad16 = (lane ^ 16) << 2;
+  const float g = (gain > 0) ? (float) gain : 1.0f;
+
+  for (int tl = wave; tl < TF; tl += nwv) {
+    const int t = t0 + tl;
+    if (t >= Tmax) break;
+    float2* row = Xo + (long) t * (N + 1);
+    if (t >= Tu) {                                   // frames past the end of this utterance: zero rows
+#pragma unroll
+      for (int rho = 0; rho < R; rho++) row[lane + 64 * rho] = make_float2(0.f, 0.f);
+      if (lane == 0) row[N] = make_float2(0.f, 0.f);
+      continue;
+    }
+    const int base = tl * D + MT * M - 1;            // window index of sample n_t
+    float2 z[R];
+#pragma unroll
+    for (int rho = 0; rho < R; rho++) {
+      const int k0 = 2 * (el + 64 * rho);
+      float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+      for (int q = 0; q < MT; q++) {
+        const float2 pr = *reinterpret_cast<const float2*>(win + (base - k0 - 1 - q * M));   // (x[n_t-k0-1-qM], x[n_t-k0-qM])
+        s0 += hreg[rho][0][q] * pr.y; s1 += hreg[rho][1][q] * pr.x;
+      }
+      z[rho] = make_float2(s0, s1);
+    }
+    // in-lane stages (spans N/2 .. 64)
+#pragma unroll
+    for (int span = N / 2; span >= 64; span >>= 1) {
+      const int sr = span / 64;
+#pragma unroll
+      for (int rho = 0; rho < R; rho++) {
+        if (rho & sr) continue;
+        const float2 a = z[rho], b = z[rho | sr];
+        const float2 w = tw[((rho & (sr - 1)) * 64 + el) * (M / (2 * span))];
+        z[rho] = make_float2(a.x + b.x, a.y + b.y);
+        z[rho | sr] = cmulf(make_float2(a.x - b.x, a.y - b.y), w);
+      }
+    }
+    // cross-lane stages (spans 32 .. 1)
+#define DSR_STAGE(S, EXCH) _Pragma("unroll") for (int rho = 0; rho < R; rho++) { \
+      const float ox = EXCH(z[rho].x), oy = EXCH(z[rho].y); \
+      const float2 t = make_float2(ox + sg[S] * z[rho].x, oy + sg[S] * z[rho].y); \
+      z[rho] = cmulf(t, wq[S]); }
+#define X32(v) bperm_f(v, ad32)
+#define X16(v) bperm_f(v, ad16)
+#define X8(v) dpp_f<0x128>(v)        /* row_ror:8          : lane ^ 8 */
+#define X7(v) dpp_f<0x141>(v)        /* row_half_mirror    : lane ^ 7 */
+#define X2(v) dpp_f<0x4E>(v)         /* quad_perm [2,3,0,1]: lane ^ 2 */
+#define X1(v) dpp_f<0xB1>(v)         /* quad_perm [1,0,3,2]: lane ^ 1 */
+    DSR_STAGE(0, X32) DSR_STAGE(1, X16) DSR_STAGE(2, X8) DSR_STAGE(3, X7) DSR_STAGE(4, X2) DSR_STAGE(5, X1)
+#undef DSR_STAGE
+#undef X32
+#undef X16
+#undef X8
+#undef X7
+#undef X2
+#undef X1
+    // natural order through the wave-private strip
+#pragma unroll
+    for (int rho = 0; rho < R; rho++) { const int i = (int) (__brev((unsigned) (rho * 64 + el)) >> (32 - LOGN)); zb[i + (i >> 3)] = z[rho]; }
+    wave_lds_sync();
+#pragma unroll
+    for (int rho = 0; rho < R; rho++) {
+      const int f = lane + 64 * rho;
+      const int fc = (N - f) & (N - 1);
+      const float2 zf = zb[f + (f >> 3)]; float2 zc = zb[fc + (fc >> 3)]; zc.y = -zc.y;
+      const float2 E = make_float2(0.5f * (zf.x + zc.x), 0.5f * (zf.y + zc.y));
+      const float2 dd = make_float2(zf.x - zc.x, zf.y - zc.y);
+      const float2 O = make_float2(0.5f * dd.y, -0.5f * dd.x);
+      const float2 w = twf[rho];
+      row[f] = make_float2((E.x + w.x * O.x - w.y * O.y) * g, (E.y + w.x * O.y + w.y * O.x) * g);
+    }
+    if (lane == 0) {                                 // bin N: X = Re(Z0) - Im(Z0)
+      const float2 z0 = zb[0];
+      row[N] = make_float2((z0.x - z0.y) * g, 0.f);
+    }
+    wave_lds_sync();
+  }
+}
+
 // LDS layout: [tw: M float2][proto g: m*M float][v: NV*M float][bufA: FB*M float][bufB: FB*M float]
 template <int M>
 __global__ __launch_bounds__(256) void k_synthesis(const float2* __restrict__ Y, const int* __restrict__ nframesArr,
@@ -260,8 +412,27 @@ template <int M> static void launch_synthesis(const FbPlan& p, const float* Y, c
   case 256: CALL(256); break; case 512: CALL(512); break; case 1024: CALL(1024); break; case 2048: CALL(2048); break; \
   default: throw Error(DSR_E_DIMENSION, "unsupported number of subbands M=%d (power of two in [16,2048])", M_); }
 
+template <int M, int MT> static void launch_analysis_w(const FbPlan& p, const float* x, const int* nsamp, int U, int C,
+                                                       long sampStride, int Tmax, float* X, hipStream_t st)
+{
+  int TF = 32; const int waves = 4;
+  if (const char* e = getenv("DSR_FB_TF")) { const int v = atoi(e); if (v >= 4 && v <= 256) TF = v; }
+  const int winLen = (TF - 1) * p.D + MT * M;
+  const size_t lds = sizeof(float2) * M + sizeof(float) * ((winLen + 3) & ~3) + sizeof(float2) * (size_t) waves * (M / 2 + M / 16);
+  DSR_HIP(hipFuncSetAttribute((const void*) k_analysis_w<M, MT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
+  dim3 grid(cdiv(Tmax, TF), C, U);
+  hipLaunchKernelGGL((k_analysis_w<M, MT>), grid, dim3(64 * waves), lds, st, x, nsamp, p.d_proto.p, p.d_tw.p, (float2*) X, C,
+                     sampStride, Tmax, p.r, p.pd, p.laN, p.gain, TF);
+  DSR_HIP(hipGetLastError());
+}
+
 void fb_analysis(const FbPlan& p, const float* x, const int* nsamp, int U, int C, long sampStride, int Tmax, float* X, hipStream_t st)
 {
+  if (!getenv("DSR_FB_GENERIC")) {
+#define W(MM, TT) if (p.M == MM && p.m == TT) { launch_analysis_w<MM, TT>(p, x, nsamp, U, C, sampStride, Tmax, X, st); return; }
+    W(128, 2) W(128, 4) W(256, 2) W(256, 4) W(512, 2) W(512, 4) W(1024, 2) W(1024, 4)
+#undef W
+  }
 #define CALL(MM) launch_analysis<MM>(p, x, nsamp, U, C, sampStride, Tmax, X, st)
   DSR_M_DISPATCH(p.M, CALL)
 #undef CALL

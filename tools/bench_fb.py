@@ -1,0 +1,33 @@
+#!/usr/bin/env python3
+"""Front-end micro benchmark (BASELINE config 2): B utterances x 8 ch x 10 s, M=256 m=4 r=1.
+Reports achieved algorithmic GB/s per stage kernel (analysis 1544 B / channel-frame etc.), timed with HIP events."""
+import argparse, os, sys
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "distantspeechrecognition-mirror_amd"))
+import torch
+import dsr._capi as dsr
+from tests import synth
+ap = argparse.ArgumentParser(); ap.add_argument("--utts", type=int, default=1024); ap.add_argument("--reps", type=int, default=5)
+a = ap.parse_args()
+dsr.load(); dev = torch.device("cuda:0")
+hg = np.load(os.path.join(ROOT, "tests", "golden", "proto_M256-m4-r1.npy")); h, g = hg
+M, m, r, Cn, n = 256, 4, 1, 8, 160000
+x = torch.randn((a.utts, Cn, n), device=dev) * 3000
+ana = dsr.FilterBank(h, M, m, r, False, 0); syn = dsr.FilterBank(g, M, m, r, True, 0)
+mp = synth.linear_array(Cn); d = dsr.calcDelaysPolar2(np.float32(0.5), np.float32(1.57), mp)
+bf = dsr.Beamformer(M, Cn); bf.calcArrayManifoldVectors(16000.0, d); bf.setDiffuseNoiseModel(mp, 16000.0); bf.divideAllNonDiagonalElements(0.01); bf.calcMVDRWeights(16000.0); bf.select("mvdr")
+def timeit(fn):
+    fn(); torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(a.reps): out = fn()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / a.reps, out
+T = ana.frames(n)
+ms, X = timeit(lambda: ana.analysis(x))
+print("analysis : %.3f ms  %.1f GB/s algorithmic (1544 B x %d channel-frames)" % (ms, a.utts * Cn * T * 1544 / ms / 1e6, a.utts * Cn * T), flush=True)
+ms, Y = timeit(lambda: bf.apply(X))
+print("beamform : %.3f ms  %.1f GB/s" % (ms, a.utts * T * 9 * 129 * 8 / ms / 1e6), flush=True)
+ms, y = timeit(lambda: syn.synthesis_run(Y))
+print("synthesis: %.3f ms  %.1f GB/s" % (ms, a.utts * T * (129 * 8 + 128 * 4) / ms / 1e6), flush=True)
