@@ -418,7 +418,8 @@ template <int M, int MT> static void launch_analysis_w(const FbPlan& p, const fl
   int TF = 32; const int waves = 4;
   if (const char* e = getenv("DSR_FB_TF")) { const int v = atoi(e); if (v >= 4 && v <= 256) TF = v; }
   const int winLen = (TF - 1) * p.D + MT * M;
-  const size_t lds = sizeof(float2) * M + sizeof(float) * ((winLen + 3) & ~3) + sizeof(float2) * (size_t) waves * (M / 2 + M / 16);
+  size_t lds = sizeof(float2) * M + sizeof(float) * ((winLen + 3) & ~3) + sizeof(float2) * (size_t) waves * (M / 2 + M / 16);
+  if (const char* e = getenv("DSR_FB_PADLDS")) lds += (size_t) atoi(e);          // occupancy experiments
   DSR_HIP(hipFuncSetAttribute((const void*) k_analysis_w<M, MT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
   dim3 grid(cdiv(Tmax, TF), C, U);
   hipLaunchKernelGGL((k_analysis_w<M, MT>), grid, dim3(64 * waves), lds, st, x, nsamp, p.d_proto.p, p.d_tw.p, (float2*) X, C,
