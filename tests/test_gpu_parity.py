@@ -357,3 +357,21 @@ def test_full_pipe_small(dsr, oracle, cuda, protos):
         assert res[u].score == ro["score"] and res[u].nArcs == len(ro["arcs"])
         assert np.array_equal(arcsO[u, :res[u].nArcs], ro["arcs"])
         assert np.array_equal(wordsO[u, :res[u].nWords], ro["words"])
+
+
+@pytest.mark.parametrize("K,R,D", [(256, 16, 39), (1024, 4, 39), (5, 7, 13), (3, 256, 39), (40, 33, 20)])
+def test_gmm_mfma_mode(dsr, oracle, cuda, K, R, D):
+    """mode 2 (fp32 MFMA, expanded quadratic): stated tolerance rel 1e-5 on the cost; the nearest Gaussian is the
+    reference's unless the two best distances differ by less than that (near ties are re-scored in reference order)."""
+    import torch
+    m = synth.gmm_model(K, R, D, seed=12)
+    rng = np.random.default_rng(11)
+    x = rng.standard_normal((3000, D)).astype(np.float32)
+    gm = dsr.Gmm(**m)
+    sc, am = gm.score(torch.from_numpy(x).to(cuda), mode=2)
+    cb = oracle.Codebooks(m["refN"], m["mean"], m["ivar"], m["det"])
+    ref, arg = oracle.gmm_score_opt(cb, m["val"], x)
+    sc = sc.cpu().numpy(); am = am.cpu().numpy().astype(np.int32)
+    same = am == arg
+    assert same.mean() > 0.99999
+    assert (np.abs(sc - ref)[same] / np.maximum(np.abs(ref[same]), 1.0)).max() < 1e-5
