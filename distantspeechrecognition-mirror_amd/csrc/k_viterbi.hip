@@ -28,19 +28,30 @@
 
 namespace dsr {
 
-struct Tok { int32_t node; float ac; float lm; uint32_t bp; };        // node bit31: edge input == silenceX
+struct Tok { int32_t node; float ac; float lm; uint32_t bp; };        // register view; node bit31: edge input == silenceX
+// token lists in memory: what a frame's beam test and expansion need (TokA) apart from what only the end phase needs (TokB)
+struct TokA { float ac; float lm; uint32_t bp; uint32_t xs; };        // xs: first expansion record of the node | bit31: edge input == silenceX
+struct TokB { int32_t node; int32_t cnt; };                           // cnt: number of expansion records of the node
+// expansion record as the register path reads it: what the expansion needs in the first 16 bytes, what the new token needs in the second
+struct XRecD { int32_t dist; float cost; uint32_t meta; float eps1; int32_t dst; int32_t dstXoff; int32_t dstCnt; int32_t pathOff; };   // eps1: cost of the first epsilon hop (meta bit17: it has an output)
+struct Side { double ttl; float ac; float lm; int32_t rec; uint32_t prevBp; int32_t c; uint32_t next; };   // a later arrival at an occupied state
 struct CandA { double ttl; float ac; float lm; };
 struct CandB { int32_t dst; int32_t next; int32_t rec; uint32_t prevBp; };   // rec bit30: the emitting arc's input is the silence symbol
 struct Bp { uint32_t prev; uint32_t rec; };
 
 static constexpr uint32_t kNone = 0xFFFFFFFFu;
 static constexpr uint32_t kEndBit = 0x80000000u;
-static constexpr int kThreads = 1024;
+static constexpr int kThreads = 512;              // 8 waves: 256 VGPRs per thread for the register path
 static constexpr int kWaves = kThreads / 64;
+static constexpr int kFastK = 16;                  // placements a thread keeps in registers on the register path
+static constexpr int kFastC = 12288;               // most placements per frame on the register path (8 more per thread are parked in memory)
+static constexpr int kFastE = 8190;                // most expanding tokens per frame on the register path
+static constexpr int kP1 = 32;                     // token rounds per wave in the register path's beam pass
+static constexpr int kSideLds = 528;               // later arrivals kept in LDS (the region also holds the slot offsets, dead by then)               // most placements / expanding tokens per frame on the register path
 
 struct GraphDev {
   int nNodes, initial;
-  const int* xoff; const XRec* xrec; const int* xarc; const int* xpathOff;
+  const int* xoff; const XRec* xrec; const XRecD* xrecD; const int* xarc; const int* xpathOff;
   const int* eoff; const ERec* erec; const int* path;
   const float* arcCost; const uint32_t* arcOut; const uint32_t* arcIn;
   const int* nodeFinal; const float* nodeCost;
@@ -50,8 +61,8 @@ struct DecDev {
   double beam, lmScale, lmPenalty, silPenalty; uint32_t silenceX;
   int maxTok, maxCand; long arenaCap;
   // per-slot scratch (slot s at base + s*stride)
-  Tok* tok; int* tokOff; int* tokCnt; int* owner; int* rank; int* chead; CandA* cA; CandB* cB; unsigned* first; unsigned* tags; Bp* arena;
-  int* queue;
+  TokA* tokA; TokB* tokB; TokA* ctok; Side* side; int fastOK; int* tokOff; int* tokCnt; int* owner; int* rank; int* chead; CandA* cA; CandB* cB; unsigned* first; unsigned* tags; Bp* arena;
+  int* queue; long long* prof;          // prof: optional per-phase wall-clock ticks (DSR_VITERBI_PROF), 16 per slot
   // dump (slot 0 only)
   int dumpOn; long dumpCap; long* dumpFrameOff; int* dumpNode; float* dumpAc; float* dumpLm; int* dumpArc; long* dumpCount;
 };
@@ -79,9 +90,19 @@ __device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long v)
   for (int d = 32; d >= 1; d >>= 1) { const unsigned long long o = __shfl_xor(v, d, 64); v = (o < v) ? o : v; }
   return v;
 }
+// wave-uniform values computed from LDS land in vector registers; these move them to scalar ones
+__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ double uni(double v) { return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)), __builtin_amdgcn_readfirstlane(__double2loint(v))); }
 __device__ __forceinline__ unsigned f2ord(float f) { const unsigned u = __float_as_uint(f); return (u & 0x80000000u) ? ~u : (u | 0x80000000u); }
 
 // One decoded utterance per loop iteration of a persistent workgroup.
+//
+// A frame runs on one of two paths that produce identical lists:
+//   * the register path (frames with at most kFastC placements, 16 per thread): thread t owns the arrival slots t, t+nthr, ...
+//     and keeps those placements in registers from expansion to the write of the new list; the expanding
+//     tokens are compacted first (slot offsets in LDS), recombination goes through the LDS state table, and only the
+//     later arrivals at an occupied state (a few percent) are spilled to memory for the first arrival to fold;
+//   * the memory path (any size, and the end expansion): placements are staged in global arrays, one thread per placement.
 __global__ __launch_bounds__(kThreads) void k_viterbi(GraphDev G, DecDev Dd, const float* __restrict__ scores,
                                                       const int* __restrict__ nframesArr, int U, int Tmax, int nDist,
                                                       dsr_decode_result* __restrict__ res, int* __restrict__ arcsOut,
@@ -94,15 +115,28 @@ __global__ __launch_bounds__(kThreads) void k_viterbi(GraphDev G, DecDev Dd, con
   // traffic on chip.  Frames with more placements than the table can take fall back to the tagged global table.
   unsigned* hkey = reinterpret_cast<unsigned*>(srow + (useLdsRow ? ((nDist + 3) & ~3) : 4));
   unsigned* hfirst = hkey + hashN;
+  unsigned short* eoff = reinterpret_cast<unsigned short*>(hfirst + hashN);     // [kFastC + 2] slot offset of every expanding token (register path)
+  Side* sideL = reinterpret_cast<Side*>(hfirst + hashN);                        // [kSideLds] same region, used after the expansion
   __shared__ int s_waveTot[kWaves];
+  __shared__ int s_waveTotE[kWaves];
   __shared__ double s_waveMin[kWaves];
   __shared__ unsigned long long s_waveKey[kWaves];
-  const int nthr = blockDim.x, nw = nthr >> 6;      // 256..1024 threads
+  __shared__ int s_sideN;
+  __shared__ unsigned s_bm[kFastC / 32];             // register path: slots where an expanding token's run starts
+  __shared__ unsigned short s_gbase[kFastC / 64 + 4]; // register path: expanding tokens that start before each group of 64 slots
+  __shared__ int s_cnt[(kFastK + 8) * kWaves];             // register path: first arrivals per (k, wave) group, then their exclusive prefix
+  __shared__ long long s_prof[16]; __shared__ long long s_tlast;
+  if (threadIdx.x < 16) s_prof[threadIdx.x] = 0;
+#define TICK(ix) do { if (Dd.prof && tid == 0) { const long long tn = (long long) wall_clock64(); s_prof[ix] += tn - s_tlast; s_tlast = tn; } } while (0)
+  const int nthr = blockDim.x, nw = nthr >> 6;      // 256 or 512 threads
   __shared__ int s_u;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int slot = blockIdx.x;
-  Tok* tokA = Dd.tok + (size_t) slot * 2 * Dd.maxTok; Tok* tokB = tokA + Dd.maxTok;
+  TokA* tokA0 = Dd.tokA + (size_t) slot * 2 * Dd.maxTok; TokA* tokA1 = tokA0 + Dd.maxTok;
+  TokB* tokB0 = Dd.tokB + (size_t) slot * 2 * Dd.maxTok; TokB* tokB1 = tokB0 + Dd.maxTok;
+  TokA* ctok = Dd.ctok + (size_t) slot * 8192;
+  Side* side = Dd.side + (size_t) slot * kFastC;
   int* tokOff = Dd.tokOff + (size_t) slot * (Dd.maxTok + 1);
   int* tokCnt = Dd.tokCnt + (size_t) slot * (Dd.maxTok + 1);
   int* chead = Dd.chead + (size_t) slot * Dd.maxCand;
@@ -114,6 +148,10 @@ __global__ __launch_bounds__(kThreads) void k_viterbi(GraphDev G, DecDev Dd, con
   // needs resetting; the table is wiped when the 8-bit tag runs out (and on the very first use of a slot)
   unsigned tag = Dd.tags[slot];
   Bp* arena = Dd.arena + (size_t) slot * Dd.arenaCap;
+  const int fastCapC0 = ((kFastK + 8) * nthr < kFastC) ? (kFastK + 8) * nthr : kFastC;
+  const int fastCapC = (fastCapC0 < (hashN >> 1) + (hashN >> 2)) ? fastCapC0 : (hashN >> 1) + (hashN >> 2);   // table load <= 0.75
+  const int fastCapN = kP1 * 64 * nw;                                   // kP1 rounds of 64 tokens per wave
+  const bool fastOK = Dd.fastOK && hashN >= 16384;
 
   for (;;) {
     __syncthreads();
@@ -128,21 +166,327 @@ __global__ __launch_bounds__(kThreads) void k_viterbi(GraphDev G, DecDev Dd, con
     int status = DSR_OK;
     if (T <= 0) status = DSR_E_ITERATOR;         // no frame at all: the exception escapes decode() (decoder.h:691)
 
-    Tok* cur = tokA; Tok* nxt = tokB;
-    int n = 1; long arenaOff = 0; long activeHypos = 0; long placements = 0; int maxActive = 0;
+    TokA* curA = tokA0; TokA* nxtA = tokA1; TokB* curB = tokB0; TokB* nxtB = tokB1;
+    int n = 1; long arenaOff = 0; long activeHypos = 0; long placements = 0; int maxActive = 0; long regFrames = 0;
     double thresh = HUGE_VAL, topScore = HUGE_VAL;
     for (int i = tid; i < 2 * hashN; i += nthr) hkey[i] = (i < hashN) ? 0u : 0xFFFFFFFFu;
-    if (tid == 0) { Tok t0; t0.node = G.initial; t0.ac = 0.0f; t0.lm = 0.0f; t0.bp = kNone; cur[0] = t0; }
+    if (tid == 0) {
+      TokA t0; t0.ac = 0.0f; t0.lm = 0.0f; t0.bp = kNone; t0.xs = (uint32_t) G.xoff[G.initial]; curA[0] = t0;
+      TokB b0; b0.node = G.initial; b0.cnt = G.xoff[G.initial + 1] - G.xoff[G.initial]; curB[0] = b0;
+    }
     __syncthreads();
 
     // frames 0..T-1 (mode 0), then the end expansion (mode 1)
     for (int fr = 0; fr <= T && status == DSR_OK; fr++) {
       const int mode = (fr == T) ? 1 : 0;
-      if (tag <= 1u) { for (int i = tid; i < G.nNodes; i += nthr) first[i] = 0xFFFFFFFFu; tag = 255u; __syncthreads(); } else tag--;
-      const unsigned tagw = tag << 24;
       if (mode == 0 && useLdsRow) { for (int i = tid; i < nDist; i += nthr) srow[i] = sc[(size_t) fr * nDist + i]; }
       const float* row = useLdsRow ? srow : (sc + (size_t) fr * nDist);
+      int numNew = 0;
+      if (Dd.prof && tid == 0) s_tlast = (long long) wall_clock64();
+      bool fast = fastOK && mode == 0 && n <= fastCapN;
 
+      if (fast) {
+        // ======================= register path =======================
+        // ---- P1: beam test, per-wave exclusive scans of the placement counts and of the expanding tokens.
+        // Token loads are issued eight at a time (straight-line, clamped indices) so their latencies overlap.
+        const int chunkT = ((n + nw * 64 - 1) / (nw * 64)) * 64;
+        float psc[kP1]; int pcn[kP1]; unsigned pk[kP1];                        // score; expansion count; slot offset | token index << 14 | bit31: expands
+        int runC = 0, runE = 0;
+        {
+          const int b0 = wave * chunkT, b1 = (b0 + chunkT < n) ? b0 + chunkT : n;
+#pragma unroll
+          for (int g = 0; g < kP1; g += 8) {
+            if (g * 64 < chunkT) {
+#pragma unroll
+              for (int it = g; it < g + 8; it++) {
+                int i = b0 + it * 64 + lane; i = (i < n) ? i : n - 1;
+                const float2 a = *reinterpret_cast<const float2*>(&curA[i].ac); pcn[it] = curB[i].cnt;
+                psc[it] = __fadd_rn(a.x, a.y);
+              }
+            } else {
+#pragma unroll
+              for (int it = g; it < g + 8; it++) { pcn[it] = 0; psc[it] = 0.0f; }
+            }
+          }
+          for (int i = tid; i < kFastC / 32; i += nthr) s_bm[i] = 0u;
+#pragma unroll
+          for (int it = 0; it < kP1; it++) {
+            const int base = b0 + it * 64; pk[it] = 0u;
+            if (base < b1) {
+              const int i = base + lane; int cnt = 0;
+              if (i < b1) {
+                if (!((double) psc[it] > thresh)) cnt = pcn[it];               // beam (decoder.h:586-588)
+              }
+              pcn[it] = cnt;
+              const int incl = wave_incl_scan(cnt, lane);
+              const unsigned long long bal = __ballot(cnt > 0);
+              if (cnt > 0) pk[it] = 0x80000000u | (unsigned) ((runC + incl - cnt) & 0x3FFF) | ((unsigned) ((runE + __popcll(bal & ((1ull << lane) - 1ull))) & 0x1FFFF) << 14);
+              runC += __shfl(incl, 63, 64); runE += __popcll(bal);
+            }
+          }
+          if (lane == 0) { s_waveTot[wave] = runC; s_waveTotE[wave] = runE; }
+          if (tid == 0) { s_sideN = 0; s_gbase[0] = 0; }
+        }
+        __syncthreads();
+        TICK(0);
+        int C = 0, E = 0, cbase = 0, ebase = 0;
+        for (int w = 0; w < nw; w++) { const int a = s_waveTot[w], b = s_waveTotE[w]; if (w < wave) { cbase += a; ebase += b; } C += a; E += b; }
+        C = uni(C); E = uni(E); cbase = uni(cbase); ebase = uni(ebase);
+        if (C > fastCapC || E > kFastE) { fast = false; __syncthreads(); }     // uniform: the memory path redoes the frame
+        else {
+          // ---- P2: compact list of the expanding tokens (their slot offsets in LDS, the tokens themselves in memory); a bitmap
+          // of the slots where a token's run starts and the token count before every group of 64 slots turn "slot -> token"
+          // into a population count
+#pragma unroll
+          for (int it = 0; it < kP1; it++) if (pk[it] & 0x80000000u) {
+            const int e = ebase + (int) ((pk[it] >> 14) & 0x1FFFFu); const int off = cbase + (int) (pk[it] & 0x3FFFu);
+            eoff[e] = (unsigned short) off;
+            ctok[e] = curA[wave * chunkT + it * 64 + lane];
+            atomicOr(&s_bm[off >> 5], 1u << (off & 31));
+            for (int g = (off >> 6) + 1; g <= ((off + pcn[it]) >> 6); g++) s_gbase[g] = (unsigned short) (e + 1);   // this token covers slot 64g-1
+          }
+          __syncthreads();
+          TICK(1);
+          placements += C; regFrames++;
+          // (tq/lq/wq = tid/lane/wave behind an opaque copy: keeps the per-slot address arithmetic of the unrolled phases inside
+          // the frame loop -- hoisted out of it, those hundred-odd invariants would live in scratch memory)
+          int tq = tid; asm volatile("" : "+v"(tq)); const int lq = tq & 63, wq = tq >> 6;
+          // ---- P3: slots c = k * nthr + tid (neighbouring lanes expand neighbouring arcs of the same few tokens).
+          // A placement is four words: ac, lm, expansion record (bit30: silence arc) and ek = compact token index | table
+          // bucket << 13 (after the fold: bit31 | side index when a later arrival won).  The first kFastK per thread stay in
+          // registers for the whole frame; slots beyond (one more batch of eight) are parked in memory between the phases.
+          const int K = (C + nthr - 1) / nthr;
+          float qac[kFastK], qlm[kFastK]; int qrec[kFastK]; unsigned ek[kFastK];
+          double* ttlS = reinterpret_cast<double*>(cA);                        // unrounded totals, read back by later arrivals only
+          uint4* ovf = reinterpret_cast<uint4*>(cB);                           // parked placements [slot - kFastK * nthr]
+          double locMin = HUGE_VAL;
+          const bool prevNull0 = (fr == 0);                                    // only the start token has no edge (decoder.h:960)
+#pragma unroll
+          for (int k = 0; k < kFastK; k++) { qac[k] = 0.0f; qlm[k] = 0.0f; qrec[k] = 0; ek[k] = 0u; }
+
+          auto expand8 = [&](const int g8, float* ac8, float* lm8, int* rec8, unsigned* ek8) __attribute__((always_inline)) {
+            int4 xr[8]; int xd[8]; bool tsil[8];
+#pragma unroll
+            for (int i = 0; i < 8; i++) {                                      // slot -> (token, position in its expansion list)
+              const int k = g8 + i; const int c = k * nthr + tq; const int grp = k * nw + wq;
+              unsigned e = 0u; int j = 0;
+              if (c < C) {
+                const unsigned long long W = ((unsigned long long) s_bm[2 * grp + 1] << 32) | s_bm[2 * grp];
+                e = (unsigned) s_gbase[grp] + (unsigned) __popcll(W & ((2ull << lq) - 1ull)) - 1u;
+                j = c - (int) eoff[e];
+              }
+              ek8[i] = e; rec8[i] = j;
+            }
+#pragma unroll
+            for (int i = 0; i < 8; i++) {                                      // eight token loads in flight
+              const TokA t = ctok[ek8[i]];
+              ac8[i] = t.ac; lm8[i] = t.lm; rec8[i] += (int) (t.xs & 0x7FFFFFFFu); tsil[i] = (t.xs >> 31) != 0u;
+            }
+#pragma unroll
+            for (int i = 0; i < 8; i++) {                                      // eight record loads in flight
+              xr[i] = *reinterpret_cast<const int4*>(&G.xrecD[rec8[i]]); xd[i] = G.xrecD[rec8[i]].dst;
+            }
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+              const int c = (g8 + i) * nthr + tq;
+              if (c < C) {
+                const int xdist = xr[i].x; const float xcost = __int_as_float(xr[i].y); const uint32_t xmeta = (uint32_t) xr[i].z;
+                const float e1 = __int_as_float(xr[i].w);
+                const int plen = (int) (xmeta & 0xFFFFu);
+                double lmNode = (double) lm8[i]; uint32_t prevIn = tsil[i] ? Dd.silenceX : (Dd.silenceX + 1u);   // only equality with silenceX matters
+                bool prevNull = prevNull0;
+                if (plen) {                                                    // intermediate epsilon tokens (decoder.h:979-983)
+                  {                                                            // first hop: its cost travels with the record
+                    double l = __dadd_rn(lmNode, __dmul_rn(Dd.lmScale, (double) e1));
+                    if (xmeta & 0x20000u) l = __dadd_rn(l, __dmul_rn(Dd.lmScale, Dd.lmPenalty));
+                    if (0u == Dd.silenceX && (prevNull || prevIn != Dd.silenceX)) l = __dadd_rn(l, __dmul_rn(Dd.lmScale, Dd.silPenalty));
+                    lmNode = (double) (float) l; prevIn = 0u; prevNull = false;
+                  }
+                  if (plen > 1) {
+                    const int* pp = G.path + G.xrecD[rec8[i]].pathOff;
+                    for (int h = 1; h < plen; h++) {
+                      const int a = pp[h];
+                      double l = __dadd_rn(lmNode, __dmul_rn(Dd.lmScale, (double) G.arcCost[a]));
+                      if (G.arcOut[a] != 0) l = __dadd_rn(l, __dmul_rn(Dd.lmScale, Dd.lmPenalty));
+                      lmNode = (double) (float) l;                              // (the edge before is an epsilon edge: no silence penalty possible here)
+                    }
+                  }
+                }
+                double lm = __dadd_rn(lmNode, __dmul_rn(Dd.lmScale, (double) xcost));
+                if (xmeta & 0x10000u) lm = __dadd_rn(lm, __dmul_rn(Dd.lmScale, Dd.lmPenalty));
+                const bool silArc = ((uint32_t) (xdist + 1) == Dd.silenceX);
+                if (silArc && (prevNull || prevIn != Dd.silenceX)) lm = __dadd_rn(lm, __dmul_rn(Dd.lmScale, Dd.silPenalty));
+                const double ac = __dadd_rn((double) ac8[i], (double) row[xdist]);
+                const double ttl = __dadd_rn(ac, lm);
+                ttlS[c] = ttl; ac8[i] = (float) ac; lm8[i] = (float) lm; rec8[i] |= (silArc ? 0x40000000 : 0);
+                if (ttl < locMin) locMin = ttl;                                // _topScore
+                // state table: claim the bucket, keep the smallest slot
+                const unsigned key = (unsigned) xd[i] + 1u;
+                unsigned h = ((unsigned) xd[i] * 2654435761u) >> 7 & (unsigned) (hashN - 1);
+                for (;;) {
+                  const unsigned kk = atomicCAS(&hkey[h], 0u, key);
+                  if (kk == 0u || kk == key) break;
+                  h = (h + 1u) & (unsigned) (hashN - 1);
+                }
+                atomicMin(&hfirst[h], (unsigned) c);
+                ek8[i] |= h << 13;
+              }
+            }
+          };
+          expand8(0, &qac[0], &qlm[0], &qrec[0], &ek[0]);
+          if (K > 8) expand8(8, &qac[8], &qlm[8], &qrec[8], &ek[8]);
+          if (K > kFastK) {
+            float oac[8], olm[8]; int orec[8]; unsigned oek[8];
+            expand8(kFastK, oac, olm, orec, oek);
+#pragma unroll
+            for (int i = 0; i < 8; i++) { const int c = (kFastK + i) * nthr + tq; if (c < C) ovf[c - kFastK * nthr] = make_uint4(__float_as_uint(oac[i]), __float_as_uint(olm[i]), (unsigned) orec[i], oek[i]); }
+          }
+          TICK(2);
+          locMin = wave_min_d(locMin);
+          if (lq == 0) s_waveMin[wq] = locMin;
+          TICK(3);
+          __syncthreads();
+          TICK(4);
+          topScore = HUGE_VAL;
+          for (int w = 0; w < nw; w++) { const double v = s_waveMin[w]; if (v < topScore) topScore = v; }
+          topScore = uni(topScore);
+          // ---- P4: later arrivals hang themselves on their bucket (the key word becomes the chain head)
+          unsigned firstMask = 0u;
+          auto later8 = [&](const int g8, const float* ac8, const float* lm8, const int* rec8, const unsigned* ek8) __attribute__((always_inline)) {
+            double tt[8]; uint32_t pb[8];
+#pragma unroll
+            for (int i = 0; i < 8; i++) {                                      // what a later arrival hands over; loaded for all (coalesced, in flight together)
+              int c = (g8 + i) * nthr + tq; c = (c < C) ? c : 0;
+              tt[i] = ttlS[c]; pb[i] = ctok[ek8[i] & 0x1FFFu].bp;
+            }
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+              const int c = (g8 + i) * nthr + tq;
+              if (c < C) {
+                const unsigned h = ek8[i] >> 13;
+                if (hfirst[h] == (unsigned) c) firstMask |= 1u << (g8 + i);
+                else {
+                  const int sx = atomicAdd(&s_sideN, 1);
+                  const unsigned nx = atomicExch(&hkey[h], 0x80000000u | (unsigned) sx);
+                  Side sd; sd.ttl = tt[i]; sd.ac = ac8[i]; sd.lm = lm8[i]; sd.rec = rec8[i]; sd.prevBp = pb[i]; sd.c = c; sd.next = nx;
+                  if (sx < kSideLds) sideL[sx] = sd; else side[sx] = sd;
+                }
+              }
+            }
+          };
+          auto park_load = [&](float* oac, float* olm, int* orec, unsigned* oek) __attribute__((always_inline)) {
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+              int c = (kFastK + i) * nthr + tq; c = (c < C) ? c : kFastK * nthr;          // K > kFastK: that slot exists
+              const uint4 v = ovf[c - kFastK * nthr];
+              oac[i] = __uint_as_float(v.x); olm[i] = __uint_as_float(v.y); orec[i] = (int) v.z; oek[i] = v.w;
+            }
+          };
+          later8(0, &qac[0], &qlm[0], &qrec[0], &ek[0]);
+          if (K > 8) later8(8, &qac[8], &qlm[8], &qrec[8], &ek[8]);
+          if (K > kFastK) { float oac[8], olm[8]; int orec[8]; unsigned oek[8]; park_load(oac, olm, orec, oek); later8(kFastK, oac, olm, orec, oek); }
+          __syncthreads();
+          TICK(5);
+          // ---- P5: fold the later arrivals of every first arrival in slot order (decoder.h:519-528); count the new tokens
+          auto fold1 = [&](const int k, float& ac, float& lm, int& rec, unsigned& ekk) __attribute__((always_inline)) {
+            const bool isFirst = (firstMask >> k) & 1u;
+            if (isFirst) {
+              const unsigned head = hkey[ekk >> 13];
+              ekk &= 0x1FFFu;
+              if (head & 0x80000000u) {
+                int wslot = k * nthr + tq, wIdx = -1; double fw = (double) __fadd_rn(ac, lm);
+                for (;;) {                                                     // next replacement = smallest later slot that beats the incumbent
+                  int best = 0x7FFFFFFF, bi = -1, steps = 0;
+                  for (unsigned p = head; (p & 0x80000000u) && steps <= C; steps++) {
+                    const int pi = (int) (p & 0x7FFFFFFFu);
+                    int pc; double pt; unsigned pn;
+                    if (pi < kSideLds) { pc = sideL[pi].c; pt = sideL[pi].ttl; pn = sideL[pi].next; } else { pc = side[pi].c; pt = side[pi].ttl; pn = side[pi].next; }
+                    if (pc > wslot && pc < best && pt < fw) { best = pc; bi = pi; }
+                    p = pn;
+                  }
+                  if (bi < 0) break;
+                  wslot = best; wIdx = bi;
+                  fw = (bi < kSideLds) ? (double) __fadd_rn(sideL[bi].ac, sideL[bi].lm) : (double) __fadd_rn(side[bi].ac, side[bi].lm);
+                }
+                if (wIdx >= 0) {
+                  if (wIdx < kSideLds) { ac = sideL[wIdx].ac; lm = sideL[wIdx].lm; rec = sideL[wIdx].rec; }
+                  else { ac = side[wIdx].ac; lm = side[wIdx].lm; rec = side[wIdx].rec; }
+                  ekk = 0x80000000u | (unsigned) wIdx;
+                }
+              }
+            }
+            const unsigned long long bal = __ballot(isFirst);
+            if (lq == 0) s_cnt[k * nw + wq] = __popcll(bal);
+          };
+#pragma unroll
+          for (int k = 0; k < kFastK; k++) if (k < K) fold1(k, qac[k], qlm[k], qrec[k], ek[k]);
+          if (K > kFastK) {
+            float oac[8], olm[8]; int orec[8]; unsigned oek[8]; park_load(oac, olm, orec, oek);
+#pragma unroll
+            for (int i = 0; i < 8; i++) if (kFastK + i < K) {
+              fold1(kFastK + i, oac[i], olm[i], orec[i], oek[i]);
+              const int c = (kFastK + i) * nthr + tq; if (c < C) ovf[c - kFastK * nthr] = make_uint4(__float_as_uint(oac[i]), __float_as_uint(olm[i]), (unsigned) orec[i], oek[i]);
+            }
+          }
+          __syncthreads();
+          if (wq == 0) {                                                     // exclusive prefix over (k, wq) = slot order of the groups
+            const int nG = K * nw;                                             // <= 4 * 64
+            int a[4], tot = 0;
+#pragma unroll
+            for (int q = 0; q < 4; q++) { a[q] = (4 * lq + q < nG) ? s_cnt[4 * lq + q] : 0; tot += a[q]; }
+            const int incl = wave_incl_scan(tot, lq); int run = incl - tot;
+#pragma unroll
+            for (int q = 0; q < 4; q++) { if (4 * lq + q < nG) s_cnt[4 * lq + q] = run; run += a[q]; }
+            if (lq == 63) s_waveTot[0] = incl;
+          }
+          __syncthreads();
+          TICK(6);
+          numNew = uni(s_waveTot[0]);
+          if (numNew > Dd.maxTok || arenaOff + numNew > Dd.arenaCap) { status = DSR_E_ALLOCATION; break; }
+          // ---- P6: the new list in reverse first-arrival order + back pointers; the state table is wiped for the next frame
+          auto write4 = [&](const int g4, const float* ac4, const float* lm4, const int* rec4, const unsigned* ek4) __attribute__((always_inline)) {
+            int4 dx[4]; uint32_t pv[4];
+#pragma unroll
+            for (int i = 0; i < 4; i++) {                                      // unconditional loads (every index is in bounds), in flight together
+              dx[i] = *reinterpret_cast<const int4*>(&G.xrecD[rec4[i] & 0x3FFFFFFF].dst);                  // same state for every arrival
+              const bool sw = (ek4[i] & 0x80000000u) != 0u; const unsigned si = ek4[i] & 0x7FFFFFFFu;
+              const uint32_t* pb = (sw && si >= (unsigned) kSideLds) ? &side[si].prevBp : &ctok[sw ? 0u : (ek4[i] & 0x1FFFu)].bp;
+              pv[i] = *pb;
+              if (sw && si < (unsigned) kSideLds) pv[i] = sideL[si].prevBp;
+            }
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+              const int k = g4 + i;
+              if (k < K) {
+                const bool isFirst = (firstMask >> k) & 1u;
+                const unsigned long long bal = __ballot(isFirst);
+                if (isFirst) {
+                  const int pos = numNew - 1 - (s_cnt[k * nw + wq] + __popcll(bal & ((1ull << lq) - 1ull)));
+                  TokA na; na.ac = ac4[i]; na.lm = lm4[i]; na.bp = (uint32_t) (arenaOff + pos); na.xs = (uint32_t) dx[i].y | ((rec4[i] & 0x40000000) ? 0x80000000u : 0u);
+                  TokB nb; nb.node = dx[i].x; nb.cnt = dx[i].z;
+                  Bp bp; bp.prev = pv[i]; bp.rec = (uint32_t) (rec4[i] & 0x3FFFFFFF);
+                  nxtA[pos] = na; nxtB[pos] = nb; arena[arenaOff + pos] = bp;
+                }
+              }
+            }
+          };
+#pragma unroll
+          for (int g4 = 0; g4 < kFastK; g4 += 4) if (g4 < K) write4(g4, &qac[g4], &qlm[g4], &qrec[g4], &ek[g4]);
+          if (K > kFastK) {
+            float oac[8], olm[8]; int orec[8]; unsigned oek[8]; park_load(oac, olm, orec, oek);
+            write4(kFastK, &oac[0], &olm[0], &orec[0], &oek[0]);
+            if (K > kFastK + 4) write4(kFastK + 4, &oac[4], &olm[4], &orec[4], &oek[4]);
+          }
+          {
+            uint4* h4 = reinterpret_cast<uint4*>(hkey); const int q4 = hashN >> 2;
+            for (int i = tid; i < 2 * q4; i += nthr) h4[i] = (i < q4) ? make_uint4(0u, 0u, 0u, 0u) : make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
+          }
+        }
+      }
+      if (!fast) {
+      // ======================= memory path =======================
+      if (tag <= 1u) { for (int i = tid; i < G.nNodes; i += nthr) first[i] = 0xFFFFFFFFu; tag = 255u; __syncthreads(); } else tag--;
+      const unsigned tagw = tag << 24;
       // ---------------- phase A: per-token placement counts, wave-local exclusive scan
       const int chunkT = ((n + nw * 64 - 1) / (nw * 64)) * 64;
       {
@@ -151,11 +495,11 @@ __global__ __launch_bounds__(kThreads) void k_viterbi(GraphDev G, DecDev Dd, con
         for (int base = b0; base < b1; base += 64) {
           const int i = base + lane; int cnt = 0;
           if (i < b1) {
-            const Tok t = cur[i]; const int nd = t.node & 0x7FFFFFFF;
+            const TokA ta = curA[i]; const TokB tb = curB[i];
             if (mode == 0) {
-              const float s = __fadd_rn(t.ac, t.lm);
-              if (!((double) s > thresh)) cnt = G.xoff[nd + 1] - G.xoff[nd];       // beam (decoder.h:586-588)
-            } else cnt = (G.nodeFinal[nd] ? 1 : 0) + (G.eoff[nd + 1] - G.eoff[nd]);
+              const float s = __fadd_rn(ta.ac, ta.lm);
+              if (!((double) s > thresh)) cnt = tb.cnt;                        // beam (decoder.h:586-588)
+            } else cnt = (G.nodeFinal[tb.node] ? 1 : 0) + (G.eoff[tb.node + 1] - G.eoff[tb.node]);
           }
           const int incl = wave_incl_scan(cnt, lane);
           if (i < b1) { tokOff[i] = running + incl - cnt; tokCnt[i] = cnt; }
@@ -167,6 +511,7 @@ __global__ __launch_bounds__(kThreads) void k_viterbi(GraphDev G, DecDev Dd, con
       int C = 0;
       for (int w = 0; w < nw; w++) C += s_waveTot[w];
       if (C > Dd.maxCand) { status = DSR_E_ALLOCATION; break; }
+      if (Dd.prof && tid == 0 && mode == 0) s_prof[C <= 8192 ? 9 : C <= 10240 ? 10 : C <= 12288 ? 11 : C <= 16384 ? 12 : C <= 24576 ? 13 : 14] += 100;   // histogram of memory-path frames
       placements += C;
       const bool useHash = hashN > 0 && C <= (hashN >> 1) + (hashN >> 2);        // load factor <= 0.75 even if every placement is a new state
       // ---------------- phase A2: absolute offsets + owner fill
@@ -183,11 +528,12 @@ __global__ __launch_bounds__(kThreads) void k_viterbi(GraphDev G, DecDev Dd, con
       // ---------------- phase B: one thread per placement
       double locMin = HUGE_VAL;
       for (int c = tid; c < C; c += nthr) {
-        const int i = owner[c]; const Tok t = cur[i]; const int nd = t.node & 0x7FFFFFFF; const bool tokSil = t.node < 0;
+        const int i = owner[c]; const TokA ta = curA[i]; const int nd = curB[i].node; const bool tokSil = (ta.xs >> 31) != 0u;
+        Tok t; t.node = nd; t.ac = ta.ac; t.lm = ta.lm; t.bp = ta.bp;
         const int j = c - tokOff[i];
         double ac = (double) t.ac, lm; int dst, recId; bool silArc = false;
         if (mode == 0) {
-          recId = G.xoff[nd] + j; const XRec x = G.xrec[recId];
+          recId = (int) (ta.xs & 0x7FFFFFFFu) + j; const XRec x = G.xrec[recId];
           const int plen = (int) (x.meta & 0xFFFFu);
           double lmNode = (double) t.lm; uint32_t prevIn = tokSil ? Dd.silenceX : (Dd.silenceX + 1u);   // only equality with silenceX matters
           bool prevNull = (t.bp == kNone) && (fr == 0);
@@ -287,7 +633,6 @@ __global__ __launch_bounds__(kThreads) void k_viterbi(GraphDev G, DecDev Dd, con
         if (lane == 0) s_waveTot[wave] = running;
       }
       __syncthreads();
-      int numNew = 0;
       for (int w = 0; w < nw; w++) numNew += s_waveTot[w];
       if (numNew > Dd.maxTok || arenaOff + numNew > Dd.arenaCap) { status = DSR_E_ALLOCATION; break; }
       // ---------------- phase C2: write the new token list (reverse first-arrival order) + back pointers
@@ -302,28 +647,31 @@ __global__ __launch_bounds__(kThreads) void k_viterbi(GraphDev G, DecDev Dd, con
               const CandB bc = cB[c];
               const int pos = numNew - 1 - (wbase + rank[c]);
               const CandA aw = cA[w]; const CandB bw = (w == c) ? bc : cB[w]; const int recW = (bw.rec & 0x3FFFFFFF) | (bw.rec & (int) 0x80000000);
-              Tok nt; nt.ac = aw.ac; nt.lm = aw.lm; nt.bp = (uint32_t) (arenaOff + pos);
+              const int xo = G.xoff[bc.dst];
+              TokA na; na.ac = aw.ac; na.lm = aw.lm; na.bp = (uint32_t) (arenaOff + pos); na.xs = (uint32_t) xo;
+              TokB nb; nb.node = bc.dst; nb.cnt = G.xoff[bc.dst + 1] - xo;
               Bp bp;
               if (mode == 0) {
-                nt.node = bc.dst | ((bw.rec & 0x40000000) ? (int) 0x80000000 : 0);
+                if (bw.rec & 0x40000000) na.xs |= 0x80000000u;
                 bp.prev = bw.prevBp; bp.rec = (uint32_t) recW;
               } else {
-                nt.node = bc.dst;
                 if (bw.rec == (int) 0x7FFFFFFE) { const Bp o = arena[bw.prevBp]; bp = o; }     // replaces the token in its chain
                 else { bp.prev = bw.prevBp; bp.rec = (uint32_t) bw.rec; }
               }
-              nxt[pos] = nt; arena[arenaOff + pos] = bp;
+              nxtA[pos] = na; nxtB[pos] = nb; arena[arenaOff + pos] = bp;
             }
           }
         }
       }
+      }   // memory path
       __syncthreads();
+      TICK(fast ? 7 : 8);
       if (mode == 0) {
         if (dump) {
           long* cnt = Dd.dumpCount; const long o = cnt[0];
           if (o + numNew <= Dd.dumpCap) {
             for (int i = tid; i < numNew; i += nthr) {
-              const Tok t = nxt[i]; Dd.dumpNode[o + i] = t.node & 0x7FFFFFFF; Dd.dumpAc[o + i] = t.ac; Dd.dumpLm[o + i] = t.lm;
+              const TokA t = nxtA[i]; Dd.dumpNode[o + i] = nxtB[i].node; Dd.dumpAc[o + i] = t.ac; Dd.dumpLm[o + i] = t.lm;
               Dd.dumpArc[o + i] = G.xarc[arena[t.bp].rec];
             }
           }
@@ -331,15 +679,16 @@ __global__ __launch_bounds__(kThreads) void k_viterbi(GraphDev G, DecDev Dd, con
           if (tid == 0) { Dd.dumpFrameOff[fr] = o; Dd.dumpFrameOff[fr + 1] = o + numNew; cnt[0] = o + numNew; cnt[1] = fr + 1; }
         }
         if (numNew == 0) { status = DSR_E_CONSISTENCY; break; }                // the reference never terminates from here
-        Tok* tmp = cur; cur = nxt; nxt = tmp; n = numNew; arenaOff += numNew;
+        { TokA* tmp = curA; curA = nxtA; nxtA = tmp; TokB* tmb = curB; curB = nxtB; nxtB = tmb; }
+        n = numNew; arenaOff += numNew;
         activeHypos += numNew; if (numNew > maxActive) maxActive = numNew;
         thresh = __dadd_rn(topScore, Dd.beam);
       } else {
         // ---------------- best token (decoder.h:639-685): list order, strict '<' on the float score
-        const Tok* lst = numNew > 0 ? nxt : cur; const int cntL = numNew > 0 ? numNew : n;
+        const TokA* lst = numNew > 0 ? nxtA : curA; const int cntL = numNew > 0 ? numNew : n;
         unsigned long long key = ~0ull;
         for (int i = tid; i < cntL; i += nthr) {
-          const Tok t = lst[i]; const float s = __fadd_rn(t.ac, t.lm);
+          const TokA t = lst[i]; const float s = __fadd_rn(t.ac, t.lm);
           if (s == s) { const unsigned long long k = ((unsigned long long) f2ord(s) << 32) | (unsigned) i; if (k < key) key = k; }
         }
         key = wave_min_u64(key);
@@ -348,9 +697,9 @@ __global__ __launch_bounds__(kThreads) void k_viterbi(GraphDev G, DecDev Dd, con
         if (tid == 0) {
           unsigned long long k = ~0ull; for (int w = 0; w < nw; w++) if (s_waveKey[w] < k) k = s_waveKey[w];
           dsr_decode_result r; memset(&r, 0, sizeof(r));
-          r.frames = T - 1; r.reachedFinal = numNew > 0 ? 1 : 0; r.activeHypos = activeHypos; r.placements = placements; r.maxActiveSeen = maxActive; r.status = DSR_OK;
+          r.frames = T - 1; r.reachedFinal = numNew > 0 ? 1 : 0; r.activeHypos = activeHypos; r.placements = placements; r.registerFrames = regFrames; r.maxActiveSeen = maxActive; r.status = DSR_OK;
           if (k != ~0ull) {
-            const Tok bt = lst[(unsigned) (k & 0xFFFFFFFFu)];
+            const TokA bt = lst[(unsigned) (k & 0xFFFFFFFFu)];
             r.ac = bt.ac; r.lm = bt.lm; r.score = __dadd_rn((double) bt.ac, (double) bt.lm);
             // traceback (bestHypo, decoder.h:748-773): count, then fill first..last
             int nA = 0;
@@ -392,6 +741,8 @@ __global__ __launch_bounds__(kThreads) void k_viterbi(GraphDev G, DecDev Dd, con
     }
   }
   if (tid == 0) Dd.tags[slot] = tag;
+  if (Dd.prof && tid < 16) Dd.prof[slot * 16 + tid] = s_prof[tid];
+#undef TICK
 }
 
 struct DecoderState {
@@ -399,8 +750,8 @@ struct DecoderState {
   WfstGraph::Csr csr; WfstGraph::Tables tab;
   DevBuf<int> d_xoff, d_xarc, d_xpathOff, d_eoff, d_path, d_nodeFinal, d_queue;
   DevBuf<XRec> d_xrec; DevBuf<ERec> d_erec; DevBuf<float> d_arcCost, d_nodeCost; DevBuf<uint32_t> d_arcOut, d_arcIn;
-  DevBuf<Tok> d_tok; DevBuf<int> d_tokOff, d_tokCnt, d_owner, d_rank, d_chead; DevBuf<unsigned> d_tags; DevBuf<CandA> d_cA; DevBuf<CandB> d_cB; DevBuf<unsigned> d_first; DevBuf<Bp> d_arena;
-  DevBuf<dsr_decode_result> d_res; DevBuf<int> d_arcs; DevBuf<unsigned> d_words;
+  DevBuf<TokA> d_tokA, d_ctok; DevBuf<TokB> d_tokB; DevBuf<Side> d_side; DevBuf<XRecD> d_xrecD; int fastOK = 0; DevBuf<int> d_tokOff, d_tokCnt, d_owner, d_rank, d_chead; DevBuf<unsigned> d_tags; DevBuf<CandA> d_cA; DevBuf<CandB> d_cB; DevBuf<unsigned> d_first; DevBuf<Bp> d_arena;
+  DevBuf<long long> d_prof; DevBuf<dsr_decode_result> d_res; DevBuf<int> d_arcs; DevBuf<unsigned> d_words;
   long arenaCap = 0; int initial = 0; int threads = kThreads;
   // dump
   int dumpOn = 0; long dumpCap = 0; DevBuf<long> d_dumpFrameOff, d_dumpCount; DevBuf<int> d_dumpNode, d_dumpArc; DevBuf<float> d_dumpAc, d_dumpLm;
@@ -448,10 +799,10 @@ dsr_status dsr_decoder_create(const dsr_decoder_cfg* cfg, dsr_decoder** out)
     if (d->cfg.maxActive <= 0) d->cfg.maxActive = 65536;
     if (d->cfg.maxCandidates <= 0) d->cfg.maxCandidates = 8 * d->cfg.maxActive;
     if (d->cfg.maxCandidates >= (1 << 24)) throw Error(DSR_E_PARAMETER, "maxCandidates must be < 2^24");
-    if (const char* e = getenv("DSR_VITERBI_THREADS")) { const int t = atoi(e); if (t == 256 || t == 512 || t == 1024) d->threads = t; }
+    if (const char* e = getenv("DSR_VITERBI_THREADS")) { const int t = atoi(e); if (t == 256 || t == 512) d->threads = t; }
     if (d->cfg.streams <= 0) {
       hipDeviceProp_t prop; int dev = 0; DSR_HIP(hipGetDevice(&dev)); DSR_HIP(hipGetDeviceProperties(&prop, dev));
-      d->cfg.streams = prop.multiProcessorCount * (kThreads / d->threads);
+      d->cfg.streams = prop.multiProcessorCount;
       if (const char* e = getenv("DSR_VITERBI_SLOTS")) { const int t = atoi(e); if (t > 0) d->cfg.streams = t; }
     }
     *out = d;
@@ -471,6 +822,20 @@ dsr_status dsr_decoder_set(dsr_decoder* d, const dsr_wfst* g)
     d->d_xoff.upload(d->tab.xoff); d->d_eoff.upload(d->tab.eoff); d->d_path.upload(d->tab.path);
     if (d->tab.xrec.empty()) throw Error(DSR_E_CONSISTENCY, "the transducer has no emitting arcs");
     d->d_xrec.upload(d->tab.xrec); d->d_xarc.upload(d->tab.xarc); d->d_xpathOff.upload(d->tab.xpathOff);
+    {
+      // expansion records with the destination's own expansion range folded in (the register path never reads xoff)
+      const size_t nx = d->tab.xrec.size(); std::vector<XRecD> xd(nx); int maxCnt = 0;
+      for (size_t r = 0; r < nx; r++) {
+        const XRec& x = d->tab.xrec[r]; XRecD& o = xd[r];
+        o.dst = x.dst; o.dist = x.dist; o.cost = x.cost; o.meta = x.meta; o.dstXoff = d->tab.xoff[x.dst]; o.dstCnt = d->tab.xoff[x.dst + 1] - d->tab.xoff[x.dst];
+        o.pathOff = d->tab.xpathOff[r]; o.eps1 = 0.0f;
+        if (x.meta & 0xFFFFu) { const int a0 = d->tab.path[o.pathOff]; o.eps1 = d->csr.cost[a0]; if (d->csr.out[a0] != 0) o.meta |= 0x20000u; }
+        if (o.dstCnt > maxCnt) maxCnt = o.dstCnt;
+      }
+      d->d_xrecD.upload(xd);
+      d->fastOK = (maxCnt < (1 << 19) && nx < ((size_t) 1 << 30)) ? 1 : 0;
+      if (getenv("DSR_VITERBI_NOFAST")) d->fastOK = 0;
+    }
     { std::vector<ERec> e = d->tab.erec; if (e.empty()) e.push_back(ERec{0, 0, 0, 0}); d->d_erec.upload(e); }
     d->d_arcCost.upload(d->csr.cost); d->d_arcOut.upload(d->csr.out); d->d_arcIn.upload(d->csr.in);
     d->d_nodeFinal.upload(nf); d->d_nodeCost.upload(nc);
@@ -490,7 +855,8 @@ static void ensure_scratch(dsr_decoder* d, int slots, int Tmax)
   if (slots < d->nSlots) slots = d->nSlots;
   if (arena < d->arenaCap) arena = d->arenaCap;
   const size_t S = (size_t) slots;
-  d->d_tok.reserve(S * 2 * c.maxActive); d->d_tokOff.reserve(S * (c.maxActive + 1));
+  d->d_tokA.reserve(S * 2 * c.maxActive); d->d_tokB.reserve(S * 2 * c.maxActive); d->d_ctok.reserve(S * 8192); d->d_side.reserve(S * kFastC);
+  d->d_tokOff.reserve(S * (c.maxActive + 1));
   d->d_owner.reserve(S * c.maxCandidates); d->d_rank.reserve(S * c.maxCandidates);
   d->d_cA.reserve(S * c.maxCandidates); d->d_cB.reserve(S * c.maxCandidates);
   d->d_first.reserve(S * d->nNodes); d->d_tokCnt.reserve(S * (c.maxActive + 1)); d->d_chead.reserve(S * c.maxCandidates);
@@ -522,20 +888,27 @@ dsr_status dsr_decoder_decode_batch(dsr_decoder* d, const float* score, const in
       d->d_dumpNode.reserve(d->dumpCap); d->d_dumpArc.reserve(d->dumpCap); d->d_dumpAc.reserve(d->dumpCap); d->d_dumpLm.reserve(d->dumpCap);
       DSR_HIP(hipMemsetAsync(d->d_dumpCount.p, 0, 2 * sizeof(long), st));
     }
-    GraphDev G; G.nNodes = d->nNodes; G.initial = d->initial; G.xoff = d->d_xoff.p; G.xrec = d->d_xrec.p; G.xarc = d->d_xarc.p;
+    GraphDev G; G.nNodes = d->nNodes; G.initial = d->initial; G.xoff = d->d_xoff.p; G.xrec = d->d_xrec.p; G.xrecD = d->d_xrecD.p; G.xarc = d->d_xarc.p;
     G.xpathOff = d->d_xpathOff.p; G.eoff = d->d_eoff.p; G.erec = d->d_erec.p; G.path = d->d_path.p; G.arcCost = d->d_arcCost.p;
     G.arcOut = d->d_arcOut.p; G.arcIn = d->d_arcIn.p; G.nodeFinal = d->d_nodeFinal.p; G.nodeCost = d->d_nodeCost.p;
     DecDev D; D.beam = d->cfg.beam; D.lmScale = d->cfg.lmScale; D.lmPenalty = d->cfg.lmPenalty; D.silPenalty = d->cfg.silPenalty;
     D.silenceX = d->cfg.silenceX; D.maxTok = d->cfg.maxActive; D.maxCand = d->cfg.maxCandidates; D.arenaCap = d->arenaCap;
-    D.tok = d->d_tok.p; D.tokOff = d->d_tokOff.p; D.owner = d->d_owner.p; D.rank = d->d_rank.p; D.cA = d->d_cA.p; D.cB = d->d_cB.p;
+    D.tokA = d->d_tokA.p; D.tokB = d->d_tokB.p; D.ctok = d->d_ctok.p; D.side = d->d_side.p; D.fastOK = d->fastOK; D.tokOff = d->d_tokOff.p; D.owner = d->d_owner.p; D.rank = d->d_rank.p; D.cA = d->d_cA.p; D.cB = d->d_cB.p;
     D.first = d->d_first.p; D.tags = d->d_tags.p; D.tokCnt = d->d_tokCnt.p; D.chead = d->d_chead.p; D.arena = d->d_arena.p; D.queue = d->d_queue.p;
+    D.prof = nullptr;
+    if (getenv("DSR_VITERBI_PROF")) { d->d_prof.reserve((size_t) slots * 16); D.prof = d->d_prof.p; }
     D.dumpOn = d->dumpOn; D.dumpCap = d->dumpCap; D.dumpFrameOff = d->d_dumpFrameOff.p; D.dumpNode = d->d_dumpNode.p; D.dumpAc = d->d_dumpAc.p;
     D.dumpLm = d->d_dumpLm.p; D.dumpArc = d->d_dumpArc.p; D.dumpCount = d->d_dumpCount.p;
-    const int useLds = (size_t) nDist * sizeof(float) <= 64 * 1024;
+    // LDS: [score row][state table: 2 x hashN words][slot offsets of the expanding tokens]; the row stays in global memory
+    // when it would push the state table below the size the register path needs
+    const size_t eoffB = (size_t) kSideLds * sizeof(Side), ldsCap = 159 * 1024;      // slot offsets [kFastC + 2] u16, later the LDS side entries
+    static_assert((size_t) kSideLds * sizeof(Side) >= (size_t) (kFastE + 2) * sizeof(unsigned short), "side region must cover the slot offsets");
+    int useLds = (size_t) nDist * sizeof(float) <= 64 * 1024;
+    if (useLds && (size_t) ((nDist + 3) & ~3) * sizeof(float) + (size_t) 16384 * 8 + eoffB > ldsCap) useLds = 0;
     const size_t rowB = useLds ? (size_t) ((nDist + 3) & ~3) * sizeof(float) : 16;
-    int hashN = 16384; while (hashN > 0 && rowB + (size_t) hashN * 8 > 150 * 1024) hashN >>= 1;
+    int hashN = 16384; while (hashN > 0 && rowB + (size_t) hashN * 8 + eoffB > ldsCap) hashN >>= 1;
     if (getenv("DSR_VITERBI_NOHASH")) hashN = 0;
-    const size_t lds = rowB + (size_t) hashN * 8;
+    const size_t lds = rowB + (size_t) hashN * 8 + eoffB;
     DSR_HIP(hipFuncSetAttribute((const void*) k_viterbi, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
     hipLaunchKernelGGL(k_viterbi, dim3(slots), dim3(d->threads), lds, st, G, D, score, nframes, U, Tmax, nDist, d->d_res.p,
                        (arcs_out || words_out) ? d->d_arcs.p : nullptr, (arcs_out || words_out) ? d->d_words.p : nullptr, maxPath, useLds, hashN);
@@ -544,6 +917,13 @@ dsr_status dsr_decoder_decode_batch(dsr_decoder* d, const float* score, const in
     if (arcs_out) DSR_HIP(hipMemcpyAsync(arcs_out, d->d_arcs.p, sizeof(int) * (size_t) U * maxPath, hipMemcpyDeviceToHost, st));
     if (words_out) DSR_HIP(hipMemcpyAsync(words_out, d->d_words.p, sizeof(unsigned) * (size_t) U * maxPath, hipMemcpyDeviceToHost, st));
     DSR_HIP(hipStreamSynchronize(st));
+    if (D.prof) {
+      std::vector<long long> hp((size_t) slots * 16); DSR_HIP(hipMemcpy(hp.data(), D.prof, hp.size() * sizeof(long long), hipMemcpyDeviceToHost));
+      double acc[16] = {0}; for (int s2 = 0; s2 < slots; s2++) for (int i = 0; i < 16; i++) acc[i] += (double) hp[(size_t) s2 * 16 + i];
+      fprintf(stderr, "[dsr viterbi prof] mean us per slot:");
+      for (int i = 0; i < 15; i++) fprintf(stderr, " p%d=%.0f", i, acc[i] / slots / 100.0);
+      fprintf(stderr, "\n");
+    }
     if (d->dumpOn) {
       long cnt[2]; DSR_HIP(hipMemcpy(cnt, d->d_dumpCount.p, sizeof(cnt), hipMemcpyDeviceToHost));
       const long N = cnt[0] < d->dumpCap ? cnt[0] : d->dumpCap; d->h_dumpFrames = cnt[1];

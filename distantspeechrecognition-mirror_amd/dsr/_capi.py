@@ -44,7 +44,7 @@ class DecoderCfg(C.Structure):
 
 class DecodeResult(C.Structure):
     _fields_ = [("score", f64), ("ac", f32), ("lm", f32), ("frames", i32), ("reachedFinal", i32), ("nArcs", i32),
-                ("nWords", i32), ("status", i32), ("maxActiveSeen", i32), ("activeHypos", i64), ("placements", i64)]
+                ("nWords", i32), ("status", i32), ("maxActiveSeen", i32), ("activeHypos", i64), ("placements", i64), ("registerFrames", i64)]
 
 
 def load():
@@ -375,7 +375,7 @@ class Decoder:
             r = res[u]
             out.append(dict(status=r.status, score=r.score, ac=r.ac, lm=r.lm, frames=r.frames, reachedFinal=bool(r.reachedFinal),
                             arcs=arcs[u, :min(r.nArcs, maxPath)].copy(), words=words[u, :min(r.nWords, maxPath)].copy(),
-                            activeHypos=r.activeHypos, maxActive=r.maxActiveSeen, placements=r.placements))
+                            activeHypos=r.activeHypos, maxActive=r.maxActiveSeen, placements=r.placements, registerFrames=r.registerFrames))
         return out
 
     def get_dump(self):

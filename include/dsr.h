@@ -217,6 +217,7 @@ typedef struct {
   int32_t maxActiveSeen;
   int64_t activeHypos;  /* sum over frames of |_next| (decoder.h:413) */
   int64_t placements;   /* calls of _placeOnList over the utterance (expanded arcs incl. the end expansion) */
+  int64_t registerFrames; /* diagnostics: frames that ran on the decoder kernel's register path (rest: memory path) */
 } dsr_decode_result;
 /* Batched decode.  score_dev [U][Tmax][nDist] fp32 costs (row t = Distrib::score(t)), nframes_dev [U].
  * Host outputs: res[U]; arcs_out [U][maxPath] (export arc ids, first..last), words_out [U][maxPath]

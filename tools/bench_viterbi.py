@@ -12,7 +12,7 @@ from tests import synth
 ap = argparse.ArgumentParser()
 ap.add_argument("--utts", type=int, default=256); ap.add_argument("--frames", type=int, default=200)
 ap.add_argument("--streams", type=str, default="0"); ap.add_argument("--beam", type=float, default=0.0)
-ap.add_argument("--reps", type=int, default=2)
+ap.add_argument("--reps", type=int, default=2); ap.add_argument("--check", action="store_true", help="compare against the memory path (DSR_VITERBI_NOFAST)")
 a = ap.parse_args()
 dsr.load(); dev = torch.device("cuda:0")
 arcs, fin = synth.random_wfst(50000, 1024, seed=21, outdeg=4, eps_frac=0.1, out_frac=0.05, nWords=5000, nFinal=50)
@@ -38,6 +38,22 @@ for st in [int(s) for s in a.streams.split(",")]:
     torch.cuda.synchronize(); dt = (time.time() - t0) / a.reps
     act = np.mean([o["activeHypos"] / a.frames for o in out]); pl = np.mean([o["placements"] / a.frames for o in out])
     bad = sum(1 for o in out if o["status"] not in (0, 5))
+    print("register-path frames: %.1f%%; statuses %s" % (100.0 * sum(o["registerFrames"] for o in out) / (a.frames * len(out)), sorted(set(o["status"] for o in out))))
     print("streams=%d utts=%d frames=%d: %.1f ms/batch, %.1f us/frame/slot-round, active %.0f placements/frame %.0f failed %d" %
           (st, a.utts, a.frames, dt * 1e3, dt * 1e6 / a.frames / max(1, -(-a.utts // (st if st else 256))), act, pl, bad), flush=True)
+    if a.check:
+        os.environ["DSR_VITERBI_NOFAST"] = "1"
+        dec2 = dsr.Decoder(beam=a.beam, lmScale=12.0, maxActive=65536, streams=st); dec2.set(g)
+        del os.environ["DSR_VITERBI_NOFAST"]
+        ref = dec2.decode_batch(sc, maxPath=16)
+        torch.cuda.synchronize(); t0 = time.time(); ref = dec2.decode_batch(sc, maxPath=16); torch.cuda.synchronize()
+        print("memory path: %.1f ms/batch" % ((time.time() - t0) * 1e3))
+        keys = ["score", "ac", "lm", "status", "activeHypos", "placements", "maxActive", "reachedFinal", "frames"]
+        nbad = 0
+        for i, (x, y) in enumerate(zip(out, ref)):
+            d = [k for k in keys if x[k] != y[k]]
+            if d or not np.array_equal(x["arcs"], y["arcs"]) or not np.array_equal(x["words"], y["words"]):
+                nbad += 1
+                if nbad <= 5: print("utt %d differs:" % i, {k: (x[k], y[k]) for k in d})
+        print("register path vs memory path: %d of %d utterances differ" % (nbad, len(out)))
     del dec
