@@ -44,7 +44,8 @@ static constexpr uint32_t kEndBit = 0x80000000u;
 static constexpr int kThreads = 512;              // 8 waves: 256 VGPRs per thread for the register path
 static constexpr int kWaves = kThreads / 64;
 static constexpr int kFastK = 16;                  // placements a thread keeps in registers on the register path
-static constexpr int kFastC = 12288;               // most placements per frame on the register path (8 more per thread are parked in memory)
+static constexpr int kFastC = 24576;               // most placements per frame on the register path (those beyond kFastK per thread are parked in memory)
+static constexpr int kTableC = 12288;              // most placements the LDS state table takes at once; above, the states are split in two passes
 static constexpr int kFastE = 8190;                // most expanding tokens per frame on the register path
 static constexpr int kP1 = 32;                     // token rounds per wave in the register path's beam pass
 static constexpr int kSideLds = 528;               // later arrivals kept in LDS (the region also holds the slot offsets, dead by then)               // most placements / expanding tokens per frame on the register path
@@ -72,10 +73,16 @@ __device__ __forceinline__ int ld_i32(const int* p) { return __hip_atomic_load(p
 __device__ __forceinline__ void st_u32(unsigned* p, unsigned v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void st_i32(int* p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
-__device__ __forceinline__ int wave_incl_scan(int v, int lane)
+// inclusive prefix sum over the wave: four row shifts inside every 16-lane row, then the row totals are handed on
+// (row_bcast:15 into rows 1 and 3, row_bcast:31 into rows 2 and 3) -- six DPP adds, no LDS round trips
+__device__ __forceinline__ int wave_incl_scan(int v, int /*lane*/)
 {
-#pragma unroll
-  for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(v, d, 64); if (lane >= d) v += o; }
+  v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xF, 0xF, true);      // row_shr:1
+  v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xF, 0xF, true);      // row_shr:2
+  v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xF, 0xF, true);      // row_shr:4
+  v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xF, 0xF, true);      // row_shr:8
+  v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xA, 0xF, false);     // row_bcast:15 -> rows 1, 3
+  v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xC, 0xF, false);     // row_bcast:31 -> rows 2, 3
   return v;
 }
 __device__ __forceinline__ double wave_min_d(double v)
@@ -124,7 +131,8 @@ __global__ __launch_bounds__(kThreads) void k_viterbi(GraphDev G, DecDev Dd, con
   __shared__ int s_sideN;
   __shared__ unsigned s_bm[kFastC / 32];             // register path: slots where an expanding token's run starts
   __shared__ unsigned short s_gbase[kFastC / 64 + 4]; // register path: expanding tokens that start before each group of 64 slots
-  __shared__ int s_cnt[(kFastK + 8) * kWaves];             // register path: first arrivals per (k, wave) group, then their exclusive prefix
+  __shared__ int s_cnt[(kFastK + 32) * kWaves];
+  __shared__ int s_err;             // register path: first arrivals per (k, wave) group, then their exclusive prefix
   __shared__ long long s_prof[16]; __shared__ long long s_tlast;
   if (threadIdx.x < 16) s_prof[threadIdx.x] = 0;
 #define TICK(ix) do { if (Dd.prof && tid == 0) { const long long tn = (long long) wall_clock64(); s_prof[ix] += tn - s_tlast; s_tlast = tn; } } while (0)
@@ -148,8 +156,7 @@ __global__ __launch_bounds__(kThreads) void k_viterbi(GraphDev G, DecDev Dd, con
   // needs resetting; the table is wiped when the 8-bit tag runs out (and on the very first use of a slot)
   unsigned tag = Dd.tags[slot];
   Bp* arena = Dd.arena + (size_t) slot * Dd.arenaCap;
-  const int fastCapC0 = ((kFastK + 8) * nthr < kFastC) ? (kFastK + 8) * nthr : kFastC;
-  const int fastCapC = (fastCapC0 < (hashN >> 1) + (hashN >> 2)) ? fastCapC0 : (hashN >> 1) + (hashN >> 2);   // table load <= 0.75
+  const int fastCapC = ((kFastK + 32) * nthr < kFastC) ? (kFastK + 32) * nthr : kFastC;
   const int fastCapN = kP1 * 64 * nw;                                   // kP1 rounds of 64 tokens per wave
   const bool fastOK = Dd.fastOK && hashN >= 16384;
 
@@ -159,6 +166,7 @@ __global__ __launch_bounds__(kThreads) void k_viterbi(GraphDev G, DecDev Dd, con
     __syncthreads();
     const int u = s_u;
     if (u >= U) break;
+    if (Dd.prof && tid == 0) { const long long tn = (long long) wall_clock64(); if (s_prof[15]) s_prof[10] += tn - s_prof[15]; s_tlast = tn; }
     const int T = nframesArr[u] < Tmax ? nframesArr[u] : Tmax;
     const float* sc = scores + (size_t) u * Tmax * nDist;
     const bool dump = Dd.dumpOn && slot == 0;
@@ -176,11 +184,12 @@ __global__ __launch_bounds__(kThreads) void k_viterbi(GraphDev G, DecDev Dd, con
     }
     __syncthreads();
 
+    TICK(11);
     // frames 0..T-1 (mode 0), then the end expansion (mode 1)
     for (int fr = 0; fr <= T && status == DSR_OK; fr++) {
       const int mode = (fr == T) ? 1 : 0;
       if (mode == 0 && useLdsRow) { for (int i = tid; i < nDist; i += nthr) srow[i] = sc[(size_t) fr * nDist + i]; }
-      const float* row = useLdsRow ? srow : (sc + (size_t) fr * nDist);
+      const float* rowG = sc + (size_t) fr * nDist;                            // the frame's score row in memory
       int numNew = 0;
       if (Dd.prof && tid == 0) s_tlast = (long long) wall_clock64();
       bool fast = fastOK && mode == 0 && n <= fastCapN;
@@ -190,7 +199,7 @@ __global__ __launch_bounds__(kThreads) void k_viterbi(GraphDev G, DecDev Dd, con
         // ---- P1: beam test, per-wave exclusive scans of the placement counts and of the expanding tokens.
         // Token loads are issued eight at a time (straight-line, clamped indices) so their latencies overlap.
         const int chunkT = ((n + nw * 64 - 1) / (nw * 64)) * 64;
-        float psc[kP1]; int pcn[kP1]; unsigned pk[kP1];                        // score; expansion count; slot offset | token index << 14 | bit31: expands
+        float psc[kP1]; int pcn[kP1]; unsigned pk[kP1];                        // score; expansion count; slot offset | token index << 15 | bit31: expands
         int runC = 0, runE = 0;
         {
           const int b0 = wave * chunkT, b1 = (b0 + chunkT < n) ? b0 + chunkT : n;
@@ -220,12 +229,12 @@ __global__ __launch_bounds__(kThreads) void k_viterbi(GraphDev G, DecDev Dd, con
               pcn[it] = cnt;
               const int incl = wave_incl_scan(cnt, lane);
               const unsigned long long bal = __ballot(cnt > 0);
-              if (cnt > 0) pk[it] = 0x80000000u | (unsigned) ((runC + incl - cnt) & 0x3FFF) | ((unsigned) ((runE + __popcll(bal & ((1ull << lane) - 1ull))) & 0x1FFFF) << 14);
+              if (cnt > 0) pk[it] = 0x80000000u | (unsigned) ((runC + incl - cnt) & 0x7FFF) | ((unsigned) ((runE + __popcll(bal & ((1ull << lane) - 1ull))) & 0xFFFF) << 15);
               runC += __shfl(incl, 63, 64); runE += __popcll(bal);
             }
           }
           if (lane == 0) { s_waveTot[wave] = runC; s_waveTotE[wave] = runE; }
-          if (tid == 0) { s_sideN = 0; s_gbase[0] = 0; }
+          if (tid == 0) { s_sideN = 0; s_gbase[0] = 0; s_err = 0; }
         }
         __syncthreads();
         TICK(0);
@@ -239,7 +248,7 @@ __global__ __launch_bounds__(kThreads) void k_viterbi(GraphDev G, DecDev Dd, con
           // into a population count
 #pragma unroll
           for (int it = 0; it < kP1; it++) if (pk[it] & 0x80000000u) {
-            const int e = ebase + (int) ((pk[it] >> 14) & 0x1FFFFu); const int off = cbase + (int) (pk[it] & 0x3FFFu);
+            const int e = ebase + (int) ((pk[it] >> 15) & 0xFFFFu); const int off = cbase + (int) (pk[it] & 0x7FFFu);
             eoff[e] = (unsigned short) off;
             ctok[e] = curA[wave * chunkT + it * 64 + lane];
             atomicOr(&s_bm[off >> 5], 1u << (off & 31));
@@ -264,6 +273,19 @@ __global__ __launch_bounds__(kThreads) void k_viterbi(GraphDev G, DecDev Dd, con
 #pragma unroll
           for (int k = 0; k < kFastK; k++) { qac[k] = 0.0f; qlm[k] = 0.0f; qrec[k] = 0; ek[k] = 0u; }
 
+          const int nPass = (C > kTableC) ? 2 : 1;
+          auto table_insert = [&](const unsigned dst, const unsigned prod, const int c) __attribute__((always_inline)) -> unsigned {
+            const unsigned key = dst + 1u;
+            unsigned h = (prod >> 7) & (unsigned) (hashN - 1); int probes = 0;
+            for (;;) {
+              const unsigned kk = atomicCAS(&hkey[h], 0u, key);
+              if (kk == 0u || kk == key) break;
+              h = (h + 1u) & (unsigned) (hashN - 1);
+              if (++probes > hashN) { s_err = 1; break; }                      // table full: cannot happen below its capacity; fail loudly, never spin
+            }
+            atomicMin(&hfirst[h], (unsigned) c);
+            return h;
+          };
           auto expand8 = [&](const int g8, float* ac8, float* lm8, int* rec8, unsigned* ek8) __attribute__((always_inline)) {
             int4 xr[8]; int xd[8]; bool tsil[8];
 #pragma unroll
@@ -316,30 +338,34 @@ __global__ __launch_bounds__(kThreads) void k_viterbi(GraphDev G, DecDev Dd, con
                 if (xmeta & 0x10000u) lm = __dadd_rn(lm, __dmul_rn(Dd.lmScale, Dd.lmPenalty));
                 const bool silArc = ((uint32_t) (xdist + 1) == Dd.silenceX);
                 if (silArc && (prevNull || prevIn != Dd.silenceX)) lm = __dadd_rn(lm, __dmul_rn(Dd.lmScale, Dd.silPenalty));
-                const double ac = __dadd_rn((double) ac8[i], (double) row[xdist]);
+                const double ac = __dadd_rn((double) ac8[i], (double) (useLdsRow ? srow[xdist] : rowG[xdist]));
                 const double ttl = __dadd_rn(ac, lm);
                 ttlS[c] = ttl; ac8[i] = (float) ac; lm8[i] = (float) lm; rec8[i] |= (silArc ? 0x40000000 : 0);
                 if (ttl < locMin) locMin = ttl;                                // _topScore
-                // state table: claim the bucket, keep the smallest slot
-                const unsigned key = (unsigned) xd[i] + 1u;
-                unsigned h = ((unsigned) xd[i] * 2654435761u) >> 7 & (unsigned) (hashN - 1);
-                for (;;) {
-                  const unsigned kk = atomicCAS(&hkey[h], 0u, key);
-                  if (kk == 0u || kk == key) break;
-                  h = (h + 1u) & (unsigned) (hashN - 1);
-                }
-                atomicMin(&hfirst[h], (unsigned) c);
-                ek8[i] |= h << 13;
+                // state table: claim the bucket, keep the smallest slot (with two passes, the other half of the states waits)
+                const unsigned prod = (unsigned) xd[i] * 2654435761u;
+                if (nPass > 1 && (prod >> 31)) ek8[i] |= 1u << 27;
+                else ek8[i] |= (table_insert((unsigned) xd[i], prod, c) << 13) | (1u << 28);      // bit28: in the table, not folded yet
               }
             }
           };
           expand8(0, &qac[0], &qlm[0], &qrec[0], &ek[0]);
           if (K > 8) expand8(8, &qac[8], &qlm[8], &qrec[8], &ek[8]);
-          if (K > kFastK) {
-            float oac[8], olm[8]; int orec[8]; unsigned oek[8];
-            expand8(kFastK, oac, olm, orec, oek);
+          auto park_store = [&](const int kb, const float* oac, const float* olm, const int* orec, const unsigned* oek) __attribute__((always_inline)) {
 #pragma unroll
-            for (int i = 0; i < 8; i++) { const int c = (kFastK + i) * nthr + tq; if (c < C) ovf[c - kFastK * nthr] = make_uint4(__float_as_uint(oac[i]), __float_as_uint(olm[i]), (unsigned) orec[i], oek[i]); }
+            for (int i = 0; i < 8; i++) { const int c = (kb + i) * nthr + tq; if (c < C) ovf[c - kFastK * nthr] = make_uint4(__float_as_uint(oac[i]), __float_as_uint(olm[i]), (unsigned) orec[i], oek[i]); }
+          };
+          auto park_load = [&](const int kb, float* oac, float* olm, int* orec, unsigned* oek) __attribute__((always_inline)) {
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+              int c = (kb + i) * nthr + tq; c = (c < C) ? c : kFastK * nthr;                // K > kFastK: that slot exists
+              const uint4 v = ovf[c - kFastK * nthr];
+              oac[i] = __uint_as_float(v.x); olm[i] = __uint_as_float(v.y); orec[i] = (int) v.z; oek[i] = v.w;
+            }
+          };
+          for (int kb = kFastK; kb < K; kb += 8) {
+            float oac[8], olm[8]; int orec[8]; unsigned oek[8];
+            expand8(kb, oac, olm, orec, oek); park_store(kb, oac, olm, orec, oek);
           }
           TICK(2);
           locMin = wave_min_d(locMin);
@@ -350,9 +376,10 @@ __global__ __launch_bounds__(kThreads) void k_viterbi(GraphDev G, DecDev Dd, con
           topScore = HUGE_VAL;
           for (int w = 0; w < nw; w++) { const double v = s_waveMin[w]; if (v < topScore) topScore = v; }
           topScore = uni(topScore);
-          // ---- P4: later arrivals hang themselves on their bucket (the key word becomes the chain head)
-          unsigned firstMask = 0u;
-          auto later8 = [&](const int g8, const float* ac8, const float* lm8, const int* rec8, const unsigned* ek8) __attribute__((always_inline)) {
+          // ---- P4/P5, once per pass over the state table: later arrivals hang themselves on their bucket (the key word becomes
+          // the chain head), then every first arrival folds its chain in slot order (decoder.h:519-528)
+          unsigned long long firstMask = 0ull;
+          auto later8 = [&](const int g8, const int pass, const float* ac8, const float* lm8, const int* rec8, const unsigned* ek8) __attribute__((always_inline)) {
             double tt[8]; uint32_t pb[8];
 #pragma unroll
             for (int i = 0; i < 8; i++) {                                      // what a later arrival hands over; loaded for all (coalesced, in flight together)
@@ -362,9 +389,9 @@ __global__ __launch_bounds__(kThreads) void k_viterbi(GraphDev G, DecDev Dd, con
 #pragma unroll
             for (int i = 0; i < 8; i++) {
               const int c = (g8 + i) * nthr + tq;
-              if (c < C) {
-                const unsigned h = ek8[i] >> 13;
-                if (hfirst[h] == (unsigned) c) firstMask |= 1u << (g8 + i);
+              if (c < C && (ek8[i] & (1u << 28)) && (int) ((ek8[i] >> 27) & 1u) == pass && !((firstMask >> (g8 + i)) & 1ull)) {
+                const unsigned h = (ek8[i] >> 13) & 0x3FFFu;
+                if (hfirst[h] == (unsigned) c) firstMask |= 1ull << (g8 + i);
                 else {
                   const int sx = atomicAdd(&s_sideN, 1);
                   const unsigned nx = atomicExch(&hkey[h], 0x80000000u | (unsigned) sx);
@@ -374,27 +401,20 @@ __global__ __launch_bounds__(kThreads) void k_viterbi(GraphDev G, DecDev Dd, con
               }
             }
           };
-          auto park_load = [&](float* oac, float* olm, int* orec, unsigned* oek) __attribute__((always_inline)) {
-#pragma unroll
-            for (int i = 0; i < 8; i++) {
-              int c = (kFastK + i) * nthr + tq; c = (c < C) ? c : kFastK * nthr;          // K > kFastK: that slot exists
-              const uint4 v = ovf[c - kFastK * nthr];
-              oac[i] = __uint_as_float(v.x); olm[i] = __uint_as_float(v.y); orec[i] = (int) v.z; oek[i] = v.w;
-            }
-          };
-          later8(0, &qac[0], &qlm[0], &qrec[0], &ek[0]);
-          if (K > 8) later8(8, &qac[8], &qlm[8], &qrec[8], &ek[8]);
-          if (K > kFastK) { float oac[8], olm[8]; int orec[8]; unsigned oek[8]; park_load(oac, olm, orec, oek); later8(kFastK, oac, olm, orec, oek); }
-          __syncthreads();
-          TICK(5);
-          // ---- P5: fold the later arrivals of every first arrival in slot order (decoder.h:519-528); count the new tokens
-          auto fold1 = [&](const int k, float& ac, float& lm, int& rec, unsigned& ekk) __attribute__((always_inline)) {
-            const bool isFirst = (firstMask >> k) & 1u;
-            if (isFirst) {
-              const unsigned head = hkey[ekk >> 13];
+          // (a first arrival that has been folded carries neither bucket nor pass bit any more: ek = token index, or bit31 | side index)
+          auto fold1 = [&](const int k, const int pass, float& ac, float& lm, int& rec, unsigned& ekk) __attribute__((always_inline)) {
+            const bool mine = ((firstMask >> k) & 1ull) && !(ekk & 0x80000000u) && (ekk & (1u << 28)) && (int) ((ekk >> 27) & 1u) == pass;
+            if (mine) {
+              const unsigned head = hkey[(ekk >> 13) & 0x3FFFu];
               ekk &= 0x1FFFu;
               if (head & 0x80000000u) {
                 int wslot = k * nthr + tq, wIdx = -1; double fw = (double) __fadd_rn(ac, lm);
+                const int hi = (int) (head & 0x7FFFFFFFu);
+                const unsigned hnext = (hi < kSideLds) ? sideL[hi].next : side[hi].next;
+                if (!(hnext & 0x80000000u)) {                                  // one later arrival (the usual case): a single comparison
+                  const double pt = (hi < kSideLds) ? sideL[hi].ttl : side[hi].ttl;
+                  if (pt < fw) wIdx = hi;
+                } else
                 for (;;) {                                                     // next replacement = smallest later slot that beats the incumbent
                   int best = 0x7FFFFFFF, bi = -1, steps = 0;
                   for (unsigned p = head; (p & 0x80000000u) && steps <= C; steps++) {
@@ -415,28 +435,61 @@ __global__ __launch_bounds__(kThreads) void k_viterbi(GraphDev G, DecDev Dd, con
                 }
               }
             }
-            const unsigned long long bal = __ballot(isFirst);
-            if (lq == 0) s_cnt[k * nw + wq] = __popcll(bal);
           };
+          // second pass: the waiting half of the states enters the (wiped) table
+          auto insert8 = [&](const int g8, const int* rec8, unsigned* ek8) __attribute__((always_inline)) {
+            int xd[8];
 #pragma unroll
-          for (int k = 0; k < kFastK; k++) if (k < K) fold1(k, qac[k], qlm[k], qrec[k], ek[k]);
-          if (K > kFastK) {
-            float oac[8], olm[8]; int orec[8]; unsigned oek[8]; park_load(oac, olm, orec, oek);
+            for (int i = 0; i < 8; i++) xd[i] = G.xrecD[rec8[i] & 0x3FFFFFFF].dst;
 #pragma unroll
-            for (int i = 0; i < 8; i++) if (kFastK + i < K) {
-              fold1(kFastK + i, oac[i], olm[i], orec[i], oek[i]);
-              const int c = (kFastK + i) * nthr + tq; if (c < C) ovf[c - kFastK * nthr] = make_uint4(__float_as_uint(oac[i]), __float_as_uint(olm[i]), (unsigned) orec[i], oek[i]);
+            for (int i = 0; i < 8; i++) {
+              const int c = (g8 + i) * nthr + tq;
+              if (c < C && (ek8[i] & (1u << 27)) && !(ek8[i] & 0x80000000u)) ek8[i] |= (table_insert((unsigned) xd[i], (unsigned) xd[i] * 2654435761u, c) << 13) | (1u << 28);
+            }
+          };
+          for (int pass = 0; pass < nPass; pass++) {
+            if (pass > 0) {
+              __syncthreads();                                                 // every chain of the pass before has been folded
+              { uint4* h4 = reinterpret_cast<uint4*>(hkey); const int q4 = hashN >> 2;
+                for (int i = tq; i < 2 * q4; i += nthr) h4[i] = (i < q4) ? make_uint4(0u, 0u, 0u, 0u) : make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu); }
+              __syncthreads();
+              insert8(0, &qrec[0], &ek[0]);
+              if (K > 8) insert8(8, &qrec[8], &ek[8]);
+              for (int kb = kFastK; kb < K; kb += 8) {
+                float oac[8], olm[8]; int orec[8]; unsigned oek[8]; park_load(kb, oac, olm, orec, oek);
+                insert8(kb, orec, oek); park_store(kb, oac, olm, orec, oek);
+              }
+              __syncthreads();
+            }
+            later8(0, pass, &qac[0], &qlm[0], &qrec[0], &ek[0]);
+            if (K > 8) later8(8, pass, &qac[8], &qlm[8], &qrec[8], &ek[8]);
+            for (int kb = kFastK; kb < K; kb += 8) { float oac[8], olm[8]; int orec[8]; unsigned oek[8]; park_load(kb, oac, olm, orec, oek); later8(kb, pass, oac, olm, orec, oek); }
+            __syncthreads();
+            if (pass == 0) TICK(5);
+#pragma unroll
+            for (int k = 0; k < kFastK; k++) if (k < K) fold1(k, pass, qac[k], qlm[k], qrec[k], ek[k]);
+            for (int kb = kFastK; kb < K; kb += 8) {
+              float oac[8], olm[8]; int orec[8]; unsigned oek[8]; park_load(kb, oac, olm, orec, oek);
+#pragma unroll
+              for (int i = 0; i < 8; i++) if (kb + i < K) fold1(kb + i, pass, oac[i], olm[i], orec[i], oek[i]);
+              park_store(kb, oac, olm, orec, oek);
             }
           }
+          if (s_err) { status = DSR_E_ALLOCATION; break; }                     // (uniform: written before the barriers above)
+          // count the new tokens per (k, wave) group of 64 slots
+          for (int k = 0; k < K; k++) {
+            const unsigned long long bal = __ballot((firstMask >> k) & 1ull);
+            if (lq == 0) s_cnt[k * nw + wq] = __popcll(bal);
+          }
           __syncthreads();
-          if (wq == 0) {                                                     // exclusive prefix over (k, wq) = slot order of the groups
-            const int nG = K * nw;                                             // <= 4 * 64
-            int a[4], tot = 0;
+          if (wq == 0) {                                                       // exclusive prefix over (k, wave) = slot order of the groups
+            const int nG = K * nw;                                             // <= 6 * 64
+            int a[6], tot = 0;
 #pragma unroll
-            for (int q = 0; q < 4; q++) { a[q] = (4 * lq + q < nG) ? s_cnt[4 * lq + q] : 0; tot += a[q]; }
+            for (int q = 0; q < 6; q++) { a[q] = (6 * lq + q < nG) ? s_cnt[6 * lq + q] : 0; tot += a[q]; }
             const int incl = wave_incl_scan(tot, lq); int run = incl - tot;
 #pragma unroll
-            for (int q = 0; q < 4; q++) { if (4 * lq + q < nG) s_cnt[4 * lq + q] = run; run += a[q]; }
+            for (int q = 0; q < 6; q++) { if (6 * lq + q < nG) s_cnt[6 * lq + q] = run; run += a[q]; }
             if (lq == 63) s_waveTot[0] = incl;
           }
           __syncthreads();
@@ -458,7 +511,7 @@ __global__ __launch_bounds__(kThreads) void k_viterbi(GraphDev G, DecDev Dd, con
             for (int i = 0; i < 4; i++) {
               const int k = g4 + i;
               if (k < K) {
-                const bool isFirst = (firstMask >> k) & 1u;
+                const bool isFirst = (firstMask >> k) & 1ull;
                 const unsigned long long bal = __ballot(isFirst);
                 if (isFirst) {
                   const int pos = numNew - 1 - (s_cnt[k * nw + wq] + __popcll(bal & ((1ull << lq) - 1ull)));
@@ -472,10 +525,10 @@ __global__ __launch_bounds__(kThreads) void k_viterbi(GraphDev G, DecDev Dd, con
           };
 #pragma unroll
           for (int g4 = 0; g4 < kFastK; g4 += 4) if (g4 < K) write4(g4, &qac[g4], &qlm[g4], &qrec[g4], &ek[g4]);
-          if (K > kFastK) {
-            float oac[8], olm[8]; int orec[8]; unsigned oek[8]; park_load(oac, olm, orec, oek);
-            write4(kFastK, &oac[0], &olm[0], &orec[0], &oek[0]);
-            if (K > kFastK + 4) write4(kFastK + 4, &oac[4], &olm[4], &orec[4], &oek[4]);
+          for (int kb = kFastK; kb < K; kb += 8) {
+            float oac[8], olm[8]; int orec[8]; unsigned oek[8]; park_load(kb, oac, olm, orec, oek);
+            write4(kb, &oac[0], &olm[0], &orec[0], &oek[0]);
+            if (K > kb + 4) write4(kb + 4, &oac[4], &olm[4], &orec[4], &oek[4]);
           }
           {
             uint4* h4 = reinterpret_cast<uint4*>(hkey); const int q4 = hashN >> 2;
@@ -511,7 +564,6 @@ __global__ __launch_bounds__(kThreads) void k_viterbi(GraphDev G, DecDev Dd, con
       int C = 0;
       for (int w = 0; w < nw; w++) C += s_waveTot[w];
       if (C > Dd.maxCand) { status = DSR_E_ALLOCATION; break; }
-      if (Dd.prof && tid == 0 && mode == 0) s_prof[C <= 8192 ? 9 : C <= 10240 ? 10 : C <= 12288 ? 11 : C <= 16384 ? 12 : C <= 24576 ? 13 : 14] += 100;   // histogram of memory-path frames
       placements += C;
       const bool useHash = hashN > 0 && C <= (hashN >> 1) + (hashN >> 2);        // load factor <= 0.75 even if every placement is a new state
       // ---------------- phase A2: absolute offsets + owner fill
@@ -550,7 +602,7 @@ __global__ __launch_bounds__(kThreads) void k_viterbi(GraphDev G, DecDev Dd, con
           lm = __dadd_rn(lmNode, __dmul_rn(Dd.lmScale, (double) x.cost));
           if (x.meta & 0x10000u) lm = __dadd_rn(lm, __dmul_rn(Dd.lmScale, Dd.lmPenalty));
           if ((uint32_t) (x.dist + 1) == Dd.silenceX && (prevNull || prevIn != Dd.silenceX)) lm = __dadd_rn(lm, __dmul_rn(Dd.lmScale, Dd.silPenalty));
-          ac = __dadd_rn(ac, (double) row[x.dist]);
+          ac = __dadd_rn(ac, (double) (useLdsRow ? srow[x.dist] : rowG[x.dist]));
           dst = x.dst; silArc = ((uint32_t) (x.dist + 1) == Dd.silenceX);
         } else {
           const int hasSelf = G.nodeFinal[nd] ? 1 : 0;
@@ -732,9 +784,11 @@ __global__ __launch_bounds__(kThreads) void k_viterbi(GraphDev G, DecDev Dd, con
           res[u] = r;
         }
         __syncthreads();
+        TICK(9);
       }
     }   // frames
 
+    if (Dd.prof && tid == 0) s_prof[15] = (long long) wall_clock64();
     if (status != DSR_OK) {
       // abort: the tagged state table needs no cleaning
       if (tid == 0) { dsr_decode_result r; memset(&r, 0, sizeof(r)); r.status = status; r.frames = T - 1; res[u] = r; }
@@ -921,7 +975,7 @@ dsr_status dsr_decoder_decode_batch(dsr_decoder* d, const float* score, const in
       std::vector<long long> hp((size_t) slots * 16); DSR_HIP(hipMemcpy(hp.data(), D.prof, hp.size() * sizeof(long long), hipMemcpyDeviceToHost));
       double acc[16] = {0}; for (int s2 = 0; s2 < slots; s2++) for (int i = 0; i < 16; i++) acc[i] += (double) hp[(size_t) s2 * 16 + i];
       fprintf(stderr, "[dsr viterbi prof] mean us per slot:");
-      for (int i = 0; i < 15; i++) fprintf(stderr, " p%d=%.0f", i, acc[i] / slots / 100.0);
+      for (int i = 0; i < 12; i++) fprintf(stderr, " p%d=%.0f", i, acc[i] / slots / 100.0);
       fprintf(stderr, "\n");
     }
     if (d->dumpOn) {
