@@ -278,6 +278,41 @@ def test_viterbi_bit_exact(dsr, oracle, cuda, seed, S, nDist, T, beam, kw):
         _check_decode(ro, out[u])
 
 
+@pytest.mark.parametrize("seed,S,gkw,path", [
+    (11, 4000, dict(ties=True), "register"),          # ~23k placements a frame: parked batches + two passes over the state table
+    (12, 600, dict(eps_frac=0.3), "register"),        # parked batches, epsilon paths longer than one hop
+    (13, 4000, dict(ties=True), "memory"),            # the same frames through the memory path
+    (14, 9500, dict(), "register"),                   # > 24576 placements: the register path hands the frame over
+])
+def test_viterbi_large_frames(dsr, oracle, cuda, seed, S, gkw, path, monkeypatch):
+    """Frames far above the 8192 placements the registers hold: every list size class of the decoder kernel against the oracle."""
+    import torch
+    arcs, fin = synth.random_wfst(S, 64, seed=seed, **gkw)
+    go, gd = _graphs(dsr, oracle, arcs, fin)
+    rng = np.random.default_rng(seed)
+    T = 14
+    sc = rng.uniform(0, 4, (2, T, 64)).astype(np.float32)
+    if gkw.get("ties"):
+        sc = np.round(sc)
+    if path == "memory":
+        monkeypatch.setenv("DSR_VITERBI_NOFAST", "1")
+    dec = dsr.Decoder(beam=1e9, lmScale=2.0, maxActive=16384, streams=2)
+    dec.set(gd)
+    out = dec.decode_batch(torch.from_numpy(sc).to(cuda))
+    for u in range(2):
+        ro = go.decode(sc[u], beam=1e9, lmScale=2.0)
+        assert ro["rc"] == 0
+        _check_decode(ro, out[u])
+        assert out[u]["placements"] / T > 5000, "the case is meant to produce large frames"
+        if path == "memory":
+            assert out[u]["registerFrames"] == 0
+        elif S < 9000:
+            print("placements/frame %.0f, register frames %d of %d" % (out[u]["placements"] / T, out[u]["registerFrames"], T))
+            assert out[u]["registerFrames"] >= (T if seed == 11 else 6)
+        else:
+            assert 0 < out[u]["registerFrames"] < T
+
+
 def test_viterbi_token_lists(dsr, oracle, cuda):
     """Every frame's active list: same states in the same list order with the same float scores."""
     import torch
