@@ -30,6 +30,7 @@ struct dsr_pipe {
   std::vector<int> h_T, h_ny, h_Tm;
   hipEvent_t ev[7]; bool evInit = false; float ms[6] = {0, 0, 0, 0, 0, 0};
   int64_t bytes[5] = {0, 0, 0, 0, 0};
+  bool pending = false;
 };
 
 extern "C" {
@@ -71,11 +72,15 @@ void dsr_pipe_destroy(dsr_pipe* p) { if (p && p->evInit) for (int i = 0; i < 7; 
 
 static void check(dsr_status s) { if (s != DSR_OK) throw Error(s, "%s", dsr_last_error()); }
 
-dsr_status dsr_pipe_run(dsr_pipe* p, const float* x, const int32_t* nsamp_dev, const int32_t* nsamp_host, int U, int C,
-                        int64_t sampStride, dsr_decode_result* res, int32_t* arcs_out, uint32_t* words_out, int maxPath, void* stream)
+// submit enqueues the whole pipe for one batch on `stream` and returns; collect waits for it and hands the results out.
+// A pipe object (and its decoder) carries one batch at a time; two pipe objects on two streams overlap the ragged end of
+// one batch's decode with the front end of the next.
+dsr_status dsr_pipe_submit(dsr_pipe* p, const float* x, const int32_t* nsamp_dev, const int32_t* nsamp_host, int U, int C,
+                           int64_t sampStride, int maxPath, int want_paths, void* stream)
 {
   return guard([&] {
-    if (!p || !x || !nsamp_dev || !nsamp_host || !res) throw Error(DSR_E_PARAMETER, "null argument");
+    if (!p || !x || !nsamp_dev || !nsamp_host) throw Error(DSR_E_PARAMETER, "null argument");
+    if (p->pending) throw Error(DSR_E_CONSISTENCY, "a batch is already in flight on this pipe: collect it first");
     if (U <= 0) return;
     hipStream_t st = (hipStream_t) stream;
     if (!p->evInit) { for (int i = 0; i < 7; i++) DSR_HIP(hipEventCreate(&p->ev[i])); p->evInit = true; }
@@ -113,11 +118,32 @@ dsr_status dsr_pipe_run(dsr_pipe* p, const float* x, const int32_t* nsamp_dev, c
     DSR_HIP(hipEventRecord(p->ev[4], st));
     check(dsr_gmm_score(p->gmm, p->feat.p, (int64_t) U * TmMax, p->gmmMode, p->scores.p, nullptr, st));
     DSR_HIP(hipEventRecord(p->ev[5], st));
-    check(dsr_decoder_decode_batch(p->dec, p->scores.p, p->d_Tm.p, U, TmMax, nDist, res, arcs_out, words_out, maxPath, st));
+    check(dsr_decoder_decode_launch(p->dec, p->scores.p, p->d_Tm.p, U, TmMax, nDist, maxPath, want_paths, st));
     DSR_HIP(hipEventRecord(p->ev[6], st));
+    p->pending = true;
+  });
+}
+
+dsr_status dsr_pipe_collect(dsr_pipe* p, dsr_decode_result* res, int32_t* arcs_out, uint32_t* words_out)
+{
+  return guard([&] {
+    if (!p || !res) throw Error(DSR_E_PARAMETER, "null argument");
+    if (!p->pending) throw Error(DSR_E_CONSISTENCY, "no batch in flight");
+    p->pending = false;
+    check(dsr_decoder_decode_collect(p->dec, res, arcs_out, words_out));
     DSR_HIP(hipEventSynchronize(p->ev[6]));
     for (int i = 0; i < 6; i++) DSR_HIP(hipEventElapsedTime(&p->ms[i], p->ev[i], p->ev[i + 1]));
   });
+}
+
+dsr_status dsr_pipe_run(dsr_pipe* p, const float* x, const int32_t* nsamp_dev, const int32_t* nsamp_host, int U, int C,
+                        int64_t sampStride, dsr_decode_result* res, int32_t* arcs_out, uint32_t* words_out, int maxPath, void* stream)
+{
+  if (!res) return guard([&] { throw Error(DSR_E_PARAMETER, "null argument"); });
+  if (U <= 0) return DSR_OK;
+  const dsr_status s1 = dsr_pipe_submit(p, x, nsamp_dev, nsamp_host, U, C, sampStride, maxPath, (arcs_out || words_out) ? 1 : 0, stream);
+  if (s1 != DSR_OK) return s1;
+  return dsr_pipe_collect(p, res, arcs_out, words_out);
 }
 
 dsr_status dsr_pipe_stage_ms(const dsr_pipe* p, float ms[6])

@@ -58,6 +58,20 @@ template <class T> struct DevBuf {
   void upload(const std::vector<T>& v) { upload(v.data(), v.size()); }
 };
 
+// pinned host memory (the target of asynchronous device-to-host copies)
+template <class T> struct PinBuf {
+  T* p = nullptr; size_t n = 0;
+  PinBuf() = default; PinBuf(const PinBuf&) = delete; PinBuf& operator=(const PinBuf&) = delete;
+  ~PinBuf() { if (p) (void) hipHostFree(p); }
+  void reserve(size_t m) {
+    if (m <= n) return;
+    if (p) { DSR_HIP(hipHostFree(p)); p = nullptr; n = 0; }
+    hipError_t e = hipHostMalloc((void**) &p, m * sizeof(T), hipHostMallocDefault);
+    if (e != hipSuccess) { p = nullptr; throw Error(DSR_E_ALLOCATION, "hipHostMalloc of %zu bytes failed: %s", m * sizeof(T), hipGetErrorString(e)); }
+    n = m;
+  }
+};
+
 static inline int ilog2(unsigned v) { int l = 0; while ((1u << l) < v) l++; return l; }
 static inline bool is_pow2(unsigned v) { return v && !(v & (v - 1)); }
 static inline int cdiv(long a, long b) { return (int) ((a + b - 1) / b); }

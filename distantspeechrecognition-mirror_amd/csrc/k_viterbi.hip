@@ -807,6 +807,8 @@ struct DecoderState {
   DevBuf<TokA> d_tokA, d_ctok; DevBuf<TokB> d_tokB; DevBuf<Side> d_side; DevBuf<XRecD> d_xrecD; int fastOK = 0; DevBuf<int> d_tokOff, d_tokCnt, d_owner, d_rank, d_chead; DevBuf<unsigned> d_tags; DevBuf<CandA> d_cA; DevBuf<CandB> d_cB; DevBuf<unsigned> d_first; DevBuf<Bp> d_arena;
   DevBuf<long long> d_prof; DevBuf<dsr_decode_result> d_res; DevBuf<int> d_arcs; DevBuf<unsigned> d_words;
   long arenaCap = 0; int initial = 0; int threads = kThreads;
+  PinBuf<dsr_decode_result> h_res; PinBuf<int> h_arcs; PinBuf<unsigned> h_words; hipEvent_t evDone = nullptr;
+  int pendingU = 0; size_t pendingPath = 0; int pendingSlots = 0; long long* pendingProf = nullptr;
   // dump
   int dumpOn = 0; long dumpCap = 0; DevBuf<long> d_dumpFrameOff, d_dumpCount; DevBuf<int> d_dumpNode, d_dumpArc; DevBuf<float> d_dumpAc, d_dumpLm;
   std::vector<int64_t> h_dumpFrameOff; std::vector<int32_t> h_dumpNode, h_dumpArc; std::vector<float> h_dumpAc, h_dumpLm; int64_t h_dumpFrames = 0;
@@ -862,7 +864,7 @@ dsr_status dsr_decoder_create(const dsr_decoder_cfg* cfg, dsr_decoder** out)
     *out = d;
   });
 }
-void dsr_decoder_destroy(dsr_decoder* d) { delete d; }
+void dsr_decoder_destroy(dsr_decoder* d) { if (d && d->evDone) (void) hipEventDestroy(d->evDone); delete d; }
 
 dsr_status dsr_decoder_set(dsr_decoder* d, const dsr_wfst* g)
 {
@@ -920,14 +922,19 @@ static void ensure_scratch(dsr_decoder* d, int slots, int Tmax)
   d->nSlots = slots; d->arenaCap = arena;
 }
 
-dsr_status dsr_decoder_decode_batch(dsr_decoder* d, const float* score, const int32_t* nframes, int U, int Tmax, int nDist,
-                                    dsr_decode_result* res, int32_t* arcs_out, uint32_t* words_out, int maxPath, void* stream)
+// Asynchronous halves of decode_batch: launch enqueues the kernel and the copies of the results into pinned staging
+// memory on `stream` and returns; collect waits for that work and hands the results out.  One launch may be in flight
+// per decoder object (its scratch memory belongs to the launch).
+dsr_status dsr_decoder_decode_launch(dsr_decoder* d, const float* score, const int32_t* nframes, int U, int Tmax, int nDist,
+                                     int maxPath, int want_paths, void* stream)
 {
   return guard([&] {
-    if (!d || !score || !nframes || !res) throw Error(DSR_E_PARAMETER, "null argument");
+    if (!d || !score || !nframes) throw Error(DSR_E_PARAMETER, "null argument");
     if (!d->haveGraph) throw Error(DSR_E_INITIALIZATION, "call set() with a transducer first");
+    if (d->pendingU > 0) throw Error(DSR_E_CONSISTENCY, "a decode is already in flight on this decoder: collect it first");
     if (U <= 0) return;
     hipStream_t st = (hipStream_t) stream;
+    int32_t* arcs_out = want_paths ? (int32_t*) 1 : nullptr; uint32_t* words_out = want_paths ? (uint32_t*) 1 : nullptr;     // (only tested for null below)
     // every input symbol must name a distribution (decoder.h:985: _dist->find(distX-1))
     for (size_t a = 0; a < d->csr.in.size(); a++) if (d->csr.in[a] > (uint32_t) nDist) throw Error(DSR_E_INDEX, "arc input %u has no distribution (nDist=%d)", d->csr.in[a], nDist);
     int slots = d->cfg.streams; if (slots > U) slots = U; if (d->dumpOn) slots = 1;
@@ -967,12 +974,30 @@ dsr_status dsr_decoder_decode_batch(dsr_decoder* d, const float* score, const in
     hipLaunchKernelGGL(k_viterbi, dim3(slots), dim3(d->threads), lds, st, G, D, score, nframes, U, Tmax, nDist, d->d_res.p,
                        (arcs_out || words_out) ? d->d_arcs.p : nullptr, (arcs_out || words_out) ? d->d_words.p : nullptr, maxPath, useLds, hashN);
     DSR_HIP(hipGetLastError());
-    DSR_HIP(hipMemcpyAsync(res, d->d_res.p, sizeof(dsr_decode_result) * U, hipMemcpyDeviceToHost, st));
-    if (arcs_out) DSR_HIP(hipMemcpyAsync(arcs_out, d->d_arcs.p, sizeof(int) * (size_t) U * maxPath, hipMemcpyDeviceToHost, st));
-    if (words_out) DSR_HIP(hipMemcpyAsync(words_out, d->d_words.p, sizeof(unsigned) * (size_t) U * maxPath, hipMemcpyDeviceToHost, st));
-    DSR_HIP(hipStreamSynchronize(st));
-    if (D.prof) {
-      std::vector<long long> hp((size_t) slots * 16); DSR_HIP(hipMemcpy(hp.data(), D.prof, hp.size() * sizeof(long long), hipMemcpyDeviceToHost));
+    const size_t nPath = want_paths ? (size_t) U * maxPath : 0;
+    d->h_res.reserve(U); d->h_arcs.reserve(nPath ? nPath : 1); d->h_words.reserve(nPath ? nPath : 1);
+    DSR_HIP(hipMemcpyAsync(d->h_res.p, d->d_res.p, sizeof(dsr_decode_result) * U, hipMemcpyDeviceToHost, st));
+    if (nPath) DSR_HIP(hipMemcpyAsync(d->h_arcs.p, d->d_arcs.p, sizeof(int) * nPath, hipMemcpyDeviceToHost, st));
+    if (nPath) DSR_HIP(hipMemcpyAsync(d->h_words.p, d->d_words.p, sizeof(unsigned) * nPath, hipMemcpyDeviceToHost, st));
+    if (!d->evDone) DSR_HIP(hipEventCreateWithFlags(&d->evDone, hipEventDisableTiming));
+    DSR_HIP(hipEventRecord(d->evDone, st));
+    d->pendingU = U; d->pendingPath = nPath; d->pendingSlots = slots; d->pendingProf = D.prof;
+  });
+}
+
+dsr_status dsr_decoder_decode_collect(dsr_decoder* d, dsr_decode_result* res, int32_t* arcs_out, uint32_t* words_out)
+{
+  return guard([&] {
+    if (!d || !res) throw Error(DSR_E_PARAMETER, "null argument");
+    if (d->pendingU <= 0) throw Error(DSR_E_CONSISTENCY, "no decode in flight");
+    const int U = d->pendingU; const size_t nPath = d->pendingPath; const int slots = d->pendingSlots; long long* prof = d->pendingProf;
+    d->pendingU = 0;
+    DSR_HIP(hipEventSynchronize(d->evDone));
+    memcpy(res, d->h_res.p, sizeof(dsr_decode_result) * U);
+    if (arcs_out && nPath) memcpy(arcs_out, d->h_arcs.p, sizeof(int) * nPath);
+    if (words_out && nPath) memcpy(words_out, d->h_words.p, sizeof(unsigned) * nPath);
+    if (prof) {
+      std::vector<long long> hp((size_t) slots * 16); DSR_HIP(hipMemcpy(hp.data(), prof, hp.size() * sizeof(long long), hipMemcpyDeviceToHost));
       double acc[16] = {0}; for (int s2 = 0; s2 < slots; s2++) for (int i = 0; i < 16; i++) acc[i] += (double) hp[(size_t) s2 * 16 + i];
       fprintf(stderr, "[dsr viterbi prof] mean us per slot:");
       for (int i = 0; i < 12; i++) fprintf(stderr, " p%d=%.0f", i, acc[i] / slots / 100.0);
@@ -992,6 +1017,16 @@ dsr_status dsr_decoder_decode_batch(dsr_decoder* d, const float* score, const in
       }
     }
   });
+}
+
+dsr_status dsr_decoder_decode_batch(dsr_decoder* d, const float* score, const int32_t* nframes, int U, int Tmax, int nDist,
+                                    dsr_decode_result* res, int32_t* arcs_out, uint32_t* words_out, int maxPath, void* stream)
+{
+  if (!res) return guard([&] { throw Error(DSR_E_PARAMETER, "null argument"); });
+  if (U <= 0) return DSR_OK;
+  const dsr_status s1 = dsr_decoder_decode_launch(d, score, nframes, U, Tmax, nDist, maxPath, (arcs_out || words_out) ? 1 : 0, stream);
+  if (s1 != DSR_OK) return s1;
+  return dsr_decoder_decode_collect(d, res, arcs_out, words_out);
 }
 
 dsr_status dsr_decoder_get_dump(dsr_decoder* d, int64_t* nFrames, const int64_t** frameOff, const int32_t** node,

@@ -407,6 +407,22 @@ class Pipe:
                                 _ptr(arcs) if want_paths else None, _ptr(words) if want_paths else None, maxPath, cur_stream()))
         return res, arcs, words
 
+    def submit(self, x, nsamp_dev, nsamp_host, maxPath=4096, want_paths=True):
+        """Enqueue one batch on the current stream and return; collect() waits for it.  One batch in flight per Pipe."""
+        U, Cn, N = x.shape
+        ns = _np(nsamp_host, np.int32)
+        self._inflight = (U, maxPath, want_paths, x, nsamp_dev, ns)              # keep the inputs alive until collected
+        check(_lib.dsr_pipe_submit(self.h, _dev(x), _dev(nsamp_dev), _ptr(ns), U, Cn, N, maxPath, 1 if want_paths else 0, cur_stream()))
+
+    def collect(self):
+        U, maxPath, want_paths = self._inflight[:3]
+        res = (DecodeResult * U)()
+        arcs = np.zeros((U, maxPath), np.int32) if want_paths else None
+        words = np.zeros((U, maxPath), np.uint32) if want_paths else None
+        check(_lib.dsr_pipe_collect(self.h, C.byref(res), _ptr(arcs) if want_paths else None, _ptr(words) if want_paths else None))
+        self._inflight = None
+        return res, arcs, words
+
     def stage_ms(self):
         ms = (f32 * 6)(); check(_lib.dsr_pipe_stage_ms(self.h, ms)); return list(ms)
 

@@ -225,6 +225,11 @@ typedef struct {
 dsr_status dsr_decoder_decode_batch(dsr_decoder*, const float* score_dev, const int32_t* nframes_dev, int U,
                                     int Tmax, int nDist, dsr_decode_result* res, int32_t* arcs_out,
                                     uint32_t* words_out, int maxPath, void* stream);
+/* The same in two halves: launch enqueues the decode (and the copy of its results to pinned staging memory) on
+ * `stream` and returns; collect waits for it and fills the host outputs.  One launch in flight per decoder object. */
+dsr_status dsr_decoder_decode_launch(dsr_decoder*, const float* score_dev, const int32_t* nframes_dev, int U,
+                                     int Tmax, int nDist, int maxPath, int want_paths, void* stream);
+dsr_status dsr_decoder_decode_collect(dsr_decoder*, dsr_decode_result* res, int32_t* arcs_out, uint32_t* words_out);
 /* debug/parity: per-frame token list (list order) of utterance 0 of the last decode with
    cfg.streams == 1 and dumpFrames enabled through dsr_decoder_enable_dump(). */
 dsr_status dsr_decoder_enable_dump(dsr_decoder*, int enable);
@@ -244,6 +249,11 @@ void       dsr_pipe_destroy(dsr_pipe*);
 dsr_status dsr_pipe_run(dsr_pipe*, const float* x_dev, const int32_t* nsamp_dev, const int32_t* nsamp_host,
                         int U, int C, int64_t sampStride, dsr_decode_result* res, int32_t* arcs_out,
                         uint32_t* words_out, int maxPath, void* stream);
+/* The same in two halves (one batch in flight per pipe object): two pipes on two streams overlap the ragged end of
+ * one batch's decode -- utterances finish at different times -- with the front end of the next batch. */
+dsr_status dsr_pipe_submit(dsr_pipe*, const float* x_dev, const int32_t* nsamp_dev, const int32_t* nsamp_host,
+                           int U, int C, int64_t sampStride, int maxPath, int want_paths, void* stream);
+dsr_status dsr_pipe_collect(dsr_pipe*, dsr_decode_result* res, int32_t* arcs_out, uint32_t* words_out);
 /* per-stage device time of the last run in milliseconds: [analysis, beamform, synthesis, mfcc, gmm, viterbi] */
 dsr_status dsr_pipe_stage_ms(const dsr_pipe*, float ms[6]);
 /* device pointers to the intermediates of the last run (borrowed): 0 X, 1 Y, 2 y, 3 feat, 4 scores */
