@@ -391,6 +391,198 @@ template <int M> static void launch_analysis(const FbPlan& p, const float* x, co
   DSR_HIP(hipGetLastError());
 }
 
+// ---------------------------------------------------------------------------------------------
+// Quarter-wave analysis bank for M = 256 (N = 128 packed complex points): sixteen lanes own one frame, a wavefront
+// works on four frames at once.  The length-128 DFT is split 8 x 16 so that almost all butterflies pair registers of
+// one lane (every cross-lane radix-2 stage of the wave-per-frame kernel costs a full complex multiply per element on
+// both partner lanes -- this kernel has a single such stage):
+//   pass 1  lane l forms the polyphase sums of the points z[l + 16e], e = 0..7, and transforms them in registers
+//           (8-point DFT over e), then turns them by w_128^(l k1);
+//   LDS     [frame][k1][l] transposition inside a wave-private strip (no workgroup barrier);
+//   pass 2  lane (k1, r) transforms the eight points l = 2m + r (8-point DFT over m); the halves r = 0, 1 of the
+//           16-point DFT over l are joined by one exchange with the neighbouring lane (DPP quad_perm);
+//   LDS     natural order [frame][f];
+//   split   the whole wave walks one frame at a time: even/odd split of the packed transform, bins f = lane and
+//           lane + 64 leave as two contiguous 512-byte stores per row.
+// Per frame that is about a third of the vector instructions of the wave-per-frame kernel, which was bound by
+// instruction issue (wave64 on SIMD16: 4 cycles per instruction), not by memory.
+// LDS layout: [tw: M float2][win: winLen float][strip: waves x 576 float2]
+__device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
+// V[k] = sum_e v[e] w8^(e k), w8 = exp(+2 pi j / 8); result in bit-reversed positions: V[k] = v[br3(k)]
+__device__ __forceinline__ void fft8_pos(float2 (&v)[8])
+{
+  const float s = 0.70710678118654752440f;
+#pragma unroll
+  for (int i = 0; i < 4; i++) { const float2 a = cadd(v[i], v[i + 4]), b = csub(v[i], v[i + 4]); v[i] = a; v[i + 4] = b; }
+  v[5] = make_float2((v[5].x - v[5].y) * s, (v[5].x + v[5].y) * s);                  // * w8^1
+  v[6] = make_float2(-v[6].y, v[6].x);                                               // * w8^2 = j
+  v[7] = make_float2((-v[7].x - v[7].y) * s, (v[7].x - v[7].y) * s);                 // * w8^3
+#pragma unroll
+  for (int h = 0; h < 8; h += 4) {
+#pragma unroll
+    for (int i = 0; i < 2; i++) { const float2 a = cadd(v[h + i], v[h + i + 2]), b = csub(v[h + i], v[h + i + 2]); v[h + i] = a; v[h + i + 2] = b; }
+    v[h + 3] = make_float2(-v[h + 3].y, v[h + 3].x);                                 // * j
+  }
+#pragma unroll
+  for (int h = 0; h < 8; h += 2) { const float2 a = cadd(v[h], v[h + 1]), b = csub(v[h], v[h + 1]); v[h] = a; v[h + 1] = b; }
+}
+
+template <int MT>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_analysis_q256(const float* __restrict__ x, const int* __restrict__ nsampArr,
+                                                       const float* __restrict__ proto, const float2* __restrict__ twG,
+                                                       float2* __restrict__ X, int C, long sampStride, int Tmax,
+                                                       int pd, int laN, int gain, int TF)
+{
+  constexpr int M = 256, N = 128, D = 128;                     // r = 1
+  constexpr int NQ = 2;                                        // quads of frames a wave works on side by side (independent chains to interleave)
+  constexpr int SQ = 146, SK = 18, SZ = 4 * SQ;                // strip pitches: per frame / per k1 row (conflict-free both ways); strip size
+  constexpr int BR[8] = {0, 4, 2, 6, 1, 5, 3, 7};
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  // The window is stored with 32 floats of padding after every 128 samples: consecutive frames (the 16-lane quarters of a
+  // wave) then start 160 floats apart and read from opposite halves of the 64 LDS banks.
+  const int winLen = (TF - 1) * D + MT * M;                    // logical samples
+  const int winPhys = winLen + 32 * ((winLen + 127) >> 7);
+  float2* tw = reinterpret_cast<float2*>(smem);
+  float* win = reinterpret_cast<float*>(tw + M);
+  const int tid = threadIdx.x, nthr = blockDim.x, lane = tid & 63, wave = tid >> 6, nwv = nthr >> 6;
+  float2* strip = reinterpret_cast<float2*>(win + ((winPhys + 3) & ~3)) + wave * (NQ * SZ);
+  // A workgroup streams one (utterance, channel) row from start to end, TF frames at a time: taps and twiddles are set up
+  // once per row, the samples of the next TF frames are fetched into registers while the current ones are transformed,
+  // and the MT*M - D samples two tiles share stay in LDS.  (Workgroups that run at the same time work on different rows:
+  // their addresses differ by the row pitches, not by a power-of-two tile pitch.)
+  const int c = (int) (blockIdx.x % (unsigned) C), u = (int) (blockIdx.x / (unsigned) C);
+  const int nsamp = nsampArr[u];
+  const int nblk = (nsamp + D - 1) / D;
+  const int Tu = (nblk < laN) ? 0 : (nblk - laN + pd);
+  const float* xs = x + ((long) u * C + c) * sampStride;
+  float2* Xo = X + ((long) u * C + c) * (long) Tmax * (N + 1);
+
+  for (int i = tid; i < M; i += nthr) tw[i] = twG[i];
+  const long lo0 = (long) (laN + 1) * D - (long) MT * M;       // first sample of the first tile's window (negative: zeros)
+  for (int i = tid; i < winLen; i += nthr) { const long n = lo0 + i; win[i + 32 * (i >> 7)] = (n >= 0 && n < nsamp) ? xs[n] : 0.0f; }
+  const int step = TF * D, keep = winLen - step;               // samples a tile brings in / shares with the tile before (multiples of 128)
+  const int stepPhys = step + 32 * (step >> 7), keepPhys = keep + 32 * (keep >> 7);
+  const bool vec = ((((uintptr_t) xs) | (uintptr_t) (sampStride * 4)) & 15) == 0;
+  constexpr int PF = 4;                                        // float4 per thread: step <= 4 * PF * nthr
+  const int l = lane & 15, q = lane >> 4;
+  // prototype taps of this lane's points: h[2(l + 16e) + {0,1} + qq M]
+  float2 hreg[8][MT];
+#pragma unroll
+  for (int e = 0; e < 8; e++)
+#pragma unroll
+    for (int qq = 0; qq < MT; qq++) hreg[e][qq] = *reinterpret_cast<const float2*>(proto + 2 * (l + 16 * e) + qq * M);
+  __syncthreads();
+  // twiddles: after pass 1  w_128^(l k1) = tw[2 l k1];  joining the halves of pass 2  w_16^(k2) = tw[16 k2] on the odd half
+  // (read from the LDS table where they are used: sixteen complex constants per lane would cost registers the taps need)
+  const int k1p = l >> 1, rr = l & 1;
+  const int l2 = 2 * l, rr16 = rr ? 16 : 0;
+  const float sgn = rr ? -1.f : 1.f;
+  // the even/odd split: lane owns the adjacent bins 2 lane, 2 lane + 1 (one 16-byte store per row and lane)
+  const float2 wf0 = tw[2 * lane], wf1 = tw[2 * lane + 1];
+  const int fc0 = (N - 2 * lane) & (N - 1), fc1 = (N - 2 * lane - 1) & (N - 1);
+  const int ic0 = fc0 + 8 * (fc0 >> 6), ic1 = fc1 + 8 * (fc1 >> 6);      // strip index of the mirror bins
+  const int iz = 2 * lane + 8 * (lane >> 5);                              // strip index of bin 2 lane (bin 2 lane + 1 follows)
+  const float g = (gain > 0) ? (float) gain : 1.0f;
+
+  const int nTiles = (Tmax + TF - 1) / TF;
+  for (int tile = 0; tile < nTiles; tile++) {
+    const int t0 = tile * TF;
+    // the next tile's new samples: in flight while this tile is transformed
+    float4 pf[PF];
+    const bool more = tile + 1 < nTiles;
+    const long nlo = lo0 + (long) (tile + 1) * step + keep;    // their first sample index
+    if (more) {
+#pragma unroll
+      for (int j = 0; j < PF; j++) {
+        const int i4 = (j * nthr + tid) * 4; const long n = nlo + i4;
+        float4 v4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (i4 < step) {
+          if (vec && n >= 0 && n + 3 < nsamp) v4 = *reinterpret_cast<const float4*>(xs + n);
+          else { v4.x = (n >= 0 && n < nsamp) ? xs[n] : 0.f; v4.y = (n + 1 >= 0 && n + 1 < nsamp) ? xs[n + 1] : 0.f;
+                 v4.z = (n + 2 >= 0 && n + 2 < nsamp) ? xs[n + 2] : 0.f; v4.w = (n + 3 >= 0 && n + 3 < nsamp) ? xs[n + 3] : 0.f; }
+        }
+        pf[j] = v4;
+      }
+    }
+    for (int tl = 4 * NQ * wave; tl < TF; tl += 4 * NQ * nwv) {
+      if (t0 + tl >= Tmax) break;
+      // ---- pass 1: polyphase sums + 8-point DFT over e + turn
+      float2 v[NQ][8];
+#pragma unroll
+      for (int h = 0; h < NQ; h++) {
+        const float* wp = win + (tl + 4 * h + q) * 160 - 2 * l;          // padded index of sample  128 (tl + q) - 2l
+#pragma unroll
+        for (int e = 0; e < 8; e++) {
+          float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+          for (int qq = 0; qq < MT; qq++) {
+            const int A = MT * M - 2 - 32 * e - 256 * qq;                // sample n_t - k0 - 1 - qq M relative to the frame's first block
+            const float2 pr = *reinterpret_cast<const float2*>(wp + (A + 32 * (A >> 7)));     // (x[n_t-k0-1-qM], x[n_t-k0-qM])
+            s0 += hreg[e][qq].x * pr.y; s1 += hreg[e][qq].y * pr.x;
+          }
+          v[h][e] = make_float2(s0, s1);
+        }
+      }
+#pragma unroll
+      for (int h = 0; h < NQ; h++) fft8_pos(v[h]);
+#pragma unroll
+      for (int h = 0; h < NQ; h++)
+#pragma unroll
+        for (int k = 0; k < 8; k++) strip[h * SZ + q * SQ + k * SK + l] = (k == 0) ? v[h][0] : cmulf(v[h][BR[k]], tw[(l2 * k) & (M - 1)]);
+      wave_lds_sync();
+      // ---- pass 2: 8-point DFT over m (points l = 2m + rr), join the halves with the neighbouring lane
+#pragma unroll
+      for (int h = 0; h < NQ; h++)
+#pragma unroll
+        for (int m2 = 0; m2 < 8; m2++) v[h][m2] = strip[h * SZ + q * SQ + k1p * SK + 2 * m2 + rr];
+#pragma unroll
+      for (int h = 0; h < NQ; h++) fft8_pos(v[h]);
+      wave_lds_sync();
+#pragma unroll
+      for (int h = 0; h < NQ; h++)
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+          const float2 b = (k == 0) ? v[h][0] : cmulf(v[h][BR[k]], tw[rr16 * k]);        // tw[0] = 1 on the even half
+          const float ox = dpp_f<0xB1>(b.x), oy = dpp_f<0xB1>(b.y);                      // quad_perm [1,0,3,2]: lane ^ 1
+          const int f = k1p + 8 * k + 64 * rr;                                           // even half: A0 + B, odd half: A0 - B
+          strip[h * SZ + q * 144 + f + 8 * rr] = make_float2(ox + sgn * b.x, oy + sgn * b.y);
+        }
+      wave_lds_sync();
+      // ---- even/odd split, one frame at a time: bins lane, lane + 64 (+ bin N by lane 0).
+      // X[f] = (E + w O) g  with  E = (Z[f] + conj Z[N-f]) / 2,  O = -j (Z[f] - conj Z[N-f]) / 2  -- the halves and the gain are
+      // one exact scale factor, zero for the rows past the end of the utterance.
+#pragma unroll
+      for (int fq = 0; fq < 4 * NQ; fq++) {
+        const int t = t0 + tl + fq;
+        if (t < Tmax && tl + fq < TF) {
+          float2* row = Xo + (long) t * (N + 1);
+          const float gh = (t < Tu) ? 0.5f * g : 0.0f;
+          const float2* Z = strip + (fq >> 2) * SZ + (fq & 3) * 144;
+          const float4 zz = *reinterpret_cast<const float4*>(Z + iz);
+          const float2 zf0 = make_float2(zz.x, zz.y), zf1 = make_float2(zz.z, zz.w), zc0 = Z[ic0], zc1 = Z[ic1];
+          const float2 s0 = make_float2(zf0.x + zc0.x, zf0.y - zc0.y), d0 = make_float2(zf0.x - zc0.x, zf0.y + zc0.y);
+          const float2 s1 = make_float2(zf1.x + zc1.x, zf1.y - zc1.y), d1 = make_float2(zf1.x - zc1.x, zf1.y + zc1.y);
+          float4 o4;
+          o4.x = (s0.x + wf0.x * d0.y + wf0.y * d0.x) * gh; o4.y = (s0.y - wf0.x * d0.x + wf0.y * d0.y) * gh;
+          o4.z = (s1.x + wf1.x * d1.y + wf1.y * d1.x) * gh; o4.w = (s1.y - wf1.x * d1.x + wf1.y * d1.y) * gh;
+          __builtin_memcpy(reinterpret_cast<char*>(row) + 16 * lane, &o4, 16);           // rows are 8-byte aligned: dwordx4 store, dword alignment suffices
+          if (lane == 0) row[N] = make_float2((zf0.x - zf0.y) * 2.0f * gh, 0.f);        // bin N: X = Re(Z0) - Im(Z0)
+        }
+      }
+      wave_lds_sync();
+    }
+    if (more) {                                                // slide the window: shared samples to the front, new ones behind
+      __syncthreads();
+      for (int i4 = tid * 4; i4 < keepPhys; i4 += nthr * 4)    // keep < step: source and destination never overlap
+        *reinterpret_cast<float4*>(win + i4) = *reinterpret_cast<const float4*>(win + stepPhys + i4);
+#pragma unroll
+      for (int j = 0; j < PF; j++) { const int i4 = (j * nthr + tid) * 4; if (i4 < step) *reinterpret_cast<float4*>(win + keepPhys + i4 + 32 * (i4 >> 7)) = pf[j]; }
+      __syncthreads();
+    }
+  }
+}
+
 template <int M> static void launch_synthesis(const FbPlan& p, const float* Y, const int* nframes, int U, int Tmax,
                                               long outStride, float* y, hipStream_t st)
 {
@@ -427,8 +619,26 @@ template <int M, int MT> static void launch_analysis_w(const FbPlan& p, const fl
   DSR_HIP(hipGetLastError());
 }
 
+template <int MT> static void launch_analysis_q256(const FbPlan& p, const float* x, const int* nsamp, int U, int C,
+                                                   long sampStride, int Tmax, float* X, hipStream_t st)
+{
+  constexpr int M = 256;
+  const int TF = 32, waves = 4;                                // 8 frames per wave and pass over the tile; 4096 new samples = 4 float4 per thread
+  const int winLen = (TF - 1) * p.D + MT * M, winPhys = winLen + 32 * ((winLen + 127) >> 7);
+  const size_t lds = sizeof(float2) * M + sizeof(float) * ((winPhys + 3) & ~3) + sizeof(float2) * (size_t) waves * 2 * 4 * 146;
+  DSR_HIP(hipFuncSetAttribute((const void*) k_analysis_q256<MT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
+  dim3 grid((unsigned) U * (unsigned) C, 1, 1);
+  hipLaunchKernelGGL((k_analysis_q256<MT>), grid, dim3(64 * waves), lds, st, x, nsamp, p.d_proto.p, p.d_tw.p, (float2*) X, C,
+                     sampStride, Tmax, p.pd, p.laN, p.gain, TF);
+  DSR_HIP(hipGetLastError());
+}
+
 void fb_analysis(const FbPlan& p, const float* x, const int* nsamp, int U, int C, long sampStride, int Tmax, float* X, hipStream_t st)
 {
+  if (!getenv("DSR_FB_GENERIC") && !getenv("DSR_FB_WAVE")) {
+    if (p.M == 256 && p.m == 2 && p.r == 1) { launch_analysis_q256<2>(p, x, nsamp, U, C, sampStride, Tmax, X, st); return; }
+    if (p.M == 256 && p.m == 4 && p.r == 1) { launch_analysis_q256<4>(p, x, nsamp, U, C, sampStride, Tmax, X, st); return; }
+  }
   if (!getenv("DSR_FB_GENERIC")) {
 #define W(MM, TT) if (p.M == MM && p.m == TT) { launch_analysis_w<MM, TT>(p, x, nsamp, U, C, sampStride, Tmax, X, st); return; }
     W(128, 2) W(128, 4) W(256, 2) W(256, 4) W(512, 2) W(512, 4) W(1024, 2) W(1024, 4)
