@@ -14,7 +14,7 @@
 
 using namespace dsr;
 
-struct dsr_fb; struct dsr_bf;
+struct dsr_fb; struct dsr_bf; struct dsr_lpc;
 
 struct dsr_stream {
   int refs = 1; std::string name; int size_ = 0; int type = DSR_T_FLOAT; int frameX = -1; bool endOfSamples = false;
@@ -97,6 +97,14 @@ struct StorageOp : dsr_stream {      // StorageFeature (feature.cc:2992-3085)
   void compute() override {
     if (ups[0]->nFrames > 100000) throw Error(DSR_E_DIMENSION, "Frame %d is greater than maximum number %d.", ups[0]->nFrames, 100000);
     alloc(ups[0]->nFrames); if (nFrames > 0) DSR_HIP(hipMemcpy(dev.p, ups[0]->dev.p, (size_t) nFrames * rowBytes(), hipMemcpyDeviceToDevice));
+  }
+};
+struct LpcOp : dsr_stream {         // WarpMVDR/BurgMVDR/WarpLPC/BurgLPC features (lpc.h:86-195,262-331)
+  dsr_lpc* plan = nullptr;
+  ~LpcOp() override { if (plan) dsr_lpc_destroy(plan); }
+  void compute() override {
+    alloc(ups[0]->nFrames);
+    if (nFrames > 0) { dsr_status s = dsr_lpc_run(plan, ups[0]->d<float>(), nFrames, d<double>(), S0); if (s) throw Error(s, "%s", dsr_last_error()); }
   }
 };
 struct CmnOp : dsr_stream { int mode; double dnf; void compute() override { alloc(ups[0]->nFrames); op_cmn(ups[0]->d<float>(), nFrames, size_, mode, dnf, d<float>(), S0); } };
@@ -303,6 +311,15 @@ dsr_status dsr_cepstral_create(dsr_stream* mel, int ncep, int type, const char* 
     need(mel, DSR_T_FLOAT, "CepstralFeature");
     GemvOp* s = mk<GemvOp>(name, "Cepstral", ncep, DSR_T_FLOAT); build_dct(ncep, mel->size_, type, s->hA);
     require_device(); s->A.upload(s->hA); s->add_up(mel); *out = s;
+  });
+}
+dsr_status dsr_lpc_feature_create(dsr_stream* src, int order, int correlate, float warp, int method, int kind, const char* name, dsr_stream** out)
+{
+  return guard([&] {
+    need(src, DSR_T_FLOAT, kind ? "LPCFeature" : "MVDRFeature");
+    dsr_lpc* plan = nullptr;
+    dsr_status s0 = dsr_lpc_create(src->size_, order, correlate, warp, method, kind, &plan); if (s0) throw Error(s0, "%s", dsr_last_error());
+    LpcOp* s = mk<LpcOp>(name, kind ? "LPC" : "MVDR", src->size_ / 2 + 1, DSR_T_DOUBLE); s->plan = plan; s->add_up(src); *out = s;
   });
 }
 dsr_status dsr_storage_create(dsr_stream* src, const char* name, dsr_stream** out)

@@ -71,6 +71,8 @@ def load():
         "dsr_bf_calc_mvdr_weights": [vp, f64, f64], "dsr_bf_calc_gsc_weights": [vp, f64, vp],
         "dsr_bf_set_active_weights": [vp, C.c_int, vp], "dsr_bf_zero_active_weights": [vp], "dsr_bf_select": [vp, C.c_int],
         "dsr_bf_get": [vp, C.c_int, vp, C.c_size_t], "dsr_bf_apply": [vp, vp, C.c_int, C.c_int, vp, vp],
+        "dsr_lpc_create": [C.c_int, C.c_int, C.c_int, f32, C.c_int, C.c_int, vp], "dsr_lpc_destroy": [vp], "dsr_lpc_size": [vp],
+        "dsr_lpc_run": [vp, vp, i64, vp, vp],
         "dsr_mfcc_default_cfg": [vp], "dsr_mfcc_create": [vp, vp, vp], "dsr_mfcc_destroy": [vp], "dsr_mfcc_frames": [vp, C.c_int],
         "dsr_mfcc_out_dim": [vp], "dsr_mfcc_run": [vp, vp, vp, C.c_int, i64, C.c_int, C.c_int, vp, vp],
         "dsr_gmm_create": [C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, vp], "dsr_gmm_load": [C.c_char_p, C.c_char_p, vp],
@@ -238,6 +240,27 @@ def calcDelaysPolar2(azimuth, elevation, micPositions):
     mp = _np(micPositions, np.float64); d = np.zeros(mp.shape[0], np.float64)
     check(_lib.dsr_calc_delays_polar2(azimuth, elevation, _ptr(mp), mp.shape[0], _ptr(d)))
     return d
+
+
+class LpcEnvelope:
+    """WarpMVDR/BurgMVDR (kind 0) and WarpLPC/BurgLPC (kind 1) envelopes of windowed frames, lpc.h:134-195,291-331."""
+
+    def __init__(self, dim, order=60, warp=0.0, method=0, kind=0, correlate=0):
+        L = load(); self.h = vp(); self.dim = dim
+        check(L.dsr_lpc_create(dim, order, correlate, warp, method, kind, C.byref(self.h)))
+
+    def __del__(self):
+        if _lib is not None and getattr(self, "h", None):
+            _lib.dsr_lpc_destroy(self.h)
+
+    def run(self, frames):
+        """frames: cuda float32 [T][dim] -> float64 [T][dim/2+1]"""
+        import torch
+        T, dim = frames.shape
+        assert dim == self.dim
+        out = torch.zeros((T, dim // 2 + 1), dtype=torch.float64, device=frames.device)
+        check(_lib.dsr_lpc_run(self.h, _dev(frames), T, _dev(out), cur_stream()))
+        return out
 
 
 class Mfcc:

@@ -96,6 +96,31 @@ class CepstralFeaturePtr(_unary(lambda *a: lib().dsr_cepstral_create(*a), "Cepst
         return (int(ncep), int(type))
 
 
+class _LpcBase(FeatureStreamPtr):
+    """lpc.h:86-195,262-331 (feature.i: WarpMVDRFeaturePtr(src, order=60, correlate=0, warp=0.0, nm=...))."""
+    _method = 0; _kind = 0; _dflt = "MVDR"
+
+    def __init__(self, src, order=60, correlate=0, warp=0.0, nm=None):
+        h, _ = _new(lib().dsr_lpc_feature_create, src._h, int(order), int(correlate), float(warp), self._method, self._kind, _b(nm or self._dflt))
+        FeatureStreamPtr.__init__(self, h, keep=(src,))
+
+
+class WarpMVDRFeaturePtr(_LpcBase):
+    _method = 0; _kind = 0; _dflt = "MVDR"
+
+
+class BurgMVDRFeaturePtr(_LpcBase):
+    _method = 1; _kind = 0; _dflt = "MVDR"
+
+
+class WarpLPCFeaturePtr(_LpcBase):
+    _method = 0; _kind = 1; _dflt = "LPC"
+
+
+class BurgLPCFeaturePtr(_LpcBase):
+    _method = 1; _kind = 1; _dflt = "LPC"
+
+
 class StorageFeaturePtr(_unary(lambda *a: lib().dsr_storage_create(*a), "Storage")):
     def _args(self, src):
         return ()

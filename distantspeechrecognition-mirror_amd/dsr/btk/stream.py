@@ -28,6 +28,7 @@ def lib():
                "dsr_vtln_create": [vp, ci, C.c_double, C.c_double, ci, C.c_char_p, vp],
                "dsr_mel_create": [vp, ci, C.c_float, C.c_float, C.c_float, ci, ci, C.c_char_p, vp],
                "dsr_log_create": [vp, C.c_double, C.c_double, ci, C.c_char_p, vp], "dsr_cepstral_create": [vp, ci, ci, C.c_char_p, vp],
+               "dsr_lpc_feature_create": [vp, ci, ci, C.c_float, ci, ci, C.c_char_p, vp],
                "dsr_storage_create": [vp, C.c_char_p, vp], "dsr_mean_subtraction_create": [vp, C.c_double, ci, C.c_char_p, vp],
                "dsr_adjacent_create": [vp, ci, C.c_char_p, vp], "dsr_linear_transform_create": [vp, ci, C.c_char_p, vp],
                "dsr_linear_transform_set": [vp, vp]}

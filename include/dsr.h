@@ -260,6 +260,19 @@ dsr_status dsr_pipe_stage_ms(const dsr_pipe*, float ms[6]);
 dsr_status dsr_pipe_intermediate(const dsr_pipe*, int which, void** dev, int64_t* bytes);
 
 /* =====================================================================================
+ * 6b. LPC / MVDR spectral envelopes  (btk/feature/lpc.cc:44-207, lpc.h:134-195,291-331:
+ *     WarpMVDRFeature, BurgMVDRFeature, WarpLPCFeature, BurgLPCFeature)
+ *     method 0 = WarpFeature (warped autocorrelation + Levinson-Durbin), 1 = BurgFeature;
+ *     kind 0 = MVDR envelope, 1 = LPC envelope.  frames_dev [T][dim] fp32 (the Hamming-windowed
+ *     blocks) -> out_dev [T][dim/2+1] fp64.  order >= dim/2+1 => DSR_E_PARAMETER (lpc.h:126-127).
+ * ===================================================================================== */
+typedef struct dsr_lpc dsr_lpc;
+dsr_status dsr_lpc_create(int dim, int order, int correlate, float warp, int method, int kind, dsr_lpc** out);
+void       dsr_lpc_destroy(dsr_lpc*);
+int        dsr_lpc_size(const dsr_lpc*);
+dsr_status dsr_lpc_run(dsr_lpc*, const float* frames_dev, int64_t T, double* out_dev, void* stream);
+
+/* =====================================================================================
  * 7. Stream/feature-operator API  (FeatureStream<Type,item>::next/reset/size/name/current/isEnd,
  *    btk/stream/stream.h:36-75).  Operators are reference counted handles that hold their
  *    upstream(s); next() returns a pointer to the operator's own output buffer (host memory),
@@ -300,6 +313,8 @@ dsr_status dsr_vtln_create(dsr_stream* pow, int coeffN, double ratio, double edg
 dsr_status dsr_mel_create(dsr_stream* mag, int powN, float rate, float low, float up, int filterN, int version, const char* name, dsr_stream** out);
 dsr_status dsr_log_create(dsr_stream* mel, double m, double a, int sphinxFlooring, const char* name, dsr_stream** out);
 dsr_status dsr_cepstral_create(dsr_stream* mel, int ncep, int type, const char* name, dsr_stream** out);
+/* WarpMVDRFeature / BurgMVDRFeature (kind 0) and WarpLPCFeature / BurgLPCFeature (kind 1), lpc.h:115-128,280-293 */
+dsr_status dsr_lpc_feature_create(dsr_stream* src, int order, int correlate, float warp, int method, int kind, const char* name, dsr_stream** out);
 dsr_status dsr_storage_create(dsr_stream* src, const char* name, dsr_stream** out);
 dsr_status dsr_mean_subtraction_create(dsr_stream* src, double devNormFactor, int runon, const char* name, dsr_stream** out);
 dsr_status dsr_adjacent_create(dsr_stream* single, int delta, const char* name, dsr_stream** out);

@@ -225,6 +225,17 @@ def gsc_apply(X, wq, B, wa, normalize=False):
 
 
 # ------------------------------------------------------------------ MFCC chain
+def lpc_feature(frames, order, warp=0.0, method=0, kind=0):
+    """WarpMVDR/BurgMVDR (kind 0) and WarpLPC/BurgLPC (kind 1) spectral envelopes, lpc.h:134-195,291-331."""
+    L = lib(); fr = _f32(frames); T, dim = fr.shape
+    out = np.zeros((T, dim // 2 + 1), np.float64)
+    L.orc_lpc_feature.restype = C.c_int
+    rc = L.orc_lpc_feature(_p(fr), C.c_long(T), dim, order, C.c_float(warp), method, kind, _p(out))
+    if rc != 0:
+        raise ValueError("Order (%d) and dimension (%d) do not match." % (order, dim // 2 + 1))
+    return out
+
+
 def mfcc_cfg(**kw):
     c = MfccCfg()
     lib().orc_mfcc_default_cfg(C.byref(c))

@@ -26,6 +26,14 @@
 extern "C" {
 #endif
 
+/* ---------------- LPC / MVDR spectral envelopes (btk/feature/lpc.cc, lpc.h) ---------------- */
+int  orc_lpc_npoints(int dim);
+void orc_lpc_fft_power(float* power, int dim);
+void orc_lpc_warp_autocorr(const float* X, int dim, int order, float warp, float* LP, float* E);
+void orc_lpc_burg_autocorr(const float* X, int dim, int order, float* A, float* E);
+/* method 0 Warp / 1 Burg; kind 0 MVDR envelope / 1 LPC envelope; frames [T][dim] -> out [T][dim/2+1] */
+int  orc_lpc_feature(const float* frames, long T, int dim, int order, float warp, int method, int kind, double* out);
+
 /* ---------------- filter banks (btk/modulated/modulated.cc) ---------------- */
 /* delayCompensationType: 0 default, 1, 2 (modulated.cc:279-296) */
 int  orc_fb_processing_delay(int m, int r, int dctype, int synthesis);

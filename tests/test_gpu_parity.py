@@ -410,3 +410,56 @@ def test_gmm_mfma_mode(dsr, oracle, cuda, K, R, D):
     same = am == arg
     assert same.mean() > 0.99999
     assert (np.abs(sc - ref)[same] / np.maximum(np.abs(ref[same]), 1.0)).max() < 1e-5
+
+
+# ------------------------------------------------------------------------------------------- LPC / MVDR envelopes
+def _ar_frames(T, dim, seed):
+    rng = np.random.default_rng(seed)
+    fr = np.zeros((T, dim), np.float32)
+    for t in range(T):
+        rad, th = rng.uniform(0.5, 0.95), rng.uniform(0.2, 2.8); a1, a2 = 2 * rad * np.cos(th), -rad * rad      # a stable resonance
+        e = rng.standard_normal(dim + 64) * 300.0; y = np.zeros(dim + 64)
+        for n in range(2, dim + 64):
+            y[n] = a1 * y[n - 1] + a2 * y[n - 2] + e[n]
+        fr[t] = (y[64:] * np.hamming(dim)).astype(np.float32)
+    return fr
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("method,kind,order,warp,dim", [
+    (0, 0, 20, 0.0, 320), (0, 0, 60, 0.4595, 320), (1, 0, 20, 0.0, 320), (0, 1, 13, 0.0, 320), (0, 1, 13, 0.3, 400),
+    (1, 1, 13, 0.0, 320), (1, 0, 40, 0.0, 512), (0, 0, 8, -0.2, 64),
+])
+def test_lpc_envelopes(dsr, oracle, cuda, method, kind, order, warp, dim):
+    """lpc.cc:44-207, lpc.h:134-195,291-331: the fp32 recursions are replayed in the reference's order (thread per frame), so the
+    envelopes agree with the oracle to the rounding of the fp64 DFT (1e-9 relative asserted; the oracle's DFT sums the same terms)."""
+    import torch
+    fr = _ar_frames(70, dim, seed=31 + order)
+    fr[3] = 0.0                                             # an all-zero frame: E[0] = 0 branches (lpc.cc:117-121, lpc.h:162-166)
+    want = oracle.lpc_feature(fr, order, warp, method, kind)
+    got = dsr.LpcEnvelope(dim, order, warp, method, kind).run(torch.from_numpy(fr).to(cuda)).cpu().numpy()
+    assert got.shape == want.shape
+    fin = np.isfinite(want)
+    assert np.array_equal(fin, np.isfinite(got))
+    np.testing.assert_allclose(got[fin], want[fin], rtol=1e-9, atol=0)
+
+
+@pytest.mark.gpu
+def test_lpc_feature_streams(dsr, oracle, cuda, headset):
+    """WarpMVDRFeaturePtr / BurgLPCFeaturePtr behind the stream protocol: Sample -> Hamming -> envelope."""
+    from dsr.btk import feature as F
+    x = headset[:16000].astype(np.float32)
+    samp = F.SampleFeaturePtr(blockLen=320, shiftLen=160, padZeros=False); samp.setSamples(x, 16000)
+    ham = F.HammingFeaturePtr(samp)
+    blocks = oracle.sample_blocks(x, 320, 160, False)
+    w = 0.54 - 0.46 * np.cos(2.0 * np.pi * np.arange(320) / 319.0)
+    fr = (blocks.astype(np.float64) * w).astype(np.float32)
+    for cls, method, kind in ((F.WarpMVDRFeaturePtr, 0, 0), (F.BurgLPCFeaturePtr, 1, 1)):
+        op = cls(ham, order=30, warp=0.0)
+        assert op.size() == 161
+        rows = [np.array(v) for v in op]
+        want = oracle.lpc_feature(fr, 30, 0.0, method, kind)
+        assert len(rows) == want.shape[0]
+        np.testing.assert_allclose(np.array(rows), want, rtol=1e-9)
+    with pytest.raises(Exception):
+        F.WarpLPCFeaturePtr(ham, order=161)                 # lpc.h:126-127: order >= dim/2+1
