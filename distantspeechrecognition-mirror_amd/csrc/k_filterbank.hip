@@ -599,6 +599,40 @@ template <int M> static void launch_synthesis(const FbPlan& p, const float* Y, c
   DSR_HIP(hipGetLastError());
 }
 
+// ---------------------------------------------------------------------------------------------
+// NormalFFTAnalysisBank (modulated.cc:121-257) with getWindow (modulated.cc:72-97): a windowed STFT.
+// Frame t transforms the M most recent samples in time order, x[(t+1)D - M + i] w[i], i = 0..M-1 (zeros before the
+// start and after the end), with the forward DFT (gsl_fft_complex_radix2_forward); all M bins are kept.
+// T = ceil(nsamp / D) + 1 frames (_processingDelay = 2 m - 1 = 1 zero-input frame).  One workgroup per FB frames.
+template <int M>
+__global__ __launch_bounds__(256) void k_normal_fft(const float* __restrict__ x, const int* __restrict__ nsampArr, const float* __restrict__ win,
+                                                     const float2* __restrict__ twG, float2* __restrict__ X, int C, long sampStride,
+                                                     int Tmax, int D, int FB)
+{
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  float2* tw = reinterpret_cast<float2*>(smem);
+  float2* bufA = tw + M; float2* bufB = bufA + (size_t) FB * M;
+  const int tid = threadIdx.x, nthr = blockDim.x;
+  const int c = blockIdx.y, u = blockIdx.z, t0 = blockIdx.x * FB;
+  const int nsamp = nsampArr[u];
+  const int Tu = (nsamp + D - 1) / D + 1;
+  const float* xs = x + ((long) u * C + c) * sampStride;
+  float2* Xo = X + ((long) u * C + c) * (long) Tmax * M;
+  for (int i = tid; i < M; i += nthr) tw[i] = twG[i];
+  for (int idx = tid; idx < FB * M; idx += nthr) {
+    const int fr = idx / M, i = idx - fr * M; const int t = t0 + fr;
+    const long n = (long) (t + 1) * D - M + i;
+    const float v = (t < Tu && n >= 0 && n < nsamp) ? xs[n] * win[i] : 0.0f;
+    bufA[idx] = make_float2(v, 0.0f);
+  }
+  __syncthreads();
+  float2* Z = fft_lds<M>(bufA, bufB, tw, 1, FB, -1, tid, nthr);
+  for (int idx = tid; idx < FB * M; idx += nthr) {
+    const int fr = idx / M, k = idx - fr * M; const int t = t0 + fr;
+    if (t < Tmax) Xo[(long) t * M + k] = (t < Tu) ? Z[idx] : make_float2(0.f, 0.f);
+  }
+}
+
 #define DSR_M_DISPATCH(M_, CALL) switch (M_) { \
   case 16: CALL(16); break; case 32: CALL(32); break; case 64: CALL(64); break; case 128: CALL(128); break; \
   case 256: CALL(256); break; case 512: CALL(512); break; case 1024: CALL(1024); break; case 2048: CALL(2048); break; \
@@ -648,6 +682,23 @@ void fb_analysis(const FbPlan& p, const float* x, const int* nsamp, int U, int C
   DSR_M_DISPATCH(p.M, CALL)
 #undef CALL
 }
+template <int M> static void launch_normal_fft(const float* x, const int* nsamp, const float* win, const float2* tw, int U, int C, long sampStride,
+                                               int Tmax, int D, float* X, hipStream_t st)
+{
+  int FB = 2048 / M; if (FB < 1) FB = 1;
+  const size_t lds = sizeof(float2) * ((size_t) M + 2 * (size_t) FB * M);
+  DSR_HIP(hipFuncSetAttribute((const void*) k_normal_fft<M>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
+  dim3 grid(cdiv(Tmax, FB), C, U);
+  hipLaunchKernelGGL(k_normal_fft<M>, grid, dim3(256), lds, st, x, nsamp, win, tw, (float2*) X, C, sampStride, Tmax, D, FB);
+  DSR_HIP(hipGetLastError());
+}
+void fb_normal_fft(int M, const float* x, const int* nsamp, const float* win, const float2* tw, int U, int C, long sampStride, int Tmax, int D,
+                   float* X, hipStream_t st)
+{
+#define CALL(MM) launch_normal_fft<MM>(x, nsamp, win, tw, U, C, sampStride, Tmax, D, X, st)
+  DSR_M_DISPATCH(M, CALL)
+#undef CALL
+}
 void fb_synthesis(const FbPlan& p, const float* Y, const int* nframes, int U, int Tmax, long outStride, float* y, hipStream_t st)
 {
 #define CALL(MM) launch_synthesis<MM>(p, Y, nframes, U, Tmax, outStride, y, st)
@@ -661,6 +712,44 @@ using namespace dsr;
 struct dsr_fb : FbPlan {};
 
 extern "C" {
+
+// NormalFFTAnalysisBank (modulated.cc:121-257): windowType 0 rectangle, 1 Hamming (default), 2 Hanning (getWindow, :72-97)
+struct dsr_stft { int M, r, D, winType; DevBuf<float> win; DevBuf<float2> tw; };
+dsr_status dsr_stft_create(int M, int r, int windowType, dsr_stft** out)
+{
+  return guard([&] {
+    if (!out) throw Error(DSR_E_PARAMETER, "null argument");
+    if (!is_pow2((unsigned) M) || M < 16 || M > 2048) throw Error(DSR_E_DIMENSION, "M=%d must be a power of two in [16,2048]", M);
+    if (r < 0 || (M >> r) < 1) throw Error(DSR_E_DIMENSION, "bad r=%d", r);
+    require_device();
+    dsr_stft* p = new dsr_stft(); p->M = M; p->r = r; p->D = M >> r; p->winType = windowType;
+    std::vector<float> w(M); std::vector<float2> tw(M);
+    for (int i = 0; i < M; i++) {
+      double v;
+      switch (windowType) {
+      case 0: v = 1.0; break;
+      case 2: v = 0.5 * (1 - cos((2.0 * M_PI * i) / (double) (M - 1))); break;
+      default: { const double temp = 2. * M_PI / (double) (M - 1); v = 0.54 - 0.46 * cos(temp * i); } break;
+      }
+      w[i] = (float) v;
+      const double a = 2.0 * M_PI * (double) i / (double) M; tw[i] = make_float2((float) cos(a), (float) sin(a));
+    }
+    p->win.upload(w); p->tw.upload(tw);
+    *out = p;
+  });
+}
+void dsr_stft_destroy(dsr_stft* p) { delete p; }
+int dsr_stft_frames(const dsr_stft* p, int nsamp) { return p ? (nsamp + p->D - 1) / p->D + 1 : 0; }
+int dsr_stft_block_len(const dsr_stft* p) { return p ? p->D : 0; }
+dsr_status dsr_stft_analysis(const dsr_stft* p, const float* x, const int32_t* nsamp_dev, int U, int C, int64_t sampStride, int Tmax,
+                             float* X, void* stream)
+{
+  return guard([&] {
+    if (!p || !x || !nsamp_dev || !X) throw Error(DSR_E_PARAMETER, "null argument");
+    if (U <= 0 || C <= 0 || Tmax <= 0) return;
+    fb_normal_fft(p->M, x, nsamp_dev, p->win.p, p->tw.p, U, C, sampStride, Tmax, p->D, X, (hipStream_t) stream);
+  });
+}
 
 dsr_status dsr_fb_create(const double* prototype, int M, int m, int r, int synthesis, int dctype, int gain, dsr_fb** out)
 {

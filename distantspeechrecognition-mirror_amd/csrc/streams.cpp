@@ -14,7 +14,7 @@
 
 using namespace dsr;
 
-struct dsr_fb; struct dsr_bf; struct dsr_lpc;
+struct dsr_fb; struct dsr_bf; struct dsr_lpc; struct dsr_stft;
 
 struct dsr_stream {
   int refs = 1; std::string name; int size_ = 0; int type = DSR_T_FLOAT; int frameX = -1; bool endOfSamples = false;
@@ -128,6 +128,19 @@ struct AnalysisOp : dsr_stream {     // OverSampledDFTAnalysisBank
     }
   }
 };
+struct StftOp : dsr_stream {         // NormalFFTAnalysisBank (modulated.cc:121-257)
+  dsr_stft* plan = nullptr; int M, D; DevBuf<float> x; DevBuf<float2> X; DevBuf<int> ns;
+  ~StftOp() override { if (plan) dsr_stft_destroy(plan); }
+  void compute() override {
+    dsr_stream* u = ups[0]; const int nblk = u->nFrames; const int n = nblk * D;
+    const int T = dsr_stft_frames(plan, n); alloc(T);
+    x.reserve(n > 0 ? n : 1); if (n > 0) DSR_HIP(hipMemcpy(x.p, u->dev.p, (size_t) n * sizeof(float), hipMemcpyDeviceToDevice));
+    ns.upload(&n, 1);
+    X.reserve((size_t) T * M);
+    dsr_status s = dsr_stft_analysis(plan, x.p, ns.p, 1, 1, n > 0 ? n : 1, T, (float*) X.p, S0); if (s) throw Error(s, "%s", dsr_last_error());
+    op_expand_bins(X.p, T, M, M, d<double2>(), S0);          // all M bins are already there: widen to complex128
+  }
+};
 struct SynthesisOp : dsr_stream {    // OverSampledDFTSynthesisBank
   dsr_fb* fb = nullptr; int M, D; DevBuf<float2> Y; DevBuf<int> nf;
   ~SynthesisOp() override { if (fb) dsr_fb_destroy(fb); }
@@ -223,6 +236,17 @@ dsr_status dsr_analysis_bank_create(dsr_stream* samp, const double* prototype, i
     if (samp->size_ != D) throw Error(DSR_E_DIMENSION, "Input block length (%d) != _D (%d)", samp->size_, D);      // modulated.cc:373-374
     AnalysisOp* s = mk<AnalysisOp>(name, "OverSampledDFTAnalysisBank", M, DSR_T_COMPLEX); s->M = M; s->D = D; s->checkOrder = false;
     dsr_status st = dsr_fb_create(prototype, M, m, r, 0, dct, 1, &s->fb); if (st) { delete s; throw Error(st, "%s", dsr_last_error()); }
+    s->add_up(samp); *out = s;
+  });
+}
+dsr_status dsr_normal_fft_bank_create(dsr_stream* samp, int M, int r, int windowType, const char* name, dsr_stream** out)
+{
+  return guard([&] {
+    need(samp, DSR_T_FLOAT, "NormalFFTAnalysisBank"); if (!out) throw Error(DSR_E_PARAMETER, "null argument");
+    const int D = M >> r;
+    if (samp->size_ != D) throw Error(DSR_E_DIMENSION, "Input block length (%d) != _D (%d)", samp->size_, D);      // modulated.cc:138-139
+    StftOp* s = mk<StftOp>(name, "NormalFFTAnalysisBank", M, DSR_T_COMPLEX); s->M = M; s->D = D; s->checkOrder = false;
+    dsr_status st = dsr_stft_create(M, r, windowType, &s->plan); if (st) { delete s; throw Error(st, "%s", dsr_last_error()); }
     s->add_up(samp); *out = s;
   });
 }

@@ -71,6 +71,8 @@ def load():
         "dsr_bf_calc_mvdr_weights": [vp, f64, f64], "dsr_bf_calc_gsc_weights": [vp, f64, vp],
         "dsr_bf_set_active_weights": [vp, C.c_int, vp], "dsr_bf_zero_active_weights": [vp], "dsr_bf_select": [vp, C.c_int],
         "dsr_bf_get": [vp, C.c_int, vp, C.c_size_t], "dsr_bf_apply": [vp, vp, C.c_int, C.c_int, vp, vp],
+        "dsr_stft_create": [C.c_int, C.c_int, C.c_int, vp], "dsr_stft_destroy": [vp], "dsr_stft_frames": [vp, C.c_int], "dsr_stft_block_len": [vp],
+        "dsr_stft_analysis": [vp, vp, vp, C.c_int, C.c_int, i64, C.c_int, vp, vp],
         "dsr_lpc_create": [C.c_int, C.c_int, C.c_int, f32, C.c_int, C.c_int, vp], "dsr_lpc_destroy": [vp], "dsr_lpc_size": [vp],
         "dsr_lpc_run": [vp, vp, i64, vp, vp],
         "dsr_mfcc_default_cfg": [vp], "dsr_mfcc_create": [vp, vp, vp], "dsr_mfcc_destroy": [vp], "dsr_mfcc_frames": [vp, C.c_int],
@@ -240,6 +242,32 @@ def calcDelaysPolar2(azimuth, elevation, micPositions):
     mp = _np(micPositions, np.float64); d = np.zeros(mp.shape[0], np.float64)
     check(_lib.dsr_calc_delays_polar2(azimuth, elevation, _ptr(mp), mp.shape[0], _ptr(d)))
     return d
+
+
+class NormalFFTBank:
+    """NormalFFTAnalysisBank (modulated.cc:121-257): windowed STFT, windowType 0 rectangle / 1 Hamming / 2 Hanning."""
+
+    def __init__(self, M, r, windowType=1):
+        L = load(); self.h = vp(); self.M = M
+        check(L.dsr_stft_create(M, r, windowType, C.byref(self.h)))
+
+    def __del__(self):
+        if _lib is not None and getattr(self, "h", None):
+            _lib.dsr_stft_destroy(self.h)
+
+    def frames(self, nsamp):
+        return _lib.dsr_stft_frames(self.h, int(nsamp))
+
+    def analysis(self, x, nsamp=None):
+        """x: cuda float32 [U][C][N] -> complex64 [U][C][T][M]"""
+        import torch
+        U, Cn, N = x.shape
+        if nsamp is None:
+            nsamp = torch.full((U,), N, dtype=torch.int32, device=x.device)
+        T = max(1, max(self.frames(int(n)) for n in nsamp.tolist()))
+        X = torch.zeros((U, Cn, T, self.M), dtype=torch.complex64, device=x.device)
+        check(_lib.dsr_stft_analysis(self.h, _dev(x), _dev(nsamp), U, Cn, N, T, _dev(X), cur_stream()))
+        return X
 
 
 class LpcEnvelope:

@@ -19,6 +19,17 @@ class OverSampledDFTAnalysisBankPtr(FeatureStreamPtr):
         return self._M
 
 
+class NormalFFTAnalysisBankPtr(FeatureStreamPtr):
+    """modulated.i: NormalFFTAnalysisBankPtr(samp, fftLen, r=1, windowType=1, nm=...) (modulated.cc:121-257)."""
+
+    def __init__(self, samp, fftLen, r=1, windowType=1, nm="NormalFFTAnalysisBank"):
+        h, _ = _new(lib().dsr_normal_fft_bank_create, samp._h, int(fftLen), int(r), int(windowType), nm.encode())
+        FeatureStreamPtr.__init__(self, h, keep=(samp,)); self._M = fftLen
+
+    def fftLen(self):
+        return self._M
+
+
 class OverSampledDFTSynthesisBankPtr(FeatureStreamPtr):
     def __init__(self, samp, prototype, M, m, r=0, delayCompensationType=0, gainFactor=1, nm="OverSampledDFTSynthesisBank"):
         p = np.ascontiguousarray(prototype, dtype=np.float64)

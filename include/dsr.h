@@ -259,6 +259,17 @@ dsr_status dsr_pipe_stage_ms(const dsr_pipe*, float ms[6]);
 /* device pointers to the intermediates of the last run (borrowed): 0 X, 1 Y, 2 y, 3 feat, 4 scores */
 dsr_status dsr_pipe_intermediate(const dsr_pipe*, int which, void** dev, int64_t* bytes);
 
+/* NormalFFTAnalysisBank (btk/modulated/modulated.cc:121-257) with getWindow (:72-97): windowed STFT, all M bins.
+ * windowType 0 rectangle, 1 Hamming, 2 Hanning.  x_dev [U][C][sampStride] -> X_dev [U][C][Tmax][M] complex64;
+ * frames(nsamp) = ceil(nsamp / D) + 1 (one zero-input frame, _processingDelay = 1), D = M >> r. */
+typedef struct dsr_stft dsr_stft;
+dsr_status dsr_stft_create(int M, int r, int windowType, dsr_stft** out);
+void       dsr_stft_destroy(dsr_stft*);
+int        dsr_stft_frames(const dsr_stft*, int nsamp);
+int        dsr_stft_block_len(const dsr_stft*);
+dsr_status dsr_stft_analysis(const dsr_stft*, const float* x_dev, const int32_t* nsamp_dev, int U, int C,
+                             int64_t sampStride, int Tmax, float* X_dev, void* stream);
+
 /* =====================================================================================
  * 6b. LPC / MVDR spectral envelopes  (btk/feature/lpc.cc:44-207, lpc.h:134-195,291-331:
  *     WarpMVDRFeature, BurgMVDRFeature, WarpLPCFeature, BurgLPCFeature)
@@ -302,6 +313,8 @@ dsr_status dsr_analysis_bank_create(dsr_stream* samp, const double* prototype, i
                                     int delayCompensationType, const char* name, dsr_stream** out);
 dsr_status dsr_synthesis_bank_create(dsr_stream* samp, const double* prototype, int M, int m, int r,
                                      int delayCompensationType, int gainFactor, const char* name, dsr_stream** out);
+/* NormalFFTAnalysisBank(samp, M, r, windowType) (modulated.i); samp delivers blocks of D = M >> r samples */
+dsr_status dsr_normal_fft_bank_create(dsr_stream* samp, int M, int r, int windowType, const char* name, dsr_stream** out);
 /* SubbandDS/GSC/MVDR as a stream: channels are analysis-bank streams (setChannel) */
 dsr_status dsr_subband_bf_create(dsr_bf* weights, const char* name, dsr_stream** out);
 dsr_status dsr_subband_bf_set_channel(dsr_stream* bf, dsr_stream* chan);

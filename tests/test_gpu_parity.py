@@ -463,3 +463,28 @@ def test_lpc_feature_streams(dsr, oracle, cuda, headset):
         np.testing.assert_allclose(np.array(rows), want, rtol=1e-9)
     with pytest.raises(Exception):
         F.WarpLPCFeaturePtr(ham, order=161)                 # lpc.h:126-127: order >= dim/2+1
+
+
+# ------------------------------------------------------------------------------------------- NormalFFTAnalysisBank
+@pytest.mark.gpu
+@pytest.mark.parametrize("M,r,win", [(256, 1, 1), (512, 2, 2), (64, 0, 0), (128, 3, 1)])
+def test_normal_fft_bank(dsr, oracle, cuda, headset, M, r, win):
+    """modulated.cc:72-97,121-257: windowed STFT (all M bins), fp32 on the device vs the fp64 oracle: 2e-5 of the frame RMS."""
+    import torch
+    x = headset[3000:3000 + 4000 + 37].astype(np.float32)              # ragged: not a multiple of D
+    want = oracle.normal_fft_bank(x, M, r, winType=win)
+    bank = dsr.NormalFFTBank(M, r, win)
+    xs = np.stack([x, x[::-1].copy()])[None]                          # [U=1][C=2][N]
+    got = bank.analysis(torch.from_numpy(xs).to(cuda)).cpu().numpy()
+    assert got.shape[2:] == want.shape
+    rms = np.sqrt(np.mean(np.abs(want) ** 2))
+    assert np.abs(got[0, 0] - want).max() < 2e-5 * rms * np.sqrt(M)
+    want2 = oracle.normal_fft_bank(x[::-1].copy(), M, r, winType=win)
+    assert np.abs(got[0, 1] - want2).max() < 2e-5 * rms * np.sqrt(M)
+    # the operator behind the stream protocol
+    from dsr.btk import feature as F, modulated as Mo
+    D = M >> r
+    samp = F.SampleFeaturePtr(blockLen=D, shiftLen=D, padZeros=True); samp.setSamples(x, 16000)
+    rows = np.array([np.array(v) for v in Mo.NormalFFTAnalysisBankPtr(samp, M, r, win)])
+    assert rows.shape == want.shape and rows.dtype == np.complex128
+    assert np.abs(rows - want).max() < 2e-5 * rms * np.sqrt(M)
