@@ -633,6 +633,105 @@ __global__ __launch_bounds__(256) void k_normal_fft(const float* __restrict__ x,
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// PerfectReconstructionFFTAnalysisBank / ...SynthesisBank (modulated.cc:686-970): the 2M-band cosine-modulated pair.
+// Closed forms of the reference's ring buffers (checked against the literal restatement in oracle/):
+//   analysis   u_t[i] = sum_k (-1)^k h[i + 2M k] x[n_t - i - (r+2) k D],  n_t = (t+1) D - 1,  i = 0..2M-1
+//              X_t = (1/2M) sum_i w_i u_t[i] e^{+2 pi j f i / 2M},  w_i = e^{-j pi i / 2M};   T = ceil(nsamp/D) + 2m - 1
+//   synthesis  V_t[i] = Re( (sum_f Y_t[f] e^{-2 pi j f i / 2M}) e^{+j pi i / 2M} )
+//              c_t[i] = sum_k s_k g[i + 2M (m-k-1)] V_{t-(r+2)k}[i],  s_0 = +1 (m odd) / -1 (m even), alternating; t >= 2m-1
+//              y_b[D-1-d] = (1/R) sum_{s<2R} c_{b+2m-1-(2R-1-s)}[d + s D],  b = 0..T-2m
+// (the (r+2) k D spacing of the taps -- not 2M k for r > 0 -- is the reference's, modulated.cc:744,938.)
+template <int M2>
+__global__ __launch_bounds__(256) void k_pr_analysis(const float* __restrict__ x, const int* __restrict__ nsampArr, const float* __restrict__ h,
+                                                      const float2* __restrict__ twG, const float2* __restrict__ wG, float2* __restrict__ X,
+                                                      int C, long sampStride, int Tmax, int D, int m, int r, int FB)
+{
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  float2* tw = reinterpret_cast<float2*>(smem);
+  float2* bufA = tw + M2; float2* bufB = bufA + (size_t) FB * M2;
+  const int tid = threadIdx.x, nthr = blockDim.x;
+  const int c = blockIdx.y, u = blockIdx.z, t0 = blockIdx.x * FB;
+  const int nsamp = nsampArr[u];
+  const int Tu = (nsamp + D - 1) / D + 2 * m - 1;
+  const float* xs = x + ((long) u * C + c) * sampStride;
+  float2* Xo = X + ((long) u * C + c) * (long) Tmax * M2;
+  for (int i = tid; i < M2; i += nthr) tw[i] = twG[i];
+  for (int idx = tid; idx < FB * M2; idx += nthr) {
+    const int fr = idx / M2, i = idx - fr * M2; const int t = t0 + fr;
+    float sum = 0.0f;
+    if (t < Tu) {
+      const long nt = (long) (t + 1) * D - 1 - i;
+      float flip = 1.0f;
+      for (int k = 0; k < m; k++) {
+        const long n = nt - (long) (r + 2) * k * D;
+        if (n >= 0 && n < nsamp) sum += flip * h[i + M2 * k] * xs[n];
+        flip = -flip;
+      }
+    }
+    const float2 w = wG[i];
+    bufA[idx] = make_float2(w.x * sum, w.y * sum);
+  }
+  __syncthreads();
+  float2* Z = fft_lds<M2>(bufA, bufB, tw, 1, FB, +1, tid, nthr);
+  const float sc = 1.0f / (float) M2;
+  for (int idx = tid; idx < FB * M2; idx += nthr) {
+    const int fr = idx / M2, k = idx - fr * M2; const int t = t0 + fr;
+    if (t < Tmax) Xo[(long) t * M2 + k] = (t < Tu) ? make_float2(Z[idx].x * sc, Z[idx].y * sc) : make_float2(0.f, 0.f);
+  }
+}
+
+// synthesis, step 1: V_t[i] for every input frame
+template <int M2>
+__global__ __launch_bounds__(256) void k_pr_synth_fft(const float2* __restrict__ Y, const int* __restrict__ nframesArr, const float2* __restrict__ twG,
+                                                       const float2* __restrict__ wG, float* __restrict__ V, int Tmax, int FB)
+{
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  float2* tw = reinterpret_cast<float2*>(smem);
+  float2* bufA = tw + M2; float2* bufB = bufA + (size_t) FB * M2;
+  const int tid = threadIdx.x, nthr = blockDim.x;
+  const int u = blockIdx.y, t0 = blockIdx.x * FB;
+  const int T = nframesArr[u] < Tmax ? nframesArr[u] : Tmax;
+  const float2* Yi = Y + (long) u * Tmax * M2; float* Vo = V + (long) u * Tmax * M2;
+  for (int i = tid; i < M2; i += nthr) tw[i] = twG[i];
+  for (int idx = tid; idx < FB * M2; idx += nthr) { const int t = t0 + idx / M2; bufA[idx] = (t < T) ? Yi[(long) t0 * M2 + idx] : make_float2(0.f, 0.f); }
+  __syncthreads();
+  float2* Z = fft_lds<M2>(bufA, bufB, tw, 1, FB, -1, tid, nthr);
+  for (int idx = tid; idx < FB * M2; idx += nthr) {
+    const int fr = idx / M2, i = idx - fr * M2; const int t = t0 + fr;
+    if (t < Tmax) { const float2 w = wG[i]; Vo[(long) t * M2 + i] = (t < T) ? Z[idx].x * w.x - Z[idx].y * w.y : 0.0f; }
+  }
+}
+// synthesis, step 2: one thread per output sample
+__global__ void k_pr_synth_out(const float* __restrict__ V, const int* __restrict__ nframesArr, const float* __restrict__ g, float* __restrict__ y,
+                               int Tmax, int M2, int D, int m, int r, long outStride)
+{
+  const int u = blockIdx.y; const long j = (long) blockIdx.x * blockDim.x + threadIdx.x;
+  const int T = nframesArr[u] < Tmax ? nframesArr[u] : Tmax;
+  const int pd = 2 * m - 1, R = 1 << r, R2 = 2 * R;
+  const long nout = (T > pd) ? (long) (T - pd) * D : 0;
+  if (j >= outStride) return;
+  float o = 0.0f;
+  if (j < nout) {
+    const int b = (int) (j / D), dd = (int) (j - (long) b * D), d = D - 1 - dd;          // y_b[D-1-d]
+    const float* Vu = V + (long) u * Tmax * M2;
+    const float invR = 1.0f / (float) R;
+    for (int s = 0; s < R2; s++) {
+      const int tc = b + pd - (R2 - 1 - s);
+      if (tc < pd) continue;                                     // the sample ring is still empty there
+      const int i = d + s * D;
+      float conv = 0.0f, flip = (m & 1) ? 1.0f : -1.0f;
+      for (int k = 0; k < m; k++) {
+        const int tv = tc - (r + 2) * k;
+        if (tv >= 0) conv += flip * g[i + M2 * (m - k - 1)] * Vu[(long) tv * M2 + i];
+        flip = -flip;
+      }
+      o += conv * invR;
+    }
+  }
+  y[(long) u * outStride + j] = o;
+}
+
 #define DSR_M_DISPATCH(M_, CALL) switch (M_) { \
   case 16: CALL(16); break; case 32: CALL(32); break; case 64: CALL(64); break; case 128: CALL(128); break; \
   case 256: CALL(256); break; case 512: CALL(512); break; case 1024: CALL(1024); break; case 2048: CALL(2048); break; \
@@ -699,6 +798,23 @@ void fb_normal_fft(int M, const float* x, const int* nsamp, const float* win, co
   DSR_M_DISPATCH(M, CALL)
 #undef CALL
 }
+struct PrPlan { int M, m, r, D; DevBuf<float> h; DevBuf<float2> tw, wA, wS; DevBuf<float> V; };
+template <int M2> static void launch_pr_analysis(const PrPlan& p, const float* x, const int* nsamp, int U, int C, long sampStride, int Tmax, float* X, hipStream_t st)
+{
+  int FB = 2048 / M2; if (FB < 1) FB = 1;
+  const size_t lds = sizeof(float2) * ((size_t) M2 + 2 * (size_t) FB * M2);
+  DSR_HIP(hipFuncSetAttribute((const void*) k_pr_analysis<M2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
+  hipLaunchKernelGGL(k_pr_analysis<M2>, dim3(cdiv(Tmax, FB), C, U), dim3(256), lds, st, x, nsamp, p.h.p, p.tw.p, p.wA.p, (float2*) X, C, sampStride, Tmax, p.D, p.m, p.r, FB);
+  DSR_HIP(hipGetLastError());
+}
+template <int M2> static void launch_pr_synth_fft(PrPlan& p, const float* Y, const int* nframes, int U, int Tmax, hipStream_t st)
+{
+  int FB = 2048 / M2; if (FB < 1) FB = 1;
+  const size_t lds = sizeof(float2) * ((size_t) M2 + 2 * (size_t) FB * M2);
+  DSR_HIP(hipFuncSetAttribute((const void*) k_pr_synth_fft<M2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
+  hipLaunchKernelGGL(k_pr_synth_fft<M2>, dim3(cdiv(Tmax, FB), U), dim3(256), lds, st, (const float2*) Y, nframes, p.tw.p, p.wS.p, p.V.p, Tmax, FB);
+  DSR_HIP(hipGetLastError());
+}
 void fb_synthesis(const FbPlan& p, const float* Y, const int* nframes, int U, int Tmax, long outStride, float* y, hipStream_t st)
 {
 #define CALL(MM) launch_synthesis<MM>(p, Y, nframes, U, Tmax, outStride, y, st)
@@ -712,6 +828,59 @@ using namespace dsr;
 struct dsr_fb : FbPlan {};
 
 extern "C" {
+
+// PerfectReconstructionFFTAnalysisBank / SynthesisBank (modulated.cc:686-970)
+struct dsr_prfb : PrPlan {};
+dsr_status dsr_prfb_create(const double* prototype, int M, int m, int r, dsr_prfb** out)
+{
+  return guard([&] {
+    if (!out || !prototype) throw Error(DSR_E_PARAMETER, "null argument");
+    if (!is_pow2((unsigned) M) || M < 8 || M > 1024) throw Error(DSR_E_DIMENSION, "M=%d must be a power of two in [8,1024]", M);
+    if (m < 1 || r < 0 || (M >> r) < 1) throw Error(DSR_E_DIMENSION, "bad m=%d r=%d", m, r);
+    require_device();
+    dsr_prfb* p = new dsr_prfb(); p->M = M; p->m = m; p->r = r; p->D = M >> r;
+    const int M2 = 2 * M;
+    std::vector<float> h((size_t) M2 * m); for (size_t i = 0; i < h.size(); i++) h[i] = (float) prototype[i];
+    std::vector<float2> tw(M2), wA(M2), wS(M2);
+    for (int i = 0; i < M2; i++) {
+      const double a = 2.0 * M_PI * (double) i / (double) M2, b = M_PI * (double) i / (double) M2;
+      tw[i] = make_float2((float) cos(a), (float) sin(a)); wA[i] = make_float2((float) cos(b), (float) -sin(b)); wS[i] = make_float2((float) cos(b), (float) sin(b));
+    }
+    p->h.upload(h); p->tw.upload(tw); p->wA.upload(wA); p->wS.upload(wS);
+    *out = p;
+  });
+}
+void dsr_prfb_destroy(dsr_prfb* p) { delete p; }
+int dsr_prfb_fft_len(const dsr_prfb* p) { return p ? 2 * p->M : 0; }
+int dsr_prfb_block_len(const dsr_prfb* p) { return p ? p->D : 0; }
+int dsr_prfb_analysis_frames(const dsr_prfb* p, int nsamp) { return p ? (nsamp + p->D - 1) / p->D + 2 * p->m - 1 : 0; }
+int dsr_prfb_synthesis_blocks(const dsr_prfb* p, int nframes) { return (p && nframes > 2 * p->m - 1) ? nframes - (2 * p->m - 1) : 0; }
+dsr_status dsr_prfb_analysis(const dsr_prfb* p, const float* x, const int32_t* nsamp_dev, int U, int C, int64_t sampStride, int Tmax, float* X, void* stream)
+{
+  return guard([&] {
+    if (!p || !x || !nsamp_dev || !X) throw Error(DSR_E_PARAMETER, "null argument");
+    if (U <= 0 || C <= 0 || Tmax <= 0) return;
+    hipStream_t st = (hipStream_t) stream;
+#define CALL(MM) launch_pr_analysis<MM>(*p, x, nsamp_dev, U, C, sampStride, Tmax, X, st)
+    DSR_M_DISPATCH(2 * p->M, CALL)
+#undef CALL
+  });
+}
+dsr_status dsr_prfb_synthesis(dsr_prfb* p, const float* Y, const int32_t* nframes_dev, int U, int Tmax, int64_t outStride, float* y, void* stream)
+{
+  return guard([&] {
+    if (!p || !Y || !nframes_dev || !y) throw Error(DSR_E_PARAMETER, "null argument");
+    if (U <= 0 || Tmax <= 0 || outStride <= 0) return;
+    hipStream_t st = (hipStream_t) stream;
+    p->V.reserve((size_t) U * Tmax * 2 * p->M);
+#define CALL(MM) launch_pr_synth_fft<MM>(*p, Y, nframes_dev, U, Tmax, st)
+    DSR_M_DISPATCH(2 * p->M, CALL)
+#undef CALL
+    hipLaunchKernelGGL(k_pr_synth_out, dim3((unsigned) ((outStride + 255) / 256), U), dim3(256), 0, st, p->V.p, nframes_dev, p->h.p, y, Tmax, 2 * p->M, p->D, p->m,
+                       p->r, (long) outStride);
+    DSR_HIP(hipGetLastError());
+  });
+}
 
 // NormalFFTAnalysisBank (modulated.cc:121-257): windowType 0 rectangle, 1 Hamming (default), 2 Hanning (getWindow, :72-97)
 struct dsr_stft { int M, r, D, winType; DevBuf<float> win; DevBuf<float2> tw; };

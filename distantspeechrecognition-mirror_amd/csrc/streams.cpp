@@ -14,7 +14,7 @@
 
 using namespace dsr;
 
-struct dsr_fb; struct dsr_bf; struct dsr_lpc; struct dsr_stft;
+struct dsr_fb; struct dsr_bf; struct dsr_lpc; struct dsr_stft; struct dsr_prfb;
 
 struct dsr_stream {
   int refs = 1; std::string name; int size_ = 0; int type = DSR_T_FLOAT; int frameX = -1; bool endOfSamples = false;
@@ -152,6 +152,29 @@ struct SynthesisOp : dsr_stream {    // OverSampledDFTSynthesisBank
     dsr_status s = dsr_fb_synthesis(fb, (const float*) Y.p, nf.p, 1, Tin, (int64_t) nb * D, d<float>(), S0); if (s) throw Error(s, "%s", dsr_last_error());
   }
 };
+struct PrAnalysisOp : dsr_stream {   // PerfectReconstructionFFTAnalysisBank (modulated.cc:686-818)
+  dsr_prfb* fb = nullptr; int M2, D; DevBuf<float> x; DevBuf<float2> X; DevBuf<int> ns;
+  ~PrAnalysisOp() override { if (fb) dsr_prfb_destroy(fb); }
+  void compute() override {
+    dsr_stream* u = ups[0]; const int nblk = u->nFrames; const int n = nblk * D;
+    const int T = dsr_prfb_analysis_frames(fb, n); alloc(T);
+    x.reserve(n > 0 ? n : 1); if (n > 0) DSR_HIP(hipMemcpy(x.p, u->dev.p, (size_t) n * sizeof(float), hipMemcpyDeviceToDevice));
+    ns.upload(&n, 1); X.reserve((size_t) T * M2);
+    dsr_status s = dsr_prfb_analysis(fb, x.p, ns.p, 1, 1, n > 0 ? n : 1, T, (float*) X.p, S0); if (s) throw Error(s, "%s", dsr_last_error());
+    op_expand_bins(X.p, T, M2, M2, d<double2>(), S0);
+  }
+};
+struct PrSynthesisOp : dsr_stream {  // PerfectReconstructionFFTSynthesisBank (modulated.cc:820-970)
+  dsr_prfb* fb = nullptr; int M2, D; DevBuf<float2> Y; DevBuf<int> nf;
+  ~PrSynthesisOp() override { if (fb) dsr_prfb_destroy(fb); }
+  void compute() override {
+    dsr_stream* u = ups[0]; const int Tin = u->nFrames; const int nb = dsr_prfb_synthesis_blocks(fb, Tin); alloc(nb);
+    if (nb <= 0) return;
+    Y.reserve((size_t) Tin * M2); op_pack_bins(u->d<double2>(), Tin, M2, M2, Y.p, S0);
+    nf.upload(&Tin, 1);
+    dsr_status s = dsr_prfb_synthesis(fb, (const float*) Y.p, nf.p, 1, Tin, (int64_t) nb * D, d<float>(), S0); if (s) throw Error(s, "%s", dsr_last_error());
+  }
+};
 struct BfOp : dsr_stream {           // SubbandDS / SubbandGSC / SubbandMVDR as a stream
   dsr_bf* w; int M; DevBuf<float2> X, Y;
   void compute() override {
@@ -236,6 +259,27 @@ dsr_status dsr_analysis_bank_create(dsr_stream* samp, const double* prototype, i
     if (samp->size_ != D) throw Error(DSR_E_DIMENSION, "Input block length (%d) != _D (%d)", samp->size_, D);      // modulated.cc:373-374
     AnalysisOp* s = mk<AnalysisOp>(name, "OverSampledDFTAnalysisBank", M, DSR_T_COMPLEX); s->M = M; s->D = D; s->checkOrder = false;
     dsr_status st = dsr_fb_create(prototype, M, m, r, 0, dct, 1, &s->fb); if (st) { delete s; throw Error(st, "%s", dsr_last_error()); }
+    s->add_up(samp); *out = s;
+  });
+}
+dsr_status dsr_pr_analysis_bank_create(dsr_stream* samp, const double* prototype, int M, int m, int r, const char* name, dsr_stream** out)
+{
+  return guard([&] {
+    need(samp, DSR_T_FLOAT, "PerfectReconstructionFFTAnalysisBank"); if (!out || !prototype) throw Error(DSR_E_PARAMETER, "null argument");
+    const int D = M >> r;
+    if (samp->size_ != D) throw Error(DSR_E_DIMENSION, "Input block length (%d) != _D (%d)", samp->size_, D);
+    PrAnalysisOp* s = mk<PrAnalysisOp>(name, "PerfectReconstructionFFTAnalysisBank", 2 * M, DSR_T_COMPLEX); s->M2 = 2 * M; s->D = D; s->checkOrder = false;
+    dsr_status st = dsr_prfb_create(prototype, M, m, r, &s->fb); if (st) { delete s; throw Error(st, "%s", dsr_last_error()); }
+    s->add_up(samp); *out = s;
+  });
+}
+dsr_status dsr_pr_synthesis_bank_create(dsr_stream* samp, const double* prototype, int M, int m, int r, const char* name, dsr_stream** out)
+{
+  return guard([&] {
+    need(samp, DSR_T_COMPLEX, "PerfectReconstructionFFTSynthesisBank"); if (!out || !prototype) throw Error(DSR_E_PARAMETER, "null argument");
+    if (samp->size_ != 2 * M) throw Error(DSR_E_DIMENSION, "Input size (%d) != 2M (%d)", samp->size_, 2 * M);
+    PrSynthesisOp* s = mk<PrSynthesisOp>(name, "PerfectReconstructionFFTSynthesisBank", M >> r, DSR_T_FLOAT); s->M2 = 2 * M; s->D = M >> r; s->checkOrder = false;
+    dsr_status st = dsr_prfb_create(prototype, M, m, r, &s->fb); if (st) { delete s; throw Error(st, "%s", dsr_last_error()); }
     s->add_up(samp); *out = s;
   });
 }

@@ -71,6 +71,9 @@ def load():
         "dsr_bf_calc_mvdr_weights": [vp, f64, f64], "dsr_bf_calc_gsc_weights": [vp, f64, vp],
         "dsr_bf_set_active_weights": [vp, C.c_int, vp], "dsr_bf_zero_active_weights": [vp], "dsr_bf_select": [vp, C.c_int],
         "dsr_bf_get": [vp, C.c_int, vp, C.c_size_t], "dsr_bf_apply": [vp, vp, C.c_int, C.c_int, vp, vp],
+        "dsr_prfb_create": [vp, C.c_int, C.c_int, C.c_int, vp], "dsr_prfb_destroy": [vp], "dsr_prfb_fft_len": [vp], "dsr_prfb_block_len": [vp],
+        "dsr_prfb_analysis_frames": [vp, C.c_int], "dsr_prfb_synthesis_blocks": [vp, C.c_int],
+        "dsr_prfb_analysis": [vp, vp, vp, C.c_int, C.c_int, i64, C.c_int, vp, vp], "dsr_prfb_synthesis": [vp, vp, vp, C.c_int, C.c_int, i64, vp, vp],
         "dsr_stft_create": [C.c_int, C.c_int, C.c_int, vp], "dsr_stft_destroy": [vp], "dsr_stft_frames": [vp, C.c_int], "dsr_stft_block_len": [vp],
         "dsr_stft_analysis": [vp, vp, vp, C.c_int, C.c_int, i64, C.c_int, vp, vp],
         "dsr_lpc_create": [C.c_int, C.c_int, C.c_int, f32, C.c_int, C.c_int, vp], "dsr_lpc_destroy": [vp], "dsr_lpc_size": [vp],
@@ -242,6 +245,44 @@ def calcDelaysPolar2(azimuth, elevation, micPositions):
     mp = _np(micPositions, np.float64); d = np.zeros(mp.shape[0], np.float64)
     check(_lib.dsr_calc_delays_polar2(azimuth, elevation, _ptr(mp), mp.shape[0], _ptr(d)))
     return d
+
+
+class PrFilterBank:
+    """PerfectReconstructionFFTAnalysisBank / SynthesisBank (modulated.cc:686-970), prototype of length 2M*m."""
+
+    def __init__(self, prototype, M, m, r=0):
+        L = load(); self.h = vp(); self.M, self.m, self.r = M, m, r
+        p = _np(prototype, np.float64)
+        if p.size != 2 * M * m:
+            raise DsrError(4, "Prototype sizes do not match (%d vs. %d)." % (p.size, 2 * M * m))
+        check(L.dsr_prfb_create(_ptr(p), M, m, r, C.byref(self.h)))
+
+    def __del__(self):
+        if _lib is not None and getattr(self, "h", None):
+            _lib.dsr_prfb_destroy(self.h)
+
+    def analysis(self, x, nsamp=None):
+        """x: cuda float32 [U][C][N] -> complex64 [U][C][T][2M]"""
+        import torch
+        U, Cn, N = x.shape
+        if nsamp is None:
+            nsamp = torch.full((U,), N, dtype=torch.int32, device=x.device)
+        T = max(1, max(_lib.dsr_prfb_analysis_frames(self.h, int(n)) for n in nsamp.tolist()))
+        X = torch.zeros((U, Cn, T, 2 * self.M), dtype=torch.complex64, device=x.device)
+        check(_lib.dsr_prfb_analysis(self.h, _dev(x), _dev(nsamp), U, Cn, N, T, _dev(X), cur_stream()))
+        return X
+
+    def synthesis(self, Y, nframes=None):
+        """Y: cuda complex64 [U][T][2M] -> float32 [U][(T-(2m-1))*D]"""
+        import torch
+        U, T, M2 = Y.shape
+        if nframes is None:
+            nframes = torch.full((U,), T, dtype=torch.int32, device=Y.device)
+        nb = max(1, max(_lib.dsr_prfb_synthesis_blocks(self.h, int(n)) for n in nframes.tolist()))
+        D = self.M >> self.r
+        y = torch.zeros((U, nb * D), dtype=torch.float32, device=Y.device)
+        check(_lib.dsr_prfb_synthesis(self.h, _dev(Y.contiguous()), _dev(nframes), U, T, nb * D, _dev(y), cur_stream()))
+        return y
 
 
 class NormalFFTBank:

@@ -259,6 +259,22 @@ dsr_status dsr_pipe_stage_ms(const dsr_pipe*, float ms[6]);
 /* device pointers to the intermediates of the last run (borrowed): 0 X, 1 Y, 2 y, 3 feat, 4 scores */
 dsr_status dsr_pipe_intermediate(const dsr_pipe*, int which, void** dev, int64_t* bytes);
 
+/* PerfectReconstructionFFTAnalysisBank / PerfectReconstructionFFTSynthesisBank (btk/modulated/modulated.cc:686-970):
+ * the 2M-band cosine-modulated pair; prototype of length 2M*m (analysis and synthesis objects each take their own).
+ * analysis: x_dev [U][C][sampStride] -> X_dev [U][C][Tmax][2M] complex64, frames(nsamp) = ceil(nsamp/D) + 2m - 1;
+ * synthesis: Y_dev [U][Tmax][2M] complex64, nframes_dev [U] -> y_dev [U][outStride] fp32, (nframes - (2m-1)) * D samples. */
+typedef struct dsr_prfb dsr_prfb;
+dsr_status dsr_prfb_create(const double* prototype, int M, int m, int r, dsr_prfb** out);
+void       dsr_prfb_destroy(dsr_prfb*);
+int        dsr_prfb_fft_len(const dsr_prfb*);
+int        dsr_prfb_block_len(const dsr_prfb*);
+int        dsr_prfb_analysis_frames(const dsr_prfb*, int nsamp);
+int        dsr_prfb_synthesis_blocks(const dsr_prfb*, int nframes);
+dsr_status dsr_prfb_analysis(const dsr_prfb*, const float* x_dev, const int32_t* nsamp_dev, int U, int C,
+                             int64_t sampStride, int Tmax, float* X_dev, void* stream);
+dsr_status dsr_prfb_synthesis(dsr_prfb*, const float* Y_dev, const int32_t* nframes_dev, int U, int Tmax,
+                              int64_t outStride, float* y_dev, void* stream);
+
 /* NormalFFTAnalysisBank (btk/modulated/modulated.cc:121-257) with getWindow (:72-97): windowed STFT, all M bins.
  * windowType 0 rectangle, 1 Hamming, 2 Hanning.  x_dev [U][C][sampStride] -> X_dev [U][C][Tmax][M] complex64;
  * frames(nsamp) = ceil(nsamp / D) + 1 (one zero-input frame, _processingDelay = 1), D = M >> r. */
@@ -313,6 +329,9 @@ dsr_status dsr_analysis_bank_create(dsr_stream* samp, const double* prototype, i
                                     int delayCompensationType, const char* name, dsr_stream** out);
 dsr_status dsr_synthesis_bank_create(dsr_stream* samp, const double* prototype, int M, int m, int r,
                                      int delayCompensationType, int gainFactor, const char* name, dsr_stream** out);
+/* PerfectReconstructionFFTAnalysisBank(samp, prototype, M, m, r) / ...SynthesisBank(samp, prototype, M, m, r) (modulated.h:377-440) */
+dsr_status dsr_pr_analysis_bank_create(dsr_stream* samp, const double* prototype, int M, int m, int r, const char* name, dsr_stream** out);
+dsr_status dsr_pr_synthesis_bank_create(dsr_stream* samp, const double* prototype, int M, int m, int r, const char* name, dsr_stream** out);
 /* NormalFFTAnalysisBank(samp, M, r, windowType) (modulated.i); samp delivers blocks of D = M >> r samples */
 dsr_status dsr_normal_fft_bank_create(dsr_stream* samp, int M, int r, int windowType, const char* name, dsr_stream** out);
 /* SubbandDS/GSC/MVDR as a stream: channels are analysis-bank streams (setChannel) */

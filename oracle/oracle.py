@@ -148,6 +148,25 @@ def synthesis_bank(Y, g, M, m, r, dctype=0, gain=1):
     return out[:n].reshape(-1)
 
 
+def pr_analysis_bank(x, h, M, m, r):
+    """PerfectReconstructionFFTAnalysisBank (modulated.cc:686-818): [T][2M] complex128."""
+    x = _f32(x); h = _f64(h); L = lib()
+    T = L.orc_pr_analysis_num_frames(len(x), M, m, r)
+    X = np.zeros((T, 2 * M), np.complex128)
+    L.orc_pr_analysis_bank(_p(x), len(x), _p(h), M, m, r, _p(X))
+    return X
+
+
+def pr_synthesis_bank(Y, g, M, m, r):
+    """PerfectReconstructionFFTSynthesisBank (modulated.cc:820-970): [T-(2m-1)][D] float32."""
+    Y = np.ascontiguousarray(Y, np.complex128); g = _f64(g); L = lib()
+    T = Y.shape[0]; D = M >> r
+    out = np.zeros((max(0, T - (2 * m - 1)), D), np.float32)
+    L.orc_pr_synthesis_bank.restype = C.c_int
+    n = L.orc_pr_synthesis_bank(_p(Y), T, _p(g), M, m, r, _p(out))
+    return out[:n]
+
+
 def normal_fft_bank(x, M, r, winType=1):
     x = _f32(x)
     T = lib().orc_normal_fft_num_frames(len(x), M, r)

@@ -47,6 +47,10 @@ void orc_analysis_bank(const float* x, int nsamp, const double* h, int M, int m,
 int  orc_synthesis_bank(const double* Y, int T, const double* g, int M, int m, int r,
                         int dctype, int gain, float* out);
 void orc_get_window(int winType, int winLen, double* win);
+/* PerfectReconstructionFFTAnalysisBank / ...SynthesisBank (modulated.cc:686-970): 2M bands, prototype length 2M*m */
+int  orc_pr_analysis_num_frames(int nsamp, int M, int m, int r);
+void orc_pr_analysis_bank(const float* x, int nsamp, const double* h, int M, int m, int r, double* X);
+int  orc_pr_synthesis_bank(const double* Y, int T, const double* g, int M, int m, int r, float* out);
 /* NormalFFTAnalysisBank (modulated.cc:121-257): X [T][M] */
 int  orc_normal_fft_num_frames(int nsamp, int M, int r);
 void orc_normal_fft_bank(const float* x, int nsamp, int M, int r, int winType, double* X);

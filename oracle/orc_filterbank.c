@@ -192,6 +192,83 @@ int orc_synthesis_bank(const double* Y, int T, const double* g, int M, int m, in
   return nout;
 }
 
+/* ---- PerfectReconstructionFFTAnalysisBank (modulated.cc:686-818) ----
+ * 2M bands; prototype of length 2M*m; input blocks of D = M/R samples; T = nblk + (2m-1) frames (zero padding at the end).
+ * X: [T][2M] interleaved complex double. */
+int orc_pr_analysis_num_frames(int nsamp, int M, int m, int r)
+{ int D = M >> r; int nblk = (nsamp + D - 1) / D; return nblk + (2 * m - 1); }
+void orc_pr_analysis_bank(const float* x, int nsamp, const double* h, int M, int m, int r, double* X)
+{
+  const int R = 1 << r, D = M / R, M2 = 2 * M, R2 = 2 * R;
+  const int nblk = (nsamp + D - 1) / D, T = nblk + (2 * m - 1);
+  ring_t buffer, gsi;
+  ring_init(&buffer, M2, m * (r + 2));          /* _buffer(_Mx2, m * (_r + 2))  modulated.cc:317 */
+  ring_init(&gsi, D, R2);                       /* _gsi(_D, _Rx2) */
+  double* convert = (double*) calloc(M2, sizeof(double));
+  double* w = (double*) calloc(2 * M2, sizeof(double));
+  float* blk = (float*) calloc(D, sizeof(float));
+  { double vr = 1.0, vi = 0.0; const double cr = cos(-M_PI / (2.0 * M)), ci = sin(-M_PI / (2.0 * M));     /* w_k by repeated multiplication :693-699 */
+    for (int k = 0; k < M2; k++) { w[2*k] = vr; w[2*k+1] = vi; const double nr = vr * cr - vi * ci, ni = vr * ci + vi * cr; vr = nr; vi = ni; } }
+  for (int t = 0; t < T; t++) {
+    if (t < nblk) { src_block(x, nsamp, D, t, blk); ring_push_f(&gsi, blk); }
+    else ring_push(&gsi, NULL, 0);
+    for (int sampX = 0; sampX < R2; sampX++)                                                              /* :722-728 */
+      for (int dimX = 0; dimX < D; dimX++)
+        convert[dimX + sampX * D] = ring_sample(&gsi, R2 - sampX - 1, dimX);
+    ring_push(&buffer, convert, 1);
+    double* out = X + (size_t) t * 2 * M2;
+    for (int mm = 0; mm < M2; mm++) {                                                                     /* :737-750 */
+      double sum = 0.0; int flip = 1;
+      for (int k = 0; k < m; k++) { sum += flip * h[mm + M2 * k] * ring_sample(&buffer, (r + 2) * k, mm); flip *= -1; }
+      out[2*mm] = w[2*mm] * sum; out[2*mm+1] = w[2*mm+1] * sum;
+    }
+    orc_fft_radix2(out, M2, +1);                                                                          /* gsl_fft_complex_radix2_inverse :759 */
+    for (int i = 0; i < 2 * M2; i++) out[i] /= (double) M2;
+  }
+  free(convert); free(w); free(blk); ring_free(&buffer); ring_free(&gsi);
+}
+
+/* ---- PerfectReconstructionFFTSynthesisBank (modulated.cc:820-970) ----
+ * Y: [T][2M] complex double in; out: [(T - (2m-1))][D] float; returns the number of output blocks */
+int orc_pr_synthesis_bank(const double* Y, int T, const double* g, int M, int m, int r, float* out)
+{
+  const int R = 1 << r, D = M / R, M2 = 2 * M, R2 = 2 * R, pd = 2 * m - 1;
+  ring_t buffer, gsi;
+  ring_init(&buffer, M2, m * (r + 2));
+  ring_init(&gsi, M2, R2);                      /* synthesis: _gsi(_Mx2, _Rx2) */
+  double* convert = (double*) calloc(M2, sizeof(double));
+  double* pin = (double*) calloc(2 * M2, sizeof(double));
+  double* w = (double*) calloc(2 * M2, sizeof(double));
+  { double vr = 1.0, vi = 0.0; const double cr = cos(M_PI / (2.0 * M)), ci = sin(M_PI / (2.0 * M));
+    for (int k = 0; k < M2; k++) { w[2*k] = vr; w[2*k+1] = vi; const double nr = vr * cr - vi * ci, ni = vr * ci + vi * cr; vr = nr; vi = ni; } }
+  int nout = 0, fed = 0;
+#define FEED() do { memcpy(pin, Y + (size_t) fed * 2 * M2, sizeof(double) * 2 * M2); fed++; \
+    orc_fft_radix2(pin, M2, -1);                                        /* forward :903 */ \
+    for (int mm = 0; mm < M2; mm++) convert[mm] = pin[2*mm] * w[2*mm] - pin[2*mm+1] * w[2*mm+1];   /* Re(val * w) :907-910 */ \
+    ring_push(&buffer, convert, 0); } while (0)
+  if (T >= pd) {
+    for (int i = 0; i < pd; i++) FEED();                                /* "prime" the buffer :921-924 */
+    while (fed < T) {
+      FEED();
+      for (int mm = 0; mm < M2; mm++) {                                 /* :933-943 */
+        double sum = 0.0; int flip = (m % 2 == 1) ? 1 : -1;
+        for (int k = 0; k < m; k++) { sum += flip * g[mm + M2 * (m - k - 1)] * ring_sample(&buffer, (r + 2) * k, mm); flip *= -1; }
+        convert[mm] = sum;
+      }
+      ring_push(&gsi, convert, 0);
+      float* o = out + (size_t) nout * D;
+      for (int d = 0; d < D; d++) o[d] = 0.0f;
+      for (int sampX = 0; sampX < R2; sampX++)                          /* :947-950: float accumulation in the output vector */
+        for (int d = 0; d < D; d++)
+          o[D - d - 1] = (float) (o[D - d - 1] + ring_sample(&gsi, R2 - sampX - 1, d + sampX * D) / R);
+      nout++;
+    }
+  }
+#undef FEED
+  free(convert); free(pin); free(w); ring_free(&buffer); ring_free(&gsi);
+  return nout;
+}
+
 /* modulated.cc:72-97 */
 void orc_get_window(int winType, int winLen, double* win)
 {

@@ -488,3 +488,44 @@ def test_normal_fft_bank(dsr, oracle, cuda, headset, M, r, win):
     rows = np.array([np.array(v) for v in Mo.NormalFFTAnalysisBankPtr(samp, M, r, win)])
     assert rows.shape == want.shape and rows.dtype == np.complex128
     assert np.abs(rows - want).max() < 2e-5 * rms * np.sqrt(M)
+
+
+# ------------------------------------------------------------------------------------------- PerfectReconstructionFFT banks
+@pytest.mark.gpu
+@pytest.mark.parametrize("M,m,r", [(128, 2, 0), (64, 3, 1), (256, 2, 2), (16, 4, 0)])
+def test_pr_fft_banks(dsr, oracle, cuda, headset, M, m, r):
+    """modulated.cc:686-970: the 2M-band pair, fp32 on the device vs the literal fp64 restatement of the ring buffers: 2e-5 of the RMS
+    (analysis), 1e-4 of the RMS (synthesis: the reference accumulates the output in fp32 as well)."""
+    import torch
+    rng = np.random.default_rng(M + m)
+    N = 2 * M * m
+    h = np.sin(np.pi * (np.arange(N) + 0.5) / N) * rng.uniform(0.9, 1.1, N)
+    x = headset[5000:5000 + 3000 + 11].astype(np.float32)
+    want = oracle.pr_analysis_bank(x, h, M, m, r)
+    bank = dsr.PrFilterBank(h, M, m, r)
+    got = bank.analysis(torch.from_numpy(x[None, None]).to(cuda)).cpu().numpy()[0, 0]
+    assert got.shape == want.shape
+    rms = np.sqrt(np.mean(np.abs(want) ** 2))
+    assert np.abs(got - want).max() < 2e-5 * rms * np.sqrt(2 * M)
+    # synthesis of a random subband sequence
+    T = 40
+    Y = (rng.standard_normal((T, 2 * M)) + 1j * rng.standard_normal((T, 2 * M))) * 100.0
+    g = rng.standard_normal(N)
+    wy = oracle.pr_synthesis_bank(Y, g, M, m, r)
+    gy = dsr.PrFilterBank(g, M, m, r).synthesis(torch.from_numpy(Y.astype(np.complex64)[None]).to(cuda)).cpu().numpy()[0]
+    assert gy.size == wy.size
+    yr = np.sqrt(np.mean(wy.astype(np.float64) ** 2))
+    assert np.abs(gy.reshape(wy.shape) - wy).max() < 1e-4 * yr * np.sqrt(2 * M)
+    # both operators behind the stream protocol: samples -> analysis -> synthesis
+    from dsr.btk import feature as F, modulated as Mo
+    D = M >> r
+    samp = F.SampleFeaturePtr(blockLen=D, shiftLen=D, padZeros=True); samp.setSamples(x, 16000)
+    ana = Mo.PerfectReconstructionFFTAnalysisBankPtr(samp, h, M, m, r)
+    assert ana.size() == 2 * M and ana.fftLen() == 2 * M
+    syn = Mo.PerfectReconstructionFFTSynthesisBankPtr(ana, g, M, m, r)
+    rows = np.array([np.array(v) for v in syn])
+    wy2 = oracle.pr_synthesis_bank(want, g, M, m, r)
+    assert rows.shape == wy2.shape
+    assert np.abs(rows - wy2).max() < 2e-4 * np.sqrt(np.mean(wy2.astype(np.float64) ** 2)) * np.sqrt(2 * M)
+    with pytest.raises(Exception):
+        Mo.PerfectReconstructionFFTAnalysisBankPtr(samp, h[:-1], M, m, r)

@@ -296,3 +296,80 @@ def test_decoder_edge_cases(oracle):
     assert r3["score"] >= r1["score"]
     # tokens are floats: the stored total equals float(ac)+float(lm) in double
     assert r1["score"] == float(np.float32(r1["ac"])) + float(np.float32(r1["lm"]))
+
+
+# ------------------------------------------------------------------ PerfectReconstructionFFT banks, LPC envelopes
+@pytest.mark.parametrize("M,m,r", [(16, 2, 0), (16, 3, 1), (8, 2, 2)])
+def test_pr_banks_match_closed_forms(oracle, M, m, r):
+    """The ring-buffer restatement of modulated.cc:686-970 against the closed forms the device kernels use."""
+    rng = np.random.default_rng(3 + M + m)
+    M2, N, D, R, pd = 2 * M, 2 * M * m, M >> r, 1 << r, 2 * m - 1
+    h = np.sin(np.pi * (np.arange(N) + 0.5) / N)
+    x = rng.standard_normal(300).astype(np.float32)
+    X = oracle.pr_analysis_bank(x, h, M, m, r)
+    assert X.shape == ((len(x) + D - 1) // D + pd, M2)
+    xp = np.concatenate([np.zeros(8 * N), x.astype(np.float64), np.zeros(8 * N)]); off = 8 * N
+    w = np.exp(-1j * np.pi * np.arange(M2) / M2)
+    for t in range(X.shape[0]):
+        nt = (t + 1) * D - 1
+        u = np.zeros(M2)
+        for k in range(m):
+            u += (-1) ** k * h[np.arange(M2) + M2 * k] * xp[off + nt - np.arange(M2) - (r + 2) * k * D]
+        ref = np.fft.ifft(w * u)
+        assert np.abs(X[t] - ref).max() < 1e-9 * (1 + np.abs(ref).max())
+    g = rng.standard_normal(N); T = 20
+    Y = rng.standard_normal((T, M2)) + 1j * rng.standard_normal((T, M2))
+    out = oracle.pr_synthesis_bank(Y, g, M, m, r)
+    V = np.real(np.fft.fft(Y, axis=1) * np.exp(1j * np.pi * np.arange(M2) / M2))
+    conv = {}
+    for t in range(pd, T):
+        c = np.zeros(M2); flip = 1 if m % 2 == 1 else -1
+        for k in range(m):
+            tv = t - (r + 2) * k
+            if tv >= 0:
+                c += flip * g[np.arange(M2) + M2 * (m - k - 1)] * V[tv]
+            flip *= -1
+        conv[t] = c
+    ref = np.zeros((T - pd, D))
+    for b in range(T - pd):
+        for s in range(2 * R):
+            tt = b + pd - (2 * R - s - 1)
+            if tt in conv:
+                ref[b, ::-1] += conv[tt][s * D:(s + 1) * D] / R
+    assert out.shape == ref.shape and np.abs(out - ref).max() < 1e-6 * np.abs(ref).max()
+
+
+def test_lpc_envelopes_against_numpy(oracle):
+    """lpc.cc / lpc.h restatement: Levinson-Durbin solves the normal equations; the envelopes follow from the coefficients."""
+    rng = np.random.default_rng(5)
+    dim, order = 320, 12
+    e = rng.standard_normal(dim + 64); y = np.zeros(dim + 64)
+    for n in range(2, dim + 64):
+        y[n] = 1.2 * y[n - 1] - 0.7 * y[n - 2] + e[n]
+    x = (y[64:] * np.hamming(dim)).astype(np.float32)
+    import ctypes as C
+    L = oracle.lib()
+    A = np.zeros(order + 1, np.float32); E = np.zeros(order + 1, np.float32)
+    L.orc_lpc_warp_autocorr(x.ctypes.data_as(C.c_void_p), dim, order, C.c_float(0.0), A.ctypes.data_as(C.c_void_p), E.ctypes.data_as(C.c_void_p))
+    r = np.array([np.dot(x[:dim - i].astype(np.float64), x[i:].astype(np.float64)) for i in range(order + 1)])
+    Rm = np.array([[r[abs(i - j)] for j in range(order)] for i in range(order)])
+    a = np.linalg.solve(Rm, r[1:])
+    assert np.allclose(-A[1:], a, rtol=2e-3, atol=2e-4)               # fp32 recursion vs fp64 solve
+    assert abs(E[0] - r[0]) < 1e-5 * r[0]
+    H = np.abs(np.fft.rfft(A.astype(np.float64), 512)) ** 2
+    lpc = oracle.lpc_feature(x[None], order, 0.0, 0, 1)[0]
+    assert np.allclose(lpc, 2 * E[0] / (H[:161] * dim), rtol=1e-5)
+    # MVDR envelope from its definition (lpc.h:153-192)
+    mv = oracle.lpc_feature(x[None], order, 0.0, 0, 0)[0]
+    pc = np.zeros(2 * order + 1)
+    for i in range(order + 1):
+        pc[order + i] = -sum((order + 1 - i - 2 * ii) * float(A[ii]) * float(A[ii + i]) for ii in range(order - i + 1))
+        pc[order - i] = pc[order + i]
+    P = np.abs(np.fft.rfft(pc, 512)) ** 2
+    assert np.allclose(mv, E[0] / np.sqrt(P[:161]), rtol=1e-4)
+    # Burg: same resonance, A[0] = 1
+    Ab = np.zeros(order + 1, np.float32); Eb = np.zeros(order + 1, np.float32)
+    L.orc_lpc_burg_autocorr(x.ctypes.data_as(C.c_void_p), dim, order, Ab.ctypes.data_as(C.c_void_p), Eb.ctypes.data_as(C.c_void_p))
+    assert Ab[0] == 1.0 and abs(Ab[1] - A[1]) < 0.05 and abs(Ab[2] - A[2]) < 0.05
+    with pytest.raises(ValueError):
+        oracle.lpc_feature(x[None], 161, 0.0, 0, 0)
