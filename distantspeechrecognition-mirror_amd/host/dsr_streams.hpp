@@ -141,7 +141,42 @@ class LinearTransformFeature : public VectorFloatFeatureStream {
  private: VectorFloatFeatureStreamPtr _s;
 };
 
+// ---- btk/feature/lpc.h: WarpMVDRFeature, BurgMVDRFeature, WarpLPCFeature, BurgLPCFeature (lpc.h:86-195,262-331)
+#define DSR_LPC_OP(NAME, METHOD, KIND, DFLT) class NAME : public VectorFeatureStream { \
+ public: NAME(const VectorFloatFeatureStreamPtr& src, unsigned order = 60, unsigned correlate = 0, float warp = 0.0, const String& nm = DFLT) \
+  : _s(src) { DSR_OP(NAME, double, dsr_lpc_feature_create(src->handle(), (int) order, (int) correlate, warp, METHOD, KIND, nm.c_str(), &h)) } \
+ private: VectorFloatFeatureStreamPtr _s; };
+DSR_LPC_OP(WarpMVDRFeature, 0, 0, "MVDR")
+DSR_LPC_OP(BurgMVDRFeature, 1, 0, "MVDR")
+DSR_LPC_OP(WarpLPCFeature, 0, 1, "LPC")
+DSR_LPC_OP(BurgLPCFeature, 1, 1, "LPC")
+#undef DSR_LPC_OP
+
 // ---- btk/modulated/modulated.h
+class NormalFFTAnalysisBank : public VectorComplexFeatureStream {
+ public:
+  NormalFFTAnalysisBank(VectorFloatFeatureStreamPtr& samp, unsigned M, unsigned r = 1, unsigned windowType = 1, const String& nm = "NormalFFTAnalysisBank")
+  : _s(samp), _M(M) { DSR_OP(NormalFFTAnalysisBank, cplx, dsr_normal_fft_bank_create(samp->handle(), (int) M, (int) r, (int) windowType, nm.c_str(), &h)) }
+  unsigned fftLen() const { return _M; }
+ private: VectorFloatFeatureStreamPtr _s; unsigned _M;
+};
+class PerfectReconstructionFFTAnalysisBank : public VectorComplexFeatureStream {
+ public:
+  PerfectReconstructionFFTAnalysisBank(VectorFloatFeatureStreamPtr& samp, const double* prototype, unsigned M, unsigned m, unsigned r,
+                                       const String& nm = "PerfectReconstructionFFTAnalysisBank")
+  : _s(samp), _M(M) { DSR_OP(PerfectReconstructionFFTAnalysisBank, cplx, dsr_pr_analysis_bank_create(samp->handle(), prototype, (int) M, (int) m, (int) r, nm.c_str(), &h)) }
+  unsigned fftLen() const { return 2 * _M; }
+  unsigned nBlocks() const { return 4; }
+  unsigned subSampRate() const { return 2; }
+ private: VectorFloatFeatureStreamPtr _s; unsigned _M;
+};
+class PerfectReconstructionFFTSynthesisBank : public VectorFloatFeatureStream {
+ public:
+  PerfectReconstructionFFTSynthesisBank(VectorComplexFeatureStreamPtr& samp, const double* prototype, unsigned M, unsigned m, unsigned r = 0,
+                                        const String& nm = "PerfectReconstructionFFTSynthesisBank")
+  : _s(samp) { DSR_OP(PerfectReconstructionFFTSynthesisBank, float, dsr_pr_synthesis_bank_create(samp->handle(), prototype, (int) M, (int) m, (int) r, nm.c_str(), &h)) }
+ private: VectorComplexFeatureStreamPtr _s;
+};
 class OverSampledDFTAnalysisBank : public VectorComplexFeatureStream {
  public:
   OverSampledDFTAnalysisBank(VectorFloatFeatureStreamPtr& samp, const double* prototype, unsigned M, unsigned m, unsigned r,
