@@ -825,6 +825,7 @@ extern "C" {
 dsr_status dsr_wfst_create(dsr_wfst** out) { return guard([&] { if (!out) throw Error(DSR_E_PARAMETER, "null argument"); *out = new dsr_wfst(); }); }
 void dsr_wfst_destroy(dsr_wfst* g) { delete g; }
 dsr_status dsr_wfst_read(dsr_wfst* g, const char* f, int binary) { return guard([&] { if (!g) throw Error(DSR_E_PARAMETER, "null argument"); g->read(f, binary != 0); }); }
+dsr_status dsr_wfst_read_dynamic(dsr_wfst* g, const char* f, int noSelfLoops) { return guard([&] { if (!g) throw Error(DSR_E_PARAMETER, "null argument"); g->readEx(f, false, noSelfLoops != 0); }); }
 dsr_status dsr_wfst_write(const dsr_wfst* g, const char* f, int binary) { return guard([&] { if (!g) throw Error(DSR_E_PARAMETER, "null argument"); g->write(f, binary != 0); }); }
 dsr_status dsr_wfst_add_arc(dsr_wfst* g, unsigned s1, unsigned s2, unsigned in, unsigned out, float cost)
 { return guard([&] { if (!g) throw Error(DSR_E_PARAMETER, "null argument"); g->addArc(s1, s2, in, out, cost, true); }); }

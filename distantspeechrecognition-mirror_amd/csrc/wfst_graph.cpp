@@ -49,7 +49,11 @@ struct BEFile {
 };
 }
 
-void WfstGraph::read(const char* file, bool binary)
+void WfstGraph::read(const char* file, bool binary) { readEx(file, binary, false); }
+
+// noSelfLoops: the dynamic container's reader, WFSTransducer::read(fileName, noSelfLoops) (asr/fsm/fsm.cc:901-986): every
+// self loop is skipped before any node is looked up (:945); otherwise identical to the fly-weight text reader.
+void WfstGraph::readEx(const char* file, bool binary, bool noSelfLoops)
 {
   if (!file || !*file) throw Error(DSR_E_IO, "File name is null.");
   nodes.clear(); arcs.clear(); nodeOf.clear(); initial = -1;       // _clear()
@@ -75,6 +79,7 @@ void WfstGraph::read(const char* file, bool binary)
         else if (i == 2) { float c = 0.f; sscanf(tok[1], "%f", &c); addFinal(s1, c); }
         else if (i == 4 || i == 5) {
           const uint32_t s2 = (uint32_t) strtoul(tok[1], nullptr, 0), in = (uint32_t) strtoul(tok[2], nullptr, 0), out = (uint32_t) strtoul(tok[3], nullptr, 0);
+          if (s1 == s2 && noSelfLoops) continue;
           float c = 0.f; if (i == 5) sscanf(tok[4], "%f", &c);
           addArc(s1, s2, in, out, c, true);
         } else { free(line); throw Error(DSR_E_IO, "Transducer file is inconsistent."); }

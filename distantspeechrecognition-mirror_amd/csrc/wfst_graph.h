@@ -29,6 +29,7 @@ struct WfstGraph {
   void addFinal(uint32_t state, float cost);
   void addArc(uint32_t s1, uint32_t s2, uint32_t in, uint32_t out, float cost, bool dropEpsSelf);
   void read(const char* file, bool binary);
+  void readEx(const char* file, bool binary, bool noSelfLoops);
   void write(const char* file, bool binary) const;
 
   // CSR in iteration order (node 0.. in creation order; the initial node is id `initial`)

@@ -408,6 +408,11 @@ class Wfst:
     def read(self, fileName, binary=False):
         check(_lib.dsr_wfst_read(self.h, fileName.encode(), int(binary)))
 
+    def read_dynamic(self, fileName, noSelfLoops=False):
+        """WFSTransducer::read (asr/fsm/fsm.cc:901-986)"""
+        _lib.dsr_wfst_read_dynamic.argtypes = [vp, C.c_char_p, C.c_int]
+        check(_lib.dsr_wfst_read_dynamic(self.h, fileName.encode(), int(noSelfLoops)))
+
     def write(self, fileName, binary=True):
         check(_lib.dsr_wfst_write(self.h, fileName.encode(), int(binary)))
 

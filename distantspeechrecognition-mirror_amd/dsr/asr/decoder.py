@@ -24,6 +24,17 @@ class WFSTFlyWeightPtr(object):
         return self._out
 
 
+class WFSTransducerPtr(WFSTFlyWeightPtr):
+    """The dynamic container (asr/fsm/fsm.h WFSTransducer): read(fileName, noSelfLoops) per asr/fsm/fsm.cc:901-986.  Node and arc
+    order (initial node of its own, arcs prepended, epsilon:epsilon self loops dropped) are those of the fly-weight reader."""
+
+    def __init__(self, statelex=None, inlex=None, outlex=None, name="WFSTransducer"):
+        WFSTFlyWeightPtr.__init__(self, statelex, inlex, outlex, name)
+
+    def read(self, fileName, noSelfLoops=False):
+        self._g.read_dynamic(fileName, noSelfLoops)
+
+
 class DecoderFlyWeightPtr(object):
     """decode() pulls every frame of the distribution set's feature stream, scores all distributions on the GPU and runs
     the token-passing kernel; bestHypo() maps the output ids through the output lexicon (decoder.h:748-773)."""
@@ -67,3 +78,7 @@ class DecoderFlyWeightPtr(object):
 
     def bestArcs(self):
         return self._last["arcs"]
+
+
+class DecoderPtr(DecoderFlyWeightPtr):
+    """Decoder (decoder.h:1107-1125): the same _Decoder<> search over the dynamic WFSTransducer container."""

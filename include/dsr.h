@@ -183,6 +183,9 @@ typedef struct dsr_wfst dsr_wfst;
 dsr_status dsr_wfst_create(dsr_wfst** out);
 void       dsr_wfst_destroy(dsr_wfst*);
 dsr_status dsr_wfst_read(dsr_wfst*, const char* fileName, int binary);    /* WFSTFlyWeight::read */
+/* the dynamic container's text reader, WFSTransducer::read(fileName, noSelfLoops) (asr/fsm/fsm.cc:901-986): same node/arc
+   order as the fly-weight reader; noSelfLoops != 0 skips every self loop (:945).  Graph for Decoder (decoder.h:1107-1125). */
+dsr_status dsr_wfst_read_dynamic(dsr_wfst*, const char* fileName, int noSelfLoops);
 dsr_status dsr_wfst_write(const dsr_wfst*, const char* fileName, int binary);
 dsr_status dsr_wfst_add_arc(dsr_wfst*, unsigned s1, unsigned s2, unsigned input, unsigned output, float cost);
 dsr_status dsr_wfst_add_final(dsr_wfst*, unsigned state, float cost);

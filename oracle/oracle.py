@@ -428,6 +428,10 @@ class Wfst:
     def read(self, path, binary=False):
         return lib().orc_wfst_read(self.h, path.encode(), int(binary))
 
+    def read_dynamic(self, path, noSelfLoops=False):
+        L = lib(); L.orc_wfst_read_dynamic.argtypes = [c_vp, C.c_char_p, c_int]
+        return L.orc_wfst_read_dynamic(self.h, path.encode(), int(noSelfLoops))
+
     def write(self, path, binary=True):
         return lib().orc_wfst_write(self.h, path.encode(), int(binary))
 

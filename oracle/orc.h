@@ -142,6 +142,7 @@ void orc_wfst_free(orc_wfst*);
 int  orc_wfst_add_arc(orc_wfst*, unsigned s1, unsigned s2, unsigned in, unsigned out, float cost);
 int  orc_wfst_add_final(orc_wfst*, unsigned s, float cost);
 int  orc_wfst_read(orc_wfst*, const char* file, int binary);
+int  orc_wfst_read_dynamic(orc_wfst* g, const char* file, int noSelfLoops);   /* WFSTransducer::read, asr/fsm/fsm.cc:901-986 */
 int  orc_wfst_write(const orc_wfst*, const char* file, int binary);
 int  orc_wfst_num_nodes(const orc_wfst*);
 int  orc_wfst_num_arcs(const orc_wfst*);

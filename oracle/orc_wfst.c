@@ -100,7 +100,11 @@ static int rd_float(FILE* fp, float* v) { int i; if (rd_int(fp, &i)) return -1; 
 static void wr_int(FILE* fp, int v) { unsigned u = (unsigned) v; unsigned char b[4] = { (unsigned char)(u >> 24), (unsigned char)(u >> 16), (unsigned char)(u >> 8), (unsigned char) u }; fwrite(b, 1, 4, fp); }
 static void wr_float(FILE* fp, float v) { int i; memcpy(&i, &v, 4); wr_int(fp, i); }
 
-int orc_wfst_read(orc_wfst* g, const char* file, int binary)
+static int read_impl(orc_wfst* g, const char* file, int binary, int noSelfLoops);
+int orc_wfst_read(orc_wfst* g, const char* file, int binary) { return read_impl(g, file, binary, 0); }
+/* WFSTransducer::read(fileName, noSelfLoops) (asr/fsm/fsm.cc:901-986) */
+int orc_wfst_read_dynamic(orc_wfst* g, const char* file, int noSelfLoops) { return read_impl(g, file, 0, noSelfLoops); }
+static int read_impl(orc_wfst* g, const char* file, int binary, int noSelfLoops)
 {
   FILE* fp = fopen(file, binary ? "rb" : "r");
   if (!fp) return -7;   /* JIO */
@@ -123,6 +127,7 @@ int orc_wfst_read(orc_wfst* g, const char* file, int binary)
       else if (i == 2) { float cost; sscanf(tok[1], "%f", &cost); if (orc_wfst_add_final(g, s1, cost)) { free(line); fclose(fp); return -3; } }
       else if (i == 4 || i == 5) {
         unsigned s2 = (unsigned) strtoul(tok[1], NULL, 0), in = (unsigned) strtoul(tok[2], NULL, 0), out = (unsigned) strtoul(tok[3], NULL, 0);
+        if (s1 == s2 && noSelfLoops) continue;             /* fsm.cc:945 */
         float cost = 0.0f; if (i == 5) sscanf(tok[4], "%f", &cost);
         add_arc_raw(g, s1, s2, in, out, cost, 1);
       } else { free(line); fclose(fp); return -7; }

@@ -313,6 +313,29 @@ def test_viterbi_large_frames(dsr, oracle, cuda, seed, S, gkw, path, monkeypatch
             assert 0 < out[u]["registerFrames"] < T
 
 
+def test_wfst_dynamic_reader(dsr, oracle, cuda, tmp_path):
+    """WFSTransducer::read(fileName, noSelfLoops) (asr/fsm/fsm.cc:901-986): identical numbering with and without self loops."""
+    arcs, fin = synth.random_wfst(300, 16, seed=41, eps_frac=0.2)
+    rng = np.random.default_rng(41)
+    f = tmp_path / "g.txt"
+    with open(f, "w") as fp:
+        for (s1, s2, i, o, c) in arcs:
+            fp.write("%d %d %d %d %g\n" % (s1, s2, i, o, c))
+            if rng.random() < 0.1:
+                fp.write("%d %d %d %d %g\n" % (s1, s1, 1 + int(rng.integers(16)), 0, 0.5))     # an emitting self loop
+        for s, c in fin:
+            fp.write("%d %g\n" % (s, c))
+    for nsl in (False, True):
+        go, gd = oracle.Wfst(), dsr.Wfst()
+        assert go.read_dynamic(str(f), nsl) == 0
+        gd.read_dynamic(str(f), nsl)
+        eo, ed = go.export(), gd.export()
+        for k in eo:
+            assert np.array_equal(eo[k], ed[k]), k
+    g0 = dsr.Wfst(); g0.read_dynamic(str(f), False); g1 = dsr.Wfst(); g1.read_dynamic(str(f), True)
+    assert g1.export()["arcDst"].size < g0.export()["arcDst"].size
+
+
 def test_viterbi_token_lists(dsr, oracle, cuda):
     """Every frame's active list: same states in the same list order with the same float scores."""
     import torch
