@@ -264,6 +264,16 @@ def main():
         else:
             roof = dict(kernel="k_" + dn, bound="mfma", achieved=amount / secs / 1e12, peak=MFMA_F32_PEAK_TF, unit="TFLOP/s")
         roof["frac"] = roof["achieved"] / roof["peak"]; roof["traffic"] = None
+        # HBM bytes per launch from the counter passes of this round (profiles/r01_traffic.json: FETCH_SIZE and WRITE_SIZE, separate
+        # rocprofv3 --pmc runs of this same workload); only quoted when the workload is the one they were collected on
+        try:
+            tj = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
+            key = {"viterbi": "k_viterbi", "analysis": "k_analysis_q256", "beamform": "k_bf_apply"}.get(dn)
+            if key in tj["kernels"] and U == 1000 and args.secs == 10.0 and args.states == 50000 and abs(beam - 53.787) < 0.01:
+                roof["traffic"] = tj["kernels"][key]["bytes_per_launch"]
+                roof["traffic_note"] = "bytes per launch, PMC FETCH_SIZE + WRITE_SIZE (profiles/r01_traffic.json)"
+        except (OSError, ValueError, KeyError):
+            pass
         roof["launch_ms"] = stage_ms[dom]
         stages = {}
         tbl_ms = serial_ms if serial_ms is not None else stage_ms
