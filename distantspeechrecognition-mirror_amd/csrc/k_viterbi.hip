@@ -45,7 +45,6 @@ static constexpr int kThreads = 512;              // 8 waves: 256 VGPRs per thre
 static constexpr int kWaves = kThreads / 64;
 static constexpr int kFastK = 16;                  // placements a thread keeps in registers on the register path
 static constexpr int kFastC = 24576;               // most placements per frame on the register path (those beyond kFastK per thread are parked in memory)
-static constexpr int kTableC = 12288;              // most placements the LDS state table takes at once; above, the states are split in two passes
 static constexpr int kFastE = 8190;                // most expanding tokens per frame on the register path
 static constexpr int kP1 = 32;                     // token rounds per wave in the register path's beam pass
 static constexpr int kSideLds = 528;               // later arrivals kept in LDS (the region also holds the slot offsets, dead by then)               // most placements / expanding tokens per frame on the register path
@@ -113,7 +112,7 @@ __device__ __forceinline__ unsigned f2ord(float f) { const unsigned u = __float_
 __global__ __launch_bounds__(kThreads) void k_viterbi(GraphDev G, DecDev Dd, const float* __restrict__ scores,
                                                       const int* __restrict__ nframesArr, int U, int Tmax, int nDist,
                                                       dsr_decode_result* __restrict__ res, int* __restrict__ arcsOut,
-                                                      unsigned* __restrict__ wordsOut, int maxPath, int useLdsRow, int hashN)
+                                                      unsigned* __restrict__ wordsOut, int maxPath, int useLdsRow, int hashN, int regionB)
 {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   float* srow = reinterpret_cast<float*>(smem);                       // [nDist] when useLdsRow
@@ -123,7 +122,7 @@ __global__ __launch_bounds__(kThreads) void k_viterbi(GraphDev G, DecDev Dd, con
   unsigned* hkey = reinterpret_cast<unsigned*>(srow + (useLdsRow ? ((nDist + 3) & ~3) : 4));
   unsigned* hfirst = hkey + hashN;
   unsigned short* eoff = reinterpret_cast<unsigned short*>(hfirst + hashN);     // [kFastC + 2] slot offset of every expanding token (register path)
-  Side* sideL = reinterpret_cast<Side*>(hfirst + hashN);                        // [kSideLds] same region, used after the expansion
+  Side* sideL = reinterpret_cast<Side*>(hfirst + hashN);                        // [regionB / 32] same region, used after the expansion
   __shared__ int s_waveTot[kWaves];
   __shared__ int s_waveTotE[kWaves];
   __shared__ double s_waveMin[kWaves];
@@ -158,7 +157,9 @@ __global__ __launch_bounds__(kThreads) void k_viterbi(GraphDev G, DecDev Dd, con
   Bp* arena = Dd.arena + (size_t) slot * Dd.arenaCap;
   const int fastCapC = ((kFastK + 32) * nthr < kFastC) ? (kFastK + 32) * nthr : kFastC;
   const int fastCapN = kP1 * 64 * nw;                                   // kP1 rounds of 64 tokens per wave
-  const bool fastOK = Dd.fastOK && hashN >= 16384;
+  const bool fastOK = Dd.fastOK && hashN >= 8192;
+  // capacities that follow from the LDS budget of this launch: table (load <= 0.75 per pass), slot offsets, LDS side records
+  const int tableC = (hashN >> 1) + (hashN >> 2), eCap = (regionB >> 1) - 2 < kFastE ? (regionB >> 1) - 2 : kFastE, sideLds = regionB >> 5;
 
   for (;;) {
     __syncthreads();
@@ -241,7 +242,7 @@ __global__ __launch_bounds__(kThreads) void k_viterbi(GraphDev G, DecDev Dd, con
         int C = 0, E = 0, cbase = 0, ebase = 0;
         for (int w = 0; w < nw; w++) { const int a = s_waveTot[w], b = s_waveTotE[w]; if (w < wave) { cbase += a; ebase += b; } C += a; E += b; }
         C = uni(C); E = uni(E); cbase = uni(cbase); ebase = uni(ebase);
-        if (C > fastCapC || E > kFastE) { fast = false; __syncthreads(); }     // uniform: the memory path redoes the frame
+        if (C > fastCapC || E > eCap || C > 2 * tableC) { fast = false; __syncthreads(); }     // uniform: the memory path redoes the frame
         else {
           // ---- P2: compact list of the expanding tokens (their slot offsets in LDS, the tokens themselves in memory); a bitmap
           // of the slots where a token's run starts and the token count before every group of 64 slots turn "slot -> token"
@@ -273,7 +274,7 @@ __global__ __launch_bounds__(kThreads) void k_viterbi(GraphDev G, DecDev Dd, con
 #pragma unroll
           for (int k = 0; k < kFastK; k++) { qac[k] = 0.0f; qlm[k] = 0.0f; qrec[k] = 0; ek[k] = 0u; }
 
-          const int nPass = (C > kTableC) ? 2 : 1;
+          const int nPass = (C > tableC) ? 2 : 1;
           auto table_insert = [&](const unsigned dst, const unsigned prod, const int c) __attribute__((always_inline)) -> unsigned {
             const unsigned key = dst + 1u;
             unsigned h = (prod >> 7) & (unsigned) (hashN - 1); int probes = 0;
@@ -350,7 +351,7 @@ __global__ __launch_bounds__(kThreads) void k_viterbi(GraphDev G, DecDev Dd, con
             }
           };
           expand8(0, &qac[0], &qlm[0], &qrec[0], &ek[0]);
-          if (K > 8) expand8(8, &qac[8], &qlm[8], &qrec[8], &ek[8]);
+          if constexpr (kFastK > 8) { if (K > 8) expand8(8, &qac[8], &qlm[8], &qrec[8], &ek[8]); }
           auto park_store = [&](const int kb, const float* oac, const float* olm, const int* orec, const unsigned* oek) __attribute__((always_inline)) {
 #pragma unroll
             for (int i = 0; i < 8; i++) { const int c = (kb + i) * nthr + tq; if (c < C) ovf[c - kFastK * nthr] = make_uint4(__float_as_uint(oac[i]), __float_as_uint(olm[i]), (unsigned) orec[i], oek[i]); }
@@ -396,7 +397,7 @@ __global__ __launch_bounds__(kThreads) void k_viterbi(GraphDev G, DecDev Dd, con
                   const int sx = atomicAdd(&s_sideN, 1);
                   const unsigned nx = atomicExch(&hkey[h], 0x80000000u | (unsigned) sx);
                   Side sd; sd.ttl = tt[i]; sd.ac = ac8[i]; sd.lm = lm8[i]; sd.rec = rec8[i]; sd.prevBp = pb[i]; sd.c = c; sd.next = nx;
-                  if (sx < kSideLds) sideL[sx] = sd; else side[sx] = sd;
+                  if (sx < sideLds) sideL[sx] = sd; else side[sx] = sd;
                 }
               }
             }
@@ -410,9 +411,9 @@ __global__ __launch_bounds__(kThreads) void k_viterbi(GraphDev G, DecDev Dd, con
               if (head & 0x80000000u) {
                 int wslot = k * nthr + tq, wIdx = -1; double fw = (double) __fadd_rn(ac, lm);
                 const int hi = (int) (head & 0x7FFFFFFFu);
-                const unsigned hnext = (hi < kSideLds) ? sideL[hi].next : side[hi].next;
+                const unsigned hnext = (hi < sideLds) ? sideL[hi].next : side[hi].next;
                 if (!(hnext & 0x80000000u)) {                                  // one later arrival (the usual case): a single comparison
-                  const double pt = (hi < kSideLds) ? sideL[hi].ttl : side[hi].ttl;
+                  const double pt = (hi < sideLds) ? sideL[hi].ttl : side[hi].ttl;
                   if (pt < fw) wIdx = hi;
                 } else
                 for (;;) {                                                     // next replacement = smallest later slot that beats the incumbent
@@ -420,16 +421,16 @@ __global__ __launch_bounds__(kThreads) void k_viterbi(GraphDev G, DecDev Dd, con
                   for (unsigned p = head; (p & 0x80000000u) && steps <= C; steps++) {
                     const int pi = (int) (p & 0x7FFFFFFFu);
                     int pc; double pt; unsigned pn;
-                    if (pi < kSideLds) { pc = sideL[pi].c; pt = sideL[pi].ttl; pn = sideL[pi].next; } else { pc = side[pi].c; pt = side[pi].ttl; pn = side[pi].next; }
+                    if (pi < sideLds) { pc = sideL[pi].c; pt = sideL[pi].ttl; pn = sideL[pi].next; } else { pc = side[pi].c; pt = side[pi].ttl; pn = side[pi].next; }
                     if (pc > wslot && pc < best && pt < fw) { best = pc; bi = pi; }
                     p = pn;
                   }
                   if (bi < 0) break;
                   wslot = best; wIdx = bi;
-                  fw = (bi < kSideLds) ? (double) __fadd_rn(sideL[bi].ac, sideL[bi].lm) : (double) __fadd_rn(side[bi].ac, side[bi].lm);
+                  fw = (bi < sideLds) ? (double) __fadd_rn(sideL[bi].ac, sideL[bi].lm) : (double) __fadd_rn(side[bi].ac, side[bi].lm);
                 }
                 if (wIdx >= 0) {
-                  if (wIdx < kSideLds) { ac = sideL[wIdx].ac; lm = sideL[wIdx].lm; rec = sideL[wIdx].rec; }
+                  if (wIdx < sideLds) { ac = sideL[wIdx].ac; lm = sideL[wIdx].lm; rec = sideL[wIdx].rec; }
                   else { ac = side[wIdx].ac; lm = side[wIdx].lm; rec = side[wIdx].rec; }
                   ekk = 0x80000000u | (unsigned) wIdx;
                 }
@@ -454,7 +455,7 @@ __global__ __launch_bounds__(kThreads) void k_viterbi(GraphDev G, DecDev Dd, con
                 for (int i = tq; i < 2 * q4; i += nthr) h4[i] = (i < q4) ? make_uint4(0u, 0u, 0u, 0u) : make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu); }
               __syncthreads();
               insert8(0, &qrec[0], &ek[0]);
-              if (K > 8) insert8(8, &qrec[8], &ek[8]);
+              if constexpr (kFastK > 8) { if (K > 8) insert8(8, &qrec[8], &ek[8]); }
               for (int kb = kFastK; kb < K; kb += 8) {
                 float oac[8], olm[8]; int orec[8]; unsigned oek[8]; park_load(kb, oac, olm, orec, oek);
                 insert8(kb, orec, oek); park_store(kb, oac, olm, orec, oek);
@@ -462,7 +463,7 @@ __global__ __launch_bounds__(kThreads) void k_viterbi(GraphDev G, DecDev Dd, con
               __syncthreads();
             }
             later8(0, pass, &qac[0], &qlm[0], &qrec[0], &ek[0]);
-            if (K > 8) later8(8, pass, &qac[8], &qlm[8], &qrec[8], &ek[8]);
+            if constexpr (kFastK > 8) { if (K > 8) later8(8, pass, &qac[8], &qlm[8], &qrec[8], &ek[8]); }
             for (int kb = kFastK; kb < K; kb += 8) { float oac[8], olm[8]; int orec[8]; unsigned oek[8]; park_load(kb, oac, olm, orec, oek); later8(kb, pass, oac, olm, orec, oek); }
             __syncthreads();
             if (pass == 0) TICK(5);
@@ -503,9 +504,9 @@ __global__ __launch_bounds__(kThreads) void k_viterbi(GraphDev G, DecDev Dd, con
             for (int i = 0; i < 4; i++) {                                      // unconditional loads (every index is in bounds), in flight together
               dx[i] = *reinterpret_cast<const int4*>(&G.xrecD[rec4[i] & 0x3FFFFFFF].dst);                  // same state for every arrival
               const bool sw = (ek4[i] & 0x80000000u) != 0u; const unsigned si = ek4[i] & 0x7FFFFFFFu;
-              const uint32_t* pb = (sw && si >= (unsigned) kSideLds) ? &side[si].prevBp : &ctok[sw ? 0u : (ek4[i] & 0x1FFFu)].bp;
+              const uint32_t* pb = (sw && si >= (unsigned) sideLds) ? &side[si].prevBp : &ctok[sw ? 0u : (ek4[i] & 0x1FFFu)].bp;
               pv[i] = *pb;
-              if (sw && si < (unsigned) kSideLds) pv[i] = sideL[si].prevBp;
+              if (sw && si < (unsigned) sideLds) pv[i] = sideL[si].prevBp;
             }
 #pragma unroll
             for (int i = 0; i < 4; i++) {
@@ -806,7 +807,7 @@ struct DecoderState {
   DevBuf<XRec> d_xrec; DevBuf<ERec> d_erec; DevBuf<float> d_arcCost, d_nodeCost; DevBuf<uint32_t> d_arcOut, d_arcIn;
   DevBuf<TokA> d_tokA, d_ctok; DevBuf<TokB> d_tokB; DevBuf<Side> d_side; DevBuf<XRecD> d_xrecD; int fastOK = 0; DevBuf<int> d_tokOff, d_tokCnt, d_owner, d_rank, d_chead; DevBuf<unsigned> d_tags; DevBuf<CandA> d_cA; DevBuf<CandB> d_cB; DevBuf<unsigned> d_first; DevBuf<Bp> d_arena;
   DevBuf<long long> d_prof; DevBuf<dsr_decode_result> d_res; DevBuf<int> d_arcs; DevBuf<unsigned> d_words;
-  long arenaCap = 0; int initial = 0; int threads = kThreads;
+  long arenaCap = 0; int initial = 0; int threads = kThreads; bool twoPerCu = false;
   PinBuf<dsr_decode_result> h_res; PinBuf<int> h_arcs; PinBuf<unsigned> h_words; hipEvent_t evDone = nullptr;
   int pendingU = 0; size_t pendingPath = 0; int pendingSlots = 0; long long* pendingProf = nullptr;
   // dump
@@ -859,7 +860,9 @@ dsr_status dsr_decoder_create(const dsr_decoder_cfg* cfg, dsr_decoder** out)
     if (const char* e = getenv("DSR_VITERBI_THREADS")) { const int t = atoi(e); if (t == 256 || t == 512) d->threads = t; }
     if (d->cfg.streams <= 0) {
       hipDeviceProp_t prop; int dev = 0; DSR_HIP(hipGetDevice(&dev)); DSR_HIP(hipGetDeviceProperties(&prop, dev));
-      d->cfg.streams = prop.multiProcessorCount;
+      if (const char* e = getenv("DSR_VITERBI_TWO")) d->twoPerCu = atoi(e) != 0;
+      if (d->twoPerCu) d->threads = 256;
+      d->cfg.streams = prop.multiProcessorCount * (d->twoPerCu ? 2 : 1);
       if (const char* e = getenv("DSR_VITERBI_SLOTS")) { const int t = atoi(e); if (t > 0) d->cfg.streams = t; }
     }
     *out = d;
@@ -963,17 +966,22 @@ dsr_status dsr_decoder_decode_launch(dsr_decoder* d, const float* score, const i
     D.dumpLm = d->d_dumpLm.p; D.dumpArc = d->d_dumpArc.p; D.dumpCount = d->d_dumpCount.p;
     // LDS: [score row][state table: 2 x hashN words][slot offsets of the expanding tokens]; the row stays in global memory
     // when it would push the state table below the size the register path needs
-    const size_t eoffB = (size_t) kSideLds * sizeof(Side), ldsCap = 159 * 1024;      // slot offsets [kFastC + 2] u16, later the LDS side entries
+    // Two shapes: one workgroup per CU (16384 buckets, 512 threads) or two per CU (8192 buckets, 256 threads each: two
+    // utterances advance side by side and fill each other's stalls).  The region after the table holds the slot offsets
+    // (u16 per expanding token) and later the LDS side records.
+    const bool two = d->twoPerCu;
+    size_t eoffB = two ? 6528 : (size_t) kSideLds * sizeof(Side); const size_t ldsCap = two ? 76160 : 159 * 1024;
     static_assert((size_t) kSideLds * sizeof(Side) >= (size_t) (kFastE + 2) * sizeof(unsigned short), "side region must cover the slot offsets");
+    const int hashMax = two ? 8192 : 16384;
     int useLds = (size_t) nDist * sizeof(float) <= 64 * 1024;
-    if (useLds && (size_t) ((nDist + 3) & ~3) * sizeof(float) + (size_t) 16384 * 8 + eoffB > ldsCap) useLds = 0;
+    if (useLds && (size_t) ((nDist + 3) & ~3) * sizeof(float) + (size_t) hashMax * 8 + eoffB > ldsCap) useLds = 0;
     const size_t rowB = useLds ? (size_t) ((nDist + 3) & ~3) * sizeof(float) : 16;
-    int hashN = 16384; while (hashN > 0 && rowB + (size_t) hashN * 8 + eoffB > ldsCap) hashN >>= 1;
+    int hashN = hashMax; while (hashN > 0 && rowB + (size_t) hashN * 8 + eoffB > ldsCap) hashN >>= 1;
     if (getenv("DSR_VITERBI_NOHASH")) hashN = 0;
     const size_t lds = rowB + (size_t) hashN * 8 + eoffB;
     DSR_HIP(hipFuncSetAttribute((const void*) k_viterbi, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
     hipLaunchKernelGGL(k_viterbi, dim3(slots), dim3(d->threads), lds, st, G, D, score, nframes, U, Tmax, nDist, d->d_res.p,
-                       (arcs_out || words_out) ? d->d_arcs.p : nullptr, (arcs_out || words_out) ? d->d_words.p : nullptr, maxPath, useLds, hashN);
+                       (arcs_out || words_out) ? d->d_arcs.p : nullptr, (arcs_out || words_out) ? d->d_words.p : nullptr, maxPath, useLds, hashN, (int) eoffB);
     DSR_HIP(hipGetLastError());
     const size_t nPath = want_paths ? (size_t) U * maxPath : 0;
     d->h_res.reserve(U); d->h_arcs.reserve(nPath ? nPath : 1); d->h_words.reserve(nPath ? nPath : 1);
