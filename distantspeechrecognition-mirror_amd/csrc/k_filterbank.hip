@@ -429,13 +429,13 @@ __device__ __forceinline__ void fft8_pos(float2 (&v)[8])
 }
 
 template <int MT>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_analysis_q256(const float* __restrict__ x, const int* __restrict__ nsampArr,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_analysis_q256(const float* __restrict__ x, const int* __restrict__ nsampArr,
                                                        const float* __restrict__ proto, const float2* __restrict__ twG,
                                                        float2* __restrict__ X, int C, long sampStride, int Tmax,
                                                        int pd, int laN, int gain, int TF)
 {
   constexpr int M = 256, N = 128, D = 128;                     // r = 1
-  constexpr int NQ = 2;                                        // quads of frames a wave works on side by side (independent chains to interleave)
+  constexpr int NQ = 1;                                        // quads of frames a wave works on side by side (independent chains to interleave)
   constexpr int SQ = 146, SK = 18, SZ = 4 * SQ;                // strip pitches: per frame / per k1 row (conflict-free both ways); strip size
   constexpr int BR[8] = {0, 4, 2, 6, 1, 5, 3, 7};
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -446,7 +446,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   float2* tw = reinterpret_cast<float2*>(smem);
   float* win = reinterpret_cast<float*>(tw + M);
   const int tid = threadIdx.x, nthr = blockDim.x, lane = tid & 63, wave = tid >> 6, nwv = nthr >> 6;
-  float2* strip = reinterpret_cast<float2*>(win + ((winPhys + 3) & ~3)) + wave * (NQ * SZ);
+  float2* hT = reinterpret_cast<float2*>(win + ((winPhys + 3) & ~3));                      // taps as pairs: hT[n + 128 qq] = (h[2n + qq M], h[2n + 1 + qq M])
+  float2* strip = hT + (M / 2) * MT + wave * (NQ * SZ);
   // A workgroup streams one (utterance, channel) row from start to end, TF frames at a time: taps and twiddles are set up
   // once per row, the samples of the next TF frames are fetched into registers while the current ones are transformed,
   // and the MT*M - D samples two tiles share stay in LDS.  (Workgroups that run at the same time work on different rows:
@@ -464,14 +465,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   const int step = TF * D, keep = winLen - step;               // samples a tile brings in / shares with the tile before (multiples of 128)
   const int stepPhys = step + 32 * (step >> 7), keepPhys = keep + 32 * (keep >> 7);
   const bool vec = ((((uintptr_t) xs) | (uintptr_t) (sampStride * 4)) & 15) == 0;
-  constexpr int PF = 4;                                        // float4 per thread: step <= 4 * PF * nthr
+  constexpr int PF = 2;                                        // float4 per thread: step = TF D <= 4 * PF * nthr (TF = 16, 256 threads)
   const int l = lane & 15, q = lane >> 4;
   // prototype taps of this lane's points: h[2(l + 16e) + {0,1} + qq M]
-  float2 hreg[8][MT];
-#pragma unroll
-  for (int e = 0; e < 8; e++)
-#pragma unroll
-    for (int qq = 0; qq < MT; qq++) hreg[e][qq] = *reinterpret_cast<const float2*>(proto + 2 * (l + 16 * e) + qq * M);
+  for (int i = tid; i < (M / 2) * MT; i += nthr) hT[i] = *reinterpret_cast<const float2*>(proto + 2 * i);   // 2 (n + 128 qq) = 2n + qq M
   __syncthreads();
   // twiddles: after pass 1  w_128^(l k1) = tw[2 l k1];  joining the halves of pass 2  w_16^(k2) = tw[16 k2] on the odd half
   // (read from the LDS table where they are used: sixteen complex constants per lane would cost registers the taps need)
@@ -519,7 +516,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
           for (int qq = 0; qq < MT; qq++) {
             const int A = MT * M - 2 - 32 * e - 256 * qq;                // sample n_t - k0 - 1 - qq M relative to the frame's first block
             const float2 pr = *reinterpret_cast<const float2*>(wp + (A + 32 * (A >> 7)));     // (x[n_t-k0-1-qM], x[n_t-k0-qM])
-            s0 += hreg[e][qq].x * pr.y; s1 += hreg[e][qq].y * pr.x;
+            const float2 hp = hT[l + 16 * e + (M / 2) * qq];
+            s0 += hp.x * pr.y; s1 += hp.y * pr.x;
           }
           v[h][e] = make_float2(s0, s1);
         }
@@ -566,16 +564,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
           float4 o4;
           o4.x = (s0.x + wf0.x * d0.y + wf0.y * d0.x) * gh; o4.y = (s0.y - wf0.x * d0.x + wf0.y * d0.y) * gh;
           o4.z = (s1.x + wf1.x * d1.y + wf1.y * d1.x) * gh; o4.w = (s1.y - wf1.x * d1.x + wf1.y * d1.y) * gh;
-          __builtin_memcpy(reinterpret_cast<char*>(row) + 16 * lane, &o4, 16);           // rows are 8-byte aligned: dwordx4 store, dword alignment suffices
+          typedef float f4a8 __attribute__((ext_vector_type(4), aligned(8)));             // rows are 8-byte aligned: dwordx4 store, dword alignment suffices
+          f4a8 ov = {o4.x, o4.y, o4.z, o4.w};
+          __builtin_nontemporal_store(ov, reinterpret_cast<f4a8*>(reinterpret_cast<char*>(row) + 16 * lane));   // written once, read by the next kernel
           if (lane == 0) row[N] = make_float2((zf0.x - zf0.y) * 2.0f * gh, 0.f);        // bin N: X = Re(Z0) - Im(Z0)
         }
       }
       wave_lds_sync();
     }
     if (more) {                                                // slide the window: shared samples to the front, new ones behind
-      __syncthreads();
-      for (int i4 = tid * 4; i4 < keepPhys; i4 += nthr * 4)    // keep < step: source and destination never overlap
-        *reinterpret_cast<float4*>(win + i4) = *reinterpret_cast<const float4*>(win + stepPhys + i4);
+      __syncthreads();                                          // every wave is done with this tile's window
+      float4 mv[2];                                             // keepPhys <= 2 * 4 * nthr (checked by the launcher)
+#pragma unroll
+      for (int j = 0; j < 2; j++) { const int i4 = (j * nthr + tid) * 4; mv[j] = (i4 < keepPhys) ? *reinterpret_cast<const float4*>(win + stepPhys + i4) : make_float4(0.f, 0.f, 0.f, 0.f); }
+      __syncthreads();                                          // the shared samples are in registers: their old place may be overwritten
+#pragma unroll
+      for (int j = 0; j < 2; j++) { const int i4 = (j * nthr + tid) * 4; if (i4 < keepPhys) *reinterpret_cast<float4*>(win + i4) = mv[j]; }
 #pragma unroll
       for (int j = 0; j < PF; j++) { const int i4 = (j * nthr + tid) * 4; if (i4 < step) *reinterpret_cast<float4*>(win + keepPhys + i4 + 32 * (i4 >> 7)) = pf[j]; }
       __syncthreads();
@@ -756,9 +760,11 @@ template <int MT> static void launch_analysis_q256(const FbPlan& p, const float*
                                                    long sampStride, int Tmax, float* X, hipStream_t st)
 {
   constexpr int M = 256;
-  const int TF = 32, waves = 4;                                // 8 frames per wave and pass over the tile; 4096 new samples = 4 float4 per thread
+  const int TF = 16, waves = 4;                                // one pass of the workgroup (4 waves x 4 frames) per tile; 2048 new samples = 2 float4 per thread
+  { const int keep = MT * M - p.D, keepPhys = keep + 32 * (keep >> 7); if (keepPhys > 2 * 4 * 64 * waves || TF * p.D > 2 * 4 * 64 * waves) throw Error(DSR_E_DIMENSION, "analysis tile does not fit the streaming kernel"); }
   const int winLen = (TF - 1) * p.D + MT * M, winPhys = winLen + 32 * ((winLen + 127) >> 7);
-  const size_t lds = sizeof(float2) * M + sizeof(float) * ((winPhys + 3) & ~3) + sizeof(float2) * (size_t) waves * 2 * 4 * 146;
+  size_t lds = sizeof(float2) * M + sizeof(float) * ((winPhys + 3) & ~3) + sizeof(float2) * (size_t) (M / 2) * MT + sizeof(float2) * (size_t) waves * 1 * 4 * 146;
+  if (const char* e = getenv("DSR_FB_PADLDS")) lds += (size_t) atoi(e);          // occupancy experiments
   DSR_HIP(hipFuncSetAttribute((const void*) k_analysis_q256<MT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
   dim3 grid((unsigned) U * (unsigned) C, 1, 1);
   hipLaunchKernelGGL((k_analysis_q256<MT>), grid, dim3(64 * waves), lds, st, x, nsamp, p.d_proto.p, p.d_tw.p, (float2*) X, C,

@@ -72,6 +72,21 @@ def test_synthesis_bank(dsr, oracle, cuda, headset, protos, pname, dct):
         assert np.all(y[u, len(ref):] == 0)
 
 
+def test_analysis_many_rows(dsr, cuda, protos):
+    """More (utterance, channel) rows than compute units: several workgroups share a CU and its LDS, their waves interleave.
+    The result of every row must be the one it has alone (regression: a missing barrier between the window slide and the
+    store of the prefetched samples only showed with co-resident workgroups)."""
+    import torch
+    M, m, r, h, g = protos["M256-m4-r1"]
+    torch.manual_seed(3)
+    x = torch.randn((80, 8, 24000), device=cuda) * 3000.0               # 640 rows
+    ana = dsr.FilterBank(h, 256, 4, 1, False, 0)
+    X = ana.analysis(x)
+    for u in (0, 31, 32, 33, 64, 79):
+        Xs = ana.analysis(x[u:u + 1].contiguous())
+        assert torch.equal(X[u], Xs[0]), u
+
+
 def test_filterbank_roundtrip_full_size(dsr, cuda, headset, protos):
     """Size-independent property at BASELINE scale: analysis -> synthesis with the reference's own Nyquist(M)
     prototypes and delayCompensationType=2 reconstructs the input (x D, zero delay)."""
