@@ -271,6 +271,8 @@ __global__ __launch_bounds__(kThreads) void k_viterbi(GraphDev G, DecDev Dd, con
           uint4* ovf = reinterpret_cast<uint4*>(cB);                           // parked placements [slot - kFastK * nthr]
           double locMin = HUGE_VAL;
           const bool prevNull0 = (fr == 0);                                    // only the start token has no edge (decoder.h:960)
+          const double lmS = Dd.lmScale, lsPen = __dmul_rn(Dd.lmScale, Dd.lmPenalty), lsSil = __dmul_rn(Dd.lmScale, Dd.silPenalty);
+          const bool sil0 = (0u == Dd.silenceX);
 #pragma unroll
           for (int k = 0; k < kFastK; k++) { qac[k] = 0.0f; qlm[k] = 0.0f; qrec[k] = 0; ek[k] = 0u; }
 
@@ -316,29 +318,32 @@ __global__ __launch_bounds__(kThreads) void k_viterbi(GraphDev G, DecDev Dd, con
                 const int xdist = xr[i].x; const float xcost = __int_as_float(xr[i].y); const uint32_t xmeta = (uint32_t) xr[i].z;
                 const float e1 = __int_as_float(xr[i].w);
                 const int plen = (int) (xmeta & 0xFFFFu);
-                double lmNode = (double) lm8[i]; uint32_t prevIn = tsil[i] ? Dd.silenceX : (Dd.silenceX + 1u);   // only equality with silenceX matters
-                bool prevNull = prevNull0;
-                if (plen) {                                                    // intermediate epsilon tokens (decoder.h:979-983)
-                  {                                                            // first hop: its cost travels with the record
-                    double l = __dadd_rn(lmNode, __dmul_rn(Dd.lmScale, (double) e1));
-                    if (xmeta & 0x20000u) l = __dadd_rn(l, __dmul_rn(Dd.lmScale, Dd.lmPenalty));
-                    if (0u == Dd.silenceX && (prevNull || prevIn != Dd.silenceX)) l = __dadd_rn(l, __dmul_rn(Dd.lmScale, Dd.silPenalty));
-                    lmNode = (double) (float) l; prevIn = 0u; prevNull = false;
-                  }
-                  if (plen > 1) {
-                    const int* pp = G.path + G.xrecD[rec8[i]].pathOff;
-                    for (int h = 1; h < plen; h++) {
-                      const int a = pp[h];
-                      double l = __dadd_rn(lmNode, __dmul_rn(Dd.lmScale, (double) G.arcCost[a]));
-                      if (G.arcOut[a] != 0) l = __dadd_rn(l, __dmul_rn(Dd.lmScale, Dd.lmPenalty));
-                      lmNode = (double) (float) l;                              // (the edge before is an epsilon edge: no silence penalty possible here)
-                    }
+                // selects in place of branches: the additions that may not apply are computed and dropped (same values, one
+                // basic block -- the scalar operands are fetched once per placement instead of once per branch)
+                const double lm0 = (double) lm8[i];
+                const bool has = plen != 0;
+                double lmNode;
+                {                                                              // first epsilon hop (decoder.h:979-983): its cost travels with the record
+                  double l = __dadd_rn(lm0, __dmul_rn(lmS, (double) e1));
+                  const double l1 = __dadd_rn(l, lsPen); l = (xmeta & 0x20000u) ? l1 : l;
+                  const double l2 = __dadd_rn(l, lsSil); l = (sil0 && (prevNull0 || !tsil[i])) ? l2 : l;     // prevIn != silenceX <=> the token's edge was no silence edge
+                  lmNode = has ? (double) (float) l : lm0;
+                }
+                const bool pnull = has ? false : prevNull0;
+                const bool pinSil = has ? sil0 : tsil[i];                      // after an epsilon hop the edge input is 0
+                if (plen > 1) {
+                  const int* pp = G.path + G.xrecD[rec8[i]].pathOff;
+                  for (int h = 1; h < plen; h++) {
+                    const int a = pp[h];
+                    double l = __dadd_rn(lmNode, __dmul_rn(lmS, (double) G.arcCost[a]));
+                    if (G.arcOut[a] != 0) l = __dadd_rn(l, lsPen);
+                    lmNode = (double) (float) l;                                // (the edge before is an epsilon edge: no silence penalty possible here)
                   }
                 }
-                double lm = __dadd_rn(lmNode, __dmul_rn(Dd.lmScale, (double) xcost));
-                if (xmeta & 0x10000u) lm = __dadd_rn(lm, __dmul_rn(Dd.lmScale, Dd.lmPenalty));
+                double lm = __dadd_rn(lmNode, __dmul_rn(lmS, (double) xcost));
+                { const double lm1 = __dadd_rn(lm, lsPen); lm = (xmeta & 0x10000u) ? lm1 : lm; }
                 const bool silArc = ((uint32_t) (xdist + 1) == Dd.silenceX);
-                if (silArc && (prevNull || prevIn != Dd.silenceX)) lm = __dadd_rn(lm, __dmul_rn(Dd.lmScale, Dd.silPenalty));
+                { const double lm2 = __dadd_rn(lm, lsSil); lm = (silArc && (pnull || !pinSil)) ? lm2 : lm; }
                 const double ac = __dadd_rn((double) ac8[i], (double) (useLdsRow ? srow[xdist] : rowG[xdist]));
                 const double ttl = __dadd_rn(ac, lm);
                 ttlS[c] = ttl; ac8[i] = (float) ac; lm8[i] = (float) lm; rec8[i] |= (silArc ? 0x40000000 : 0);

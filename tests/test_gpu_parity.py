@@ -432,6 +432,54 @@ def test_full_pipe_small(dsr, oracle, cuda, protos):
         assert np.array_equal(wordsO[u, :res[u].nWords], ro["words"])
 
 
+def test_full_pipe_batch_invariance(dsr, cuda, protos):
+    """Every stage with far more workgroups than compute units (co-resident workgroups, several rounds, more utterances than
+    decoder slots): each utterance's intermediates and 1-best are bit-identical to those it gets in a batch of its own."""
+    import torch
+    M, m, r, h, g = protos["M256-m4-r1"]
+    Cn, U, n = 8, 300, 8000
+    rng = np.random.default_rng(77)
+    x = (rng.standard_normal((U, Cn, n)) * 2000.0).astype(np.float32)
+    lens = [n - 16 * (u % 5) for u in range(U)]
+    for u, L in enumerate(lens):
+        x[u, :, L:] = 0.0
+    ana = dsr.FilterBank(h, M, m, r, False, 0); syn = dsr.FilterBank(g, M, m, r, True, 0)
+    mp = synth.linear_array(Cn)
+    delays = dsr.calcDelaysPolar2(np.float32(np.deg2rad(30.0)), np.float32(np.pi / 2), mp)
+    bf = dsr.Beamformer(M, Cn); bf.calcArrayManifoldVectors(16000.0, delays); bf.setDiffuseNoiseModel(mp, 16000.0, 343740.0)
+    bf.divideAllNonDiagonalElements(0.01); bf.calcMVDRWeights(16000.0, 1e-8); bf.select("mvdr")
+    lda = (rng.standard_normal((39, 195)) / np.sqrt(195)).astype(np.float32)
+    K = 64
+    gm_m = synth.gmm_model(K, 16, 39, seed=12); gm_m["mean"] *= 3.0
+    gm = dsr.Gmm(**gm_m)
+    arcs, fin = synth.random_wfst(3000, K, seed=21)
+    gd = dsr.Wfst()
+    for a in arcs:
+        gd.add_arc(*a)
+    for st, c in fin:
+        gd.add_final(st, c)
+
+    def run(idx):
+        mf = dsr.Mfcc(lda=lda)
+        dec = dsr.Decoder(beam=60.0, lmScale=12.0, maxActive=16384); dec.set(gd)
+        pipe = dsr.Pipe(ana, syn, bf, mf, gm, dec, gmmMode=0)
+        xs = torch.from_numpy(np.ascontiguousarray(x[idx])).to(cuda); ls = [lens[i] for i in idx]
+        res, arcsO, wordsO = pipe.run(xs, torch.tensor(ls, dtype=torch.int32, device=cuda), ls, maxPath=512)
+        inter = [pipe.intermediate_host(k).copy() for k in range(5)]
+        return res, arcsO, wordsO, inter
+
+    allidx = list(range(U))
+    resA, arcsA, wordsA, interA = run(allidx)
+    for u in (0, 7, 255, 256, 299):
+        resS, arcsS, wordsS, interS = run([u])
+        for k in range(5):
+            per = interS[k].size                                     # one utterance's share; Tmax is the same (equal padded lengths)
+            assert np.array_equal(interA[k][u * per:(u + 1) * per].view(np.uint32), interS[k].view(np.uint32)), (u, k)
+        assert resA[u].status == 0 and resA[u].score == resS[0].score and resA[u].nArcs == resS[0].nArcs
+        nA, nW = resA[u].nArcs, resA[u].nWords
+        assert nW == resS[0].nWords and np.array_equal(arcsA[u, :nA], arcsS[0, :nA]) and np.array_equal(wordsA[u, :nW], wordsS[0, :nW])
+
+
 @pytest.mark.parametrize("K,R,D", [(256, 16, 39), (1024, 4, 39), (5, 7, 13), (3, 256, 39), (40, 33, 20)])
 def test_gmm_mfma_mode(dsr, oracle, cuda, K, R, D):
     """mode 2 (fp32 MFMA, expanded quadratic): stated tolerance rel 1e-5 on the cost; the nearest Gaussian is the
