@@ -428,7 +428,7 @@ __device__ __forceinline__ void fft8_pos(float2 (&v)[8])
   for (int h = 0; h < 8; h += 2) { const float2 a = cadd(v[h], v[h + 1]), b = csub(v[h], v[h + 1]); v[h] = a; v[h + 1] = b; }
 }
 
-template <int MT>
+template <int MT, int PF>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_analysis_q256(const float* __restrict__ x, const int* __restrict__ nsampArr,
                                                        const float* __restrict__ proto, const float2* __restrict__ twG,
                                                        float2* __restrict__ X, int C, long sampStride, int Tmax,
@@ -465,7 +465,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
   const int step = TF * D, keep = winLen - step;               // samples a tile brings in / shares with the tile before (multiples of 128)
   const int stepPhys = step + 32 * (step >> 7), keepPhys = keep + 32 * (keep >> 7);
   const bool vec = ((((uintptr_t) xs) | (uintptr_t) (sampStride * 4)) & 15) == 0;
-  constexpr int PF = 2;                                        // float4 per thread: step = TF D <= 4 * PF * nthr (TF = 16, 256 threads)
+  // PF float4 per thread bring in the next tile: step = TF D = 4 * PF * nthr samples (TF = 8 PF frames, 256 threads)
   const int l = lane & 15, q = lane >> 4;
   // prototype taps of this lane's points: h[2(l + 16e) + {0,1} + qq M]
   for (int i = tid; i < (M / 2) * MT; i += nthr) hT[i] = *reinterpret_cast<const float2*>(proto + 2 * i);   // 2 (n + 128 qq) = 2n + qq M
@@ -760,15 +760,20 @@ template <int MT> static void launch_analysis_q256(const FbPlan& p, const float*
                                                    long sampStride, int Tmax, float* X, hipStream_t st)
 {
   constexpr int M = 256;
-  const int TF = 16, waves = 4;                                // one pass of the workgroup (4 waves x 4 frames) per tile; 2048 new samples = 2 float4 per thread
-  { const int keep = MT * M - p.D, keepPhys = keep + 32 * (keep >> 7); if (keepPhys > 2 * 4 * 64 * waves || TF * p.D > 2 * 4 * 64 * waves) throw Error(DSR_E_DIMENSION, "analysis tile does not fit the streaming kernel"); }
+  int TF = 16; const int waves = 4;                            // TF = 16: one pass of the workgroup (4 waves x 4 frames) per tile, 4 workgroups per CU
+  if (const char* e = getenv("DSR_FB_TF")) { const int v = atoi(e); if (v == 16 || v == 32) TF = v; }
+  { const int keep = MT * M - p.D, keepPhys = keep + 32 * (keep >> 7); if (keepPhys > 2 * 4 * 64 * waves || TF * p.D > (TF / 8) * 4 * 64 * waves) throw Error(DSR_E_DIMENSION, "analysis tile does not fit the streaming kernel"); }
   const int winLen = (TF - 1) * p.D + MT * M, winPhys = winLen + 32 * ((winLen + 127) >> 7);
   size_t lds = sizeof(float2) * M + sizeof(float) * ((winPhys + 3) & ~3) + sizeof(float2) * (size_t) (M / 2) * MT + sizeof(float2) * (size_t) waves * 1 * 4 * 146;
   if (const char* e = getenv("DSR_FB_PADLDS")) lds += (size_t) atoi(e);          // occupancy experiments
-  DSR_HIP(hipFuncSetAttribute((const void*) k_analysis_q256<MT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
   dim3 grid((unsigned) U * (unsigned) C, 1, 1);
-  hipLaunchKernelGGL((k_analysis_q256<MT>), grid, dim3(64 * waves), lds, st, x, nsamp, p.d_proto.p, p.d_tw.p, (float2*) X, C,
-                     sampStride, Tmax, p.pd, p.laN, p.gain, TF);
+  if (TF == 16) {
+    DSR_HIP(hipFuncSetAttribute((const void*) k_analysis_q256<MT, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
+    hipLaunchKernelGGL((k_analysis_q256<MT, 2>), grid, dim3(64 * waves), lds, st, x, nsamp, p.d_proto.p, p.d_tw.p, (float2*) X, C, sampStride, Tmax, p.pd, p.laN, p.gain, TF);
+  } else {
+    DSR_HIP(hipFuncSetAttribute((const void*) k_analysis_q256<MT, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
+    hipLaunchKernelGGL((k_analysis_q256<MT, 4>), grid, dim3(64 * waves), lds, st, x, nsamp, p.d_proto.p, p.d_tw.p, (float2*) X, C, sampStride, Tmax, p.pd, p.laN, p.gain, TF);
+  }
   DSR_HIP(hipGetLastError());
 }
 
