@@ -14,7 +14,7 @@
 
 using namespace dsr;
 
-struct dsr_fb; struct dsr_bf; struct dsr_lpc; struct dsr_stft; struct dsr_prfb;
+struct dsr_fb; struct dsr_bf; struct dsr_lpc; struct dsr_stft; struct dsr_prfb; struct dsr_zelinski;
 
 struct dsr_stream {
   int refs = 1; std::string name; int size_ = 0; int type = DSR_T_FLOAT; int frameX = -1; bool endOfSamples = false;
@@ -189,6 +189,28 @@ struct BfOp : dsr_stream {           // SubbandDS / SubbandGSC / SubbandMVDR as 
   }
 };
 
+struct ZelinskiOp : dsr_stream {     // ZelinskiPostFilter (postfilter.cc:350-493): ups[0] = beamformer output, ups[1..] = the snapshot array's channels
+  dsr_zelinski* plan = nullptr; int M = 0; double alpha = 0.6; int ptype = 2, minFrames = 0; std::vector<std::vector<double>> manifold; int chanSet = 0;
+  DevBuf<float2> X, Y, O; DevBuf<int> nf;
+  ~ZelinskiOp() override { if (plan) dsr_zelinski_destroy(plan); }
+  void compute() override {
+    const int C = (int) ups.size() - 1;
+    if (C < 1 || chanSet == 0) throw Error(DSR_E_ERROR, "set beamformer's weights");                     // postfilter.cc:447-450
+    if (chanSet != C) throw Error(DSR_E_DIMENSION, "array manifold has %d channels, the snapshot array %d", chanSet, C);
+    int T = ups[0]->nFrames; for (int c = 1; c <= C; c++) if (ups[c]->nFrames < T) T = ups[c]->nFrames;
+    alloc(T); if (T <= 0) return;
+    if (plan) { dsr_zelinski_destroy(plan); plan = nullptr; }
+    dsr_status s = dsr_zelinski_create(M, C, alpha, ptype, minFrames, &plan); if (s) throw Error(s, "%s", dsr_last_error());
+    for (int f = 0; f <= M / 2; f++) if (!manifold[f].empty()) dsr_zelinski_set_manifold(plan, f, manifold[f].data());
+    const int F = M / 2 + 1; X.reserve((size_t) C * T * F); Y.reserve((size_t) T * F); O.reserve((size_t) T * F);
+    for (int c = 0; c < C; c++) op_pack_bins(ups[c + 1]->d<double2>(), T, F, M, X.p + (size_t) c * T * F, S0);
+    op_pack_bins(ups[0]->d<double2>(), T, F, M, Y.p, S0);
+    nf.upload(&T, 1);
+    s = dsr_zelinski_apply(plan, (const float*) X.p, (const float*) Y.p, nf.p, 1, T, (float*) O.p, nullptr, S0); if (s) throw Error(s, "%s", dsr_last_error());
+    op_expand_bins(O.p, T, F, M, d<double2>(), S0);
+  }
+};
+
 template <class T> T* mk(const char* name, const char* dflt, int size, int type) { T* s = new T(); s->name = (name && *name) ? name : dflt; s->size_ = size; s->type = type; return s; }
 dsr_stream* need(dsr_stream* s, int type, const char* what) {
   if (!s) throw Error(DSR_E_PARAMETER, "null upstream for %s", what);
@@ -302,6 +324,33 @@ dsr_status dsr_synthesis_bank_create(dsr_stream* samp, const double* prototype, 
     SynthesisOp* s = mk<SynthesisOp>(name, "OverSampledDFTSynthesisBank", M >> r, DSR_T_FLOAT); s->M = M; s->D = M >> r; s->checkOrder = false;
     dsr_status st = dsr_fb_create(prototype, M, m, r, 1, dct, gain, &s->fb); if (st) { delete s; throw Error(st, "%s", dsr_last_error()); }
     s->add_up(samp); *out = s;
+  });
+}
+dsr_status dsr_zelinski_stream_create(dsr_stream* output, int fftLen, double alpha, int type, int minFrames, const char* name, dsr_stream** out)
+{
+  return guard([&] {
+    need(output, DSR_T_COMPLEX, "ZelinskiPostFilter"); if (!out) throw Error(DSR_E_PARAMETER, "null argument");
+    if (output->size_ != fftLen) throw Error(DSR_E_DIMENSION, "Input block length (%d) != fftLen (%d)", output->size_, fftLen);      // postfilter.cc:359-362
+    ZelinskiOp* s = mk<ZelinskiOp>(name, "ZelinskPostFilter", fftLen, DSR_T_COMPLEX); s->M = fftLen; s->alpha = alpha; s->ptype = type; s->minFrames = minFrames;
+    s->manifold.assign((size_t) fftLen / 2 + 1, std::vector<double>()); s->checkOrder = false;
+    s->add_up(output); *out = s;
+  });
+}
+dsr_status dsr_zelinski_stream_set_channel(dsr_stream* pf, dsr_stream* chan)
+{
+  return guard([&] {
+    ZelinskiOp* q = dynamic_cast<ZelinskiOp*>(pf); if (!q) throw Error(DSR_E_PARAMETER, "not a Zelinski post-filter");
+    need(chan, DSR_T_COMPLEX, "ZelinskiPostFilter channel"); if (chan->size_ != q->M) throw Error(DSR_E_DIMENSION, "channel size %d != fftLen %d", chan->size_, q->M);
+    q->add_up(chan); q->ready = false;
+  });
+}
+dsr_status dsr_zelinski_stream_set_manifold(dsr_stream* pf, int fbinX, const double* vec, int chanN)
+{
+  return guard([&] {
+    ZelinskiOp* q = dynamic_cast<ZelinskiOp*>(pf); if (!q || !vec) throw Error(DSR_E_PARAMETER, "not a Zelinski post-filter");
+    if (fbinX < 0 || fbinX >= q->M) throw Error(DSR_E_DIMENSION, "fbinX %d must be less than %d", fbinX, q->M);
+    if (fbinX <= q->M / 2) q->manifold[fbinX].assign(vec, vec + 2 * (size_t) chanN);
+    q->chanSet = chanN; q->ready = false;
   });
 }
 dsr_status dsr_subband_bf_create(dsr_bf* weights, const char* name, dsr_stream** out)

@@ -76,6 +76,8 @@ def load():
         "dsr_prfb_analysis": [vp, vp, vp, C.c_int, C.c_int, i64, C.c_int, vp, vp], "dsr_prfb_synthesis": [vp, vp, vp, C.c_int, C.c_int, i64, vp, vp],
         "dsr_stft_create": [C.c_int, C.c_int, C.c_int, vp], "dsr_stft_destroy": [vp], "dsr_stft_frames": [vp, C.c_int], "dsr_stft_block_len": [vp],
         "dsr_stft_analysis": [vp, vp, vp, C.c_int, C.c_int, i64, C.c_int, vp, vp],
+        "dsr_zelinski_create": [C.c_int, C.c_int, f64, C.c_int, C.c_int, vp], "dsr_zelinski_destroy": [vp], "dsr_zelinski_set_manifold": [vp, C.c_int, vp],
+        "dsr_zelinski_apply": [vp, vp, vp, vp, C.c_int, C.c_int, vp, vp, vp],
         "dsr_lpc_create": [C.c_int, C.c_int, C.c_int, f32, C.c_int, C.c_int, vp], "dsr_lpc_destroy": [vp], "dsr_lpc_size": [vp],
         "dsr_lpc_run": [vp, vp, i64, vp, vp],
         "dsr_mfcc_default_cfg": [vp], "dsr_mfcc_create": [vp, vp, vp], "dsr_mfcc_destroy": [vp], "dsr_mfcc_frames": [vp, C.c_int],
@@ -309,6 +311,32 @@ class NormalFFTBank:
         X = torch.zeros((U, Cn, T, self.M), dtype=torch.complex64, device=x.device)
         check(_lib.dsr_stft_analysis(self.h, _dev(x), _dev(nsamp), U, Cn, N, T, _dev(X), cur_stream()))
         return X
+
+
+class ZelinskiPostFilter:
+    """Zelinski post-filter (postfilter.cc:8-221,350-493); manifold [M/2+1][C] complex = arrayManifold() (or wq() with type | 8)."""
+
+    def __init__(self, fftLen, chanN, manifold, alpha=0.6, type=2, minFrames=0):
+        L = load(); self.h = vp(); self.M, self.C = fftLen, chanN
+        check(L.dsr_zelinski_create(fftLen, chanN, alpha, type, minFrames, C.byref(self.h)))
+        m = np.ascontiguousarray(manifold, np.complex128)
+        for f in range(fftLen // 2 + 1):
+            check(L.dsr_zelinski_set_manifold(self.h, f, _ptr(m[f])))
+
+    def __del__(self):
+        if _lib is not None and getattr(self, "h", None):
+            _lib.dsr_zelinski_destroy(self.h)
+
+    def apply(self, X, Y, nframes=None, want_weights=False):
+        """X: cuda complex64 [U][C][T][F], Y: [U][T][F] -> out [U][T][F] (and the weights [U][T][F] fp32)"""
+        import torch
+        U, Cn, T, F = X.shape
+        if nframes is None:
+            nframes = torch.full((U,), T, dtype=torch.int32, device=X.device)
+        out = torch.zeros((U, T, F), dtype=torch.complex64, device=X.device)
+        w = torch.zeros((U, T, F), dtype=torch.float32, device=X.device) if want_weights else None
+        check(_lib.dsr_zelinski_apply(self.h, _dev(X.contiguous()), _dev(Y.contiguous()), _dev(nframes), U, T, _dev(out), _dev(w) if want_weights else None, cur_stream()))
+        return (out, w) if want_weights else out
 
 
 class LpcEnvelope:

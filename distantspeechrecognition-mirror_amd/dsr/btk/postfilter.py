@@ -1,0 +1,34 @@
+"""btk.postfilter: ZelinskiPostFilterPtr (postfilter.i:77-90, postfilter.h:95-126)."""
+import ctypes as C
+
+import numpy as np
+
+from .. import _capi as K
+from .stream import FeatureStreamPtr, lib, _new
+
+TYPE_ZELINSKI1_REAL, TYPE_ZELINSKI1_ABS, TYPE_APAB, TYPE_ZELINSKI2, NO_USE_POST_FILTER = 0x01, 0x02, 0x04, 0x08, 0x00
+
+
+class ZelinskiPostFilterPtr(FeatureStreamPtr):
+    def __init__(self, output, M, alpha=0.6, type=2, minFrames=0, nm="ZelinskPostFilter"):
+        h, _ = _new(lib().dsr_zelinski_stream_create, output._h, int(M), float(alpha), int(type), int(minFrames), nm.encode())
+        FeatureStreamPtr.__init__(self, h, keep=(output,)); self._M = M; self._type = type; self._chans = []
+
+    def setBeamformer(self, bf):
+        """the beamformer's snapshot array (its channel streams) and its weight object (postfilter.cc:376-385,441-444):
+        arrayManifold(), or wq() for TYPE_ZELINSKI2 -- both are the delay-and-sum vectors of calcArrayManifoldVectors here"""
+        w = bf._weights().get(0)
+        for c in bf._chans:
+            K.check(lib().dsr_zelinski_stream_set_channel(self._h, c._h)); self._chans.append(c)
+        for f in range(self._M // 2 + 1):
+            self.setArrayManifoldVector(f, w[f], False)
+
+    def setSnapShotArray(self, channels):
+        for c in channels:
+            K.check(lib().dsr_zelinski_stream_set_channel(self._h, c._h)); self._chans.append(c)
+
+    def setArrayManifoldVector(self, fbinX, arrayManifoldVector, halfBandShift=False, NC=1):
+        if halfBandShift:
+            raise K.DsrError(2, "halfBandShift==true is not supported")
+        v = np.ascontiguousarray(arrayManifoldVector, np.complex128)
+        K.check(lib().dsr_zelinski_stream_set_manifold(self._h, int(fbinX), v.ctypes.data_as(C.c_void_p), v.size))

@@ -152,6 +152,17 @@ DSR_LPC_OP(WarpLPCFeature, 0, 1, "LPC")
 DSR_LPC_OP(BurgLPCFeature, 1, 1, "LPC")
 #undef DSR_LPC_OP
 
+// ---- btk/postfilter/postfilter.h:95-126
+class ZelinskiPostFilter : public VectorComplexFeatureStream {
+ public:
+  ZelinskiPostFilter(VectorComplexFeatureStreamPtr& output, unsigned fftLen, double alpha = 0.6, int type = 2, int minFrames = 0, const String& nm = "ZelinskPostFilter")
+  : _s(output) { DSR_OP(ZelinskiPostFilter, cplx, dsr_zelinski_stream_create(output->handle(), (int) fftLen, alpha, type, minFrames, nm.c_str(), &h)) }
+  void setSnapShotChannel(VectorComplexFeatureStreamPtr& chan) { dsr_throw(dsr_zelinski_stream_set_channel(_h, chan->handle())); _chans.push_back(chan); }
+  void setArrayManifoldVector(unsigned fbinX, const double* vec, unsigned chanN, bool halfBandShift = false, unsigned NC = 1)
+  { (void) halfBandShift; (void) NC; dsr_throw(dsr_zelinski_stream_set_manifold(_h, (int) fbinX, vec, (int) chanN)); }
+ private: VectorComplexFeatureStreamPtr _s; std::vector<VectorComplexFeatureStreamPtr> _chans;
+};
+
 // ---- btk/modulated/modulated.h
 class NormalFFTAnalysisBank : public VectorComplexFeatureStream {
  public:

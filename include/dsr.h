@@ -290,6 +290,22 @@ dsr_status dsr_stft_analysis(const dsr_stft*, const float* x_dev, const int32_t*
                              int64_t sampStride, int Tmax, float* X_dev, void* stream);
 
 /* =====================================================================================
+ * 6a. Zelinski post-filter on the beamformer output  (btk/postfilter/postfilter.cc:8-221,350-493:
+ *     calcCSD, TimeAlignment, ZelinskiFilter_f, ZelinskiFilter, ZelinskiPostFilter; halfBandShift == false)
+ *     type: 1 = Re(sum of CSDs), 2 = |sum| (the SWIG default), +8 = TYPE_ZELINSKI2 (the caller then passes wq() instead of
+ *     arrayManifold() to set_manifold).  The densities start from scratch in every utterance (alpha = 0 for its first two
+ *     frames, postfilter.cc:463-466); frames with frameX-1 < minFrames pass unfiltered (:471-473).
+ *     X_dev [U][C][Tmax][M/2+1] complex64 (the analysis banks' snapshots), Y_dev [U][Tmax][M/2+1] complex64 (beamformer
+ *     output) -> out_dev [U][Tmax][M/2+1]; wp1_dev (optional) [U][Tmax][M/2+1] fp32 = getPostFilterWeights().
+ * ===================================================================================== */
+typedef struct dsr_zelinski dsr_zelinski;
+dsr_status dsr_zelinski_create(int fftLen, int chanN, double alpha, int type, int minFrames, dsr_zelinski** out);
+void       dsr_zelinski_destroy(dsr_zelinski*);
+dsr_status dsr_zelinski_set_manifold(dsr_zelinski*, int fbinX, const double* vec /* chanN complex128 */);   /* setArrayManifoldVector */
+dsr_status dsr_zelinski_apply(dsr_zelinski*, const float* X_dev, const float* Y_dev, const int32_t* nframes_dev, int U, int Tmax,
+                              float* out_dev, float* wp1_dev, void* stream);
+
+/* =====================================================================================
  * 6b. LPC / MVDR spectral envelopes  (btk/feature/lpc.cc:44-207, lpc.h:134-195,291-331:
  *     WarpMVDRFeature, BurgMVDRFeature, WarpLPCFeature, BurgLPCFeature)
  *     method 0 = WarpFeature (warped autocorrelation + Levinson-Durbin), 1 = BurgFeature;
@@ -337,6 +353,11 @@ dsr_status dsr_pr_analysis_bank_create(dsr_stream* samp, const double* prototype
 dsr_status dsr_pr_synthesis_bank_create(dsr_stream* samp, const double* prototype, int M, int m, int r, const char* name, dsr_stream** out);
 /* NormalFFTAnalysisBank(samp, M, r, windowType) (modulated.i); samp delivers blocks of D = M >> r samples */
 dsr_status dsr_normal_fft_bank_create(dsr_stream* samp, int M, int r, int windowType, const char* name, dsr_stream** out);
+/* ZelinskiPostFilter(output, fftLen, alpha, type, minFrames) (postfilter.h:95-126): channels = the snapshot array's analysis
+   streams (setSnapShotArray / setBeamformer), manifold = setArrayManifoldVector per bin */
+dsr_status dsr_zelinski_stream_create(dsr_stream* output, int fftLen, double alpha, int type, int minFrames, const char* name, dsr_stream** out);
+dsr_status dsr_zelinski_stream_set_channel(dsr_stream* pf, dsr_stream* chan);
+dsr_status dsr_zelinski_stream_set_manifold(dsr_stream* pf, int fbinX, const double* vec, int chanN);
 /* SubbandDS/GSC/MVDR as a stream: channels are analysis-bank streams (setChannel) */
 dsr_status dsr_subband_bf_create(dsr_bf* weights, const char* name, dsr_stream** out);
 dsr_status dsr_subband_bf_set_channel(dsr_stream* bf, dsr_stream* chan);

@@ -244,6 +244,18 @@ def gsc_apply(X, wq, B, wa, normalize=False):
 
 
 # ------------------------------------------------------------------ MFCC chain
+def zelinski_postfilter(X, Y, wq, alpha=0.6, type=2, minFrames=0):
+    """X [C][T][F], Y [T][F], wq [F][C] complex -> (out [T][F] complex128, wp1 [T][F]) (postfilter.cc:56-221,428-493)."""
+    X = np.ascontiguousarray(X, np.complex128); Y = np.ascontiguousarray(Y, np.complex128); wq = np.ascontiguousarray(wq, np.complex128)
+    Cn, T, F = X.shape
+    out = np.zeros((T, F), np.complex128); wp1 = np.zeros((T, F), np.float64)
+    L = lib(); L.orc_zelinski_postfilter.restype = C.c_int
+    rc = L.orc_zelinski_postfilter(_p(X), _p(Y), _p(wq), Cn, T, F, C.c_double(alpha), type, minFrames, _p(out), _p(wp1))
+    if rc != 0:
+        raise ValueError("The number of channels %d is <= 1" % Cn)
+    return out, wp1
+
+
 def lpc_feature(frames, order, warp=0.0, method=0, kind=0):
     """WarpMVDR/BurgMVDR (kind 0) and WarpLPC/BurgLPC (kind 1) spectral envelopes, lpc.h:134-195,291-331."""
     L = lib(); fr = _f32(frames); T, dim = fr.shape

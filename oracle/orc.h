@@ -26,6 +26,10 @@
 extern "C" {
 #endif
 
+/* ---------------- Zelinski post-filter (btk/postfilter/postfilter.cc:8-221,428-493) ---------------- */
+int  orc_zelinski_postfilter(const double* X, const double* Y, const double* wq, int C, int T, int F, double alpha, int type, int minFrames,
+                             double* out, double* wp1);
+
 /* ---------------- LPC / MVDR spectral envelopes (btk/feature/lpc.cc, lpc.h) ---------------- */
 int  orc_lpc_npoints(int dim);
 void orc_lpc_fft_power(float* power, int dim);

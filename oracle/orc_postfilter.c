@@ -1,0 +1,72 @@
+/*
+ * oracle/orc_postfilter.c -- TEST INFRASTRUCTURE, NOT PRODUCT CODE (see orc.h).
+ *
+ * CPU restatement of the Zelinski post-filter of btk/postfilter:
+ *   calcCSD                     btk/postfilter/postfilter.cc:8-21
+ *   TimeAlignment               :30-43
+ *   ZelinskiFilter_f            :56-139   (Eq. (4) of the cited paper; spectral floor 1e-4, clamp at 1)
+ *   ZelinskiFilter              :157-221  (halfBandShift == false: bins 0..M/2, conjugate mirror)
+ *   ZelinskiPostFilter::next    :428-493  (alpha = 0 for the first two frames, minFrames, TYPE_ZELINSKI2 uses wq)
+ * Parity unpinned: the reference holds no outputs for this operator; restated from the source text.
+ * All arithmetic is fp64 as in the reference (gsl_complex).
+ */
+#include "orc.h"
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+/* X: [C][T][F] complex double (snapshots, bins 0..M/2), Y: [T][F] complex double (beamformer output), wq: [F][C] complex double
+ * (arrayManifold() -- or wq() when type has TYPE_ZELINSKI2 = 8).  out: [T][F] complex double, wp1: [T][F] double (may be NULL).
+ * type: 1 Re(.), 2 |.| (the SWIG default), +8 ZELINSKI2.  returns 0, -1 when C <= 1 (jdimension_error, :63-66) */
+int orc_zelinski_postfilter(const double* X, const double* Y, const double* wq, int C, int T, int F, double alpha_, int type, int minFrames,
+                            double* out, double* wp1)
+{
+  if (C <= 1) return -1;
+  const int NP = C * C;
+  double* csd = (double*) calloc((size_t) F * NP * 2, sizeof(double));       /* prevCSDs[fbin][i*C+j] */
+  double* ta = (double*) calloc((size_t) C * 2, sizeof(double));
+  for (int t = 0; t < T; t++) {
+    const int frameX = t - 1;                                                 /* _frameX before _increment() */
+    const double alpha = (frameX > 0) ? alpha_ : 0.0;                         /* :463-466 */
+    const int pfType = (frameX < minFrames) ? 0 : type;                       /* :471-476, NO_USE_POST_FILTER = 0 */
+    for (int f = 0; f < F; f++) {
+      double* prev = csd + (size_t) f * NP * 2;
+      for (int i = 0; i < C; i++) {                                           /* TimeAlignment: conj(d_i) x_i */
+        const double dr = wq[((size_t) f * C + i) * 2], di = -wq[((size_t) f * C + i) * 2 + 1];
+        const double xr = X[(((size_t) i * T + t) * F + f) * 2], xi = X[(((size_t) i * T + t) * F + f) * 2 + 1];
+        ta[2*i] = dr * xr - di * xi; ta[2*i+1] = dr * xi + di * xr;            /* gsl_complex_mul(dsf, xsf) */
+      }
+      double sr = 0.0, si = 0.0;
+      for (int i = 0; i < C - 1; i++)
+        for (int j = i + 1; j < C; j++) {
+          const int idx = i * C + j;
+          const double ar = ta[2*i], ai = ta[2*i+1], br = ta[2*j], bi = -ta[2*j+1];   /* xi * conj(xj) */
+          const double pr = ar * br - ai * bi, pi = ar * bi + ai * br;
+          double er, ei;
+          if (alpha > 0.0) { er = prev[2*idx] * alpha + pr * (1.0 - alpha); ei = prev[2*idx+1] * alpha + pi * (1.0 - alpha); }
+          else { er = pr; ei = pi; }
+          sr += er; si += ei; prev[2*idx] = er; prev[2*idx+1] = ei;
+        }
+      double numerator;
+      if (1 & pfType) { numerator = sr; if (numerator < 0.0) numerator = 0.0; }
+      else numerator = hypot(sr, si);                                         /* gsl_complex_abs */
+      double denominator = 0.0;
+      for (int i = 0; i < C; i++) {
+        const int idx = i * C + i;
+        const double a2 = ta[2*i] * ta[2*i] + ta[2*i+1] * ta[2*i+1];          /* gsl_complex_abs2 */
+        double est;
+        if (alpha > 0.0) est = alpha * prev[2*idx] + (1.0 - alpha) * a2; else est = a2;
+        denominator += est; prev[2*idx] = est; prev[2*idx+1] = 0.0;
+      }
+      double W = (numerator / denominator) * (2.0 / (C - 1.0));
+      if (W >= 1.0) W = 1.0;
+      if (W < 0.0001) W = 0.0001;
+      if (wp1) wp1[(size_t) t * F + f] = W;
+      const double yr = Y[((size_t) t * F + f) * 2], yi = Y[((size_t) t * F + f) * 2 + 1];
+      if (pfType == 0) { out[((size_t) t * F + f) * 2] = yr; out[((size_t) t * F + f) * 2 + 1] = yi; }
+      else { out[((size_t) t * F + f) * 2] = W * yr - 0.0 * yi; out[((size_t) t * F + f) * 2 + 1] = W * yi + 0.0 * yr; }   /* polar(W, 0) * y */
+    }
+  }
+  free(csd); free(ta);
+  return 0;
+}

@@ -615,3 +615,64 @@ def test_pr_fft_banks(dsr, oracle, cuda, headset, M, m, r):
     assert np.abs(rows - wy2).max() < 2e-4 * np.sqrt(np.mean(wy2.astype(np.float64) ** 2)) * np.sqrt(2 * M)
     with pytest.raises(Exception):
         Mo.PerfectReconstructionFFTAnalysisBankPtr(samp, h[:-1], M, m, r)
+
+
+# ------------------------------------------------------------------------------------------- Zelinski post-filter
+@pytest.mark.gpu
+@pytest.mark.parametrize("Cn,ptype,alpha,minFrames", [(8, 2, 0.6, 0), (8, 1, 0.6, 3), (4, 10, 0.9, 0), (2, 2, 0.0, 0), (13, 1, 0.5, 1)])
+def test_zelinski_postfilter(dsr, oracle, cuda, Cn, ptype, alpha, minFrames):
+    """postfilter.cc:8-221,428-493: fp64 recursions of the auto/cross spectral densities in the reference's order, one thread per
+    (utterance, bin).  Weights agree to 1e-6 relative (they leave as fp32), the filtered output to 1e-6 of its magnitude."""
+    import torch
+    rng = np.random.default_rng(5 + Cn)
+    U, T, M = 3, 40, 64
+    F = M // 2 + 1
+    wq = (np.exp(-1j * rng.uniform(0, 6, (F, Cn))) / Cn).astype(np.complex128)
+    s = rng.standard_normal((U, T, F)) + 1j * rng.standard_normal((U, T, F))
+    X = np.stack([s * np.conj(wq[:, c]) * Cn + 0.4 * (rng.standard_normal((U, T, F)) + 1j * rng.standard_normal((U, T, F))) for c in range(Cn)], axis=1)
+    X = X.astype(np.complex64); X[1, :, 7] = 0                           # an all-zero snapshot (0/0 in the weight: NaN, as in the reference)
+    Y = np.einsum("fc,uctf->utf", np.conj(wq), X.astype(np.complex128)).astype(np.complex64)
+    nfr = [T, T - 9, 1]
+    pf = dsr.ZelinskiPostFilter(M, Cn, wq, alpha=alpha, type=ptype, minFrames=minFrames)
+    got, w = pf.apply(torch.from_numpy(X).to(cuda), torch.from_numpy(Y).to(cuda), torch.tensor(nfr, dtype=torch.int32, device=cuda), want_weights=True)
+    got, w = got.cpu().numpy(), w.cpu().numpy()
+    for u in range(U):
+        n = nfr[u]
+        wo, ww = oracle.zelinski_postfilter(X[u, :, :n].astype(np.complex128), Y[u, :n].astype(np.complex128), wq, alpha, ptype, minFrames)
+        fin = np.isfinite(ww)
+        assert np.array_equal(fin, np.isfinite(w[u, :n]))
+        np.testing.assert_allclose(w[u, :n][fin], ww[fin], rtol=1e-6)
+        fo = np.isfinite(wo)
+        assert np.array_equal(fo, np.isfinite(got[u, :n]))
+        assert np.abs(got[u, :n][fo] - wo[fo]).max() <= 1e-6 * np.abs(wo[fo]).max()
+        assert not got[u, n:].any()
+
+
+@pytest.mark.gpu
+def test_zelinski_postfilter_stream(dsr, oracle, cuda, protos, headset):
+    """ZelinskiPostFilterPtr behind the stream protocol: analysis banks -> SubbandDS -> post-filter (setBeamformer)."""
+    from dsr.btk import feature as F, modulated as Mo, beamformer as B, postfilter as P
+    M, m, r, h, g = protos["M256-m4-r1"]
+    Cn, n = 4, 6000
+    x = synth.array_signal(n, Cn, seed=3)
+    mp = synth.linear_array(Cn)
+    delays = B.calcDelaysPolar2(np.deg2rad(30.0), np.pi / 2, mp)
+    D = M >> r
+    bf = B.SubbandDSPtr(fftLen=M)
+    chans = []
+    for c in range(Cn):
+        sm = F.SampleFeaturePtr(blockLen=D, shiftLen=D, padZeros=True); sm.setSamples(x[c], 16000)
+        a = Mo.OverSampledDFTAnalysisBankPtr(sm, h, M, m, r); chans.append(a); bf.setChannel(a)
+    bf.calcArrayManifoldVectors(16000.0, delays)
+    pf = P.ZelinskiPostFilterPtr(bf, M, alpha=0.7, type=2, minFrames=0)
+    pf.setBeamformer(bf)
+    rows = np.array([np.array(v) for v in pf])
+    Xc = np.stack([oracle.analysis_bank(x[c], h, M, m, r, 0) for c in range(Cn)])          # [C][T][M]
+    Fh = M // 2 + 1
+    wq = bf._weights().get(0)[:Fh]
+    Yo = np.einsum("fc,ctf->tf", np.conj(wq), Xc[:, :, :Fh])
+    wo, _ = oracle.zelinski_postfilter(Xc[:, :, :Fh], Yo, wq, 0.7, 2, 0)
+    assert rows.shape == (Xc.shape[1], M)
+    sc = np.abs(wo).max()
+    assert np.abs(rows[:, :Fh] - wo).max() < 5e-5 * sc                  # fp32 snapshots and beamformer output on the device
+    assert np.abs(rows[:, Fh:] - np.conj(rows[:, 1:Fh - 1][:, ::-1])).max() < 1e-12      # conjugate mirror (postfilter.cc:194-196,213-215)

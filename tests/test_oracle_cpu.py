@@ -373,3 +373,31 @@ def test_lpc_envelopes_against_numpy(oracle):
     assert Ab[0] == 1.0 and abs(Ab[1] - A[1]) < 0.05 and abs(Ab[2] - A[2]) < 0.05
     with pytest.raises(ValueError):
         oracle.lpc_feature(x[None], 161, 0.0, 0, 0)
+
+
+def test_zelinski_postfilter_against_numpy(oracle):
+    """postfilter.cc:56-221,428-493 restated vs a direct numpy recursion (alpha = 0 for the first two frames, minFrames, clamps)."""
+    rng = np.random.default_rng(2)
+    Cn, T, F, alpha, minFrames = 5, 12, 7, 0.6, 2
+    wq = np.exp(-1j * rng.uniform(0, 6, (F, Cn))) / Cn
+    X = rng.standard_normal((Cn, T, F)) + 1j * rng.standard_normal((Cn, T, F))
+    Y = np.einsum("fc,ctf->tf", np.conj(wq), X)
+    for ptype in (1, 2):
+        out, w = oracle.zelinski_postfilter(X, Y, wq, alpha, ptype, minFrames)
+        phi = np.zeros((F, Cn, Cn), complex)
+        for t in range(T):
+            a = alpha if t - 1 > 0 else 0.0
+            ta = np.conj(wq).T[:, None, :] * X[:, t:t + 1, :]          # [C][1][F]
+            ta = ta[:, 0, :]
+            for f in range(F):
+                outer = np.outer(ta[:, f], np.conj(ta[:, f]))
+                phi[f] = a * phi[f] + (1 - a) * outer if a > 0 else outer
+                iu = np.triu_indices(Cn, 1)
+                s = phi[f][iu].sum()
+                num = max(s.real, 0.0) if (ptype & 1) and (t - 1 >= minFrames) else abs(s)
+                W = min(max(num / np.trace(phi[f]).real * 2.0 / (Cn - 1.0), 1e-4), 1.0)
+                assert abs(W - w[t, f]) < 1e-12
+                ref = Y[t, f] if t - 1 < minFrames else W * Y[t, f]
+                assert abs(out[t, f] - ref) < 1e-12
+    with pytest.raises(ValueError):
+        oracle.zelinski_postfilter(X[:1], Y, wq[:, :1])
