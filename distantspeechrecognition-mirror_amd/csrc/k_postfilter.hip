@@ -65,6 +65,75 @@ __global__ __launch_bounds__(128) void k_zelinski(const float2* __restrict__ X, 
   }
 }
 
+// the same with the densities in registers (C(C-1)/2 complex + C real fp64 values per thread), for the usual small arrays:
+// no state traffic at all, the kernel then moves the algorithmic (C + 2) x 8 bytes per (frame, bin)
+template <int C>
+__global__ __launch_bounds__(64) void k_zelinski_reg(const float2* __restrict__ X, const float2* __restrict__ Y, const int* __restrict__ nframesArr,
+                                                     const double2* __restrict__ wq, float2* __restrict__ out, float* __restrict__ wp1,
+                                                     int U, int Tmax, int F, double alphaCfg, int type, int minFrames)
+{
+  constexpr int NP = C * (C - 1) / 2;
+  const long n = (long) blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= (long) U * F) return;
+  const int u = (int) (n / F), f = (int) (n - (long) u * F);
+  const int T = nframesArr[u] < Tmax ? nframesArr[u] : Tmax;
+  const float2* Xu = X + (long) u * C * Tmax * F;
+  const float2* Yu = Y + (long) u * Tmax * F;
+  float2* Ou = out + (long) u * Tmax * F;
+  double2 d[C];
+#pragma unroll
+  for (int i = 0; i < C; i++) { d[i] = wq[(long) f * C + i]; d[i].y = -d[i].y; }
+  double2 csd[NP]; double psd[C];
+#pragma unroll
+  for (int e = 0; e < NP; e++) csd[e] = make_double2(0.0, 0.0);
+#pragma unroll
+  for (int i = 0; i < C; i++) psd[i] = 0.0;
+  for (int t = 0; t < Tmax; t++) {
+    if (t >= T) { Ou[(long) t * F + f] = make_float2(0.f, 0.f); if (wp1) wp1[((long) u * Tmax + t) * F + f] = 0.f; continue; }
+    const int frameX = t - 1;
+    const double alpha = (frameX > 0) ? alphaCfg : 0.0;
+    const int pfType = (frameX < minFrames) ? 0 : type;
+    double2 ta[C];
+#pragma unroll
+    for (int i = 0; i < C; i++) {
+      const float2 x = Xu[((long) i * Tmax + t) * F + f];
+      const double xr = (double) x.x, xi = (double) x.y;
+      ta[i] = make_double2(d[i].x * xr - d[i].y * xi, d[i].x * xi + d[i].y * xr);
+    }
+    double sr = 0.0, si = 0.0;
+    {
+      int e = 0;
+#pragma unroll
+      for (int i = 0; i < C - 1; i++)
+#pragma unroll
+        for (int j = i + 1; j < C; j++, e++) {
+          const double ar = ta[i].x, ai = ta[i].y, br = ta[j].x, bi = -ta[j].y;
+          const double pr = ar * br - ai * bi, pi = ar * bi + ai * br;
+          double er = pr, ei = pi;
+          if (alpha > 0.0) { er = csd[e].x * alpha + pr * (1.0 - alpha); ei = csd[e].y * alpha + pi * (1.0 - alpha); }
+          sr += er; si += ei; csd[e] = make_double2(er, ei);
+        }
+    }
+    double numerator;
+    if (1 & pfType) { numerator = sr; if (numerator < 0.0) numerator = 0.0; }
+    else numerator = hypot(sr, si);
+    double denominator = 0.0;
+#pragma unroll
+    for (int i = 0; i < C; i++) {
+      const double a2 = ta[i].x * ta[i].x + ta[i].y * ta[i].y;
+      double est = a2;
+      if (alpha > 0.0) est = alpha * psd[i] + (1.0 - alpha) * a2;
+      denominator += est; psd[i] = est;
+    }
+    double W = (numerator / denominator) * (2.0 / ((double) C - 1.0));
+    if (W >= 1.0) W = 1.0;
+    if (W < 0.0001) W = 0.0001;
+    if (wp1) wp1[((long) u * Tmax + t) * F + f] = (float) W;
+    const float2 y = Yu[(long) t * F + f];
+    Ou[(long) t * F + f] = (pfType == 0) ? y : make_float2((float) (W * (double) y.x), (float) (W * (double) y.y));
+  }
+}
+
 struct ZelinskiPlan { int M = 0, C = 0, type = 2, minFrames = 0; double alpha = 0.6; std::vector<double> h_wq; bool dirty = true; DevBuf<double2> wq, state; };
 
 }  // namespace dsr
@@ -106,6 +175,11 @@ dsr_status dsr_zelinski_apply(dsr_zelinski* p, const float* X, const float* Y, c
     const int F = p->M / 2 + 1;
     if (p->dirty) { std::vector<double2> w((size_t) F * p->C); for (size_t i = 0; i < w.size(); i++) w[i] = make_double2(p->h_wq[2 * i], p->h_wq[2 * i + 1]); p->wq.upload(w); p->dirty = false; }
     const size_t S = (size_t) U * F, NE = (size_t) p->C * (p->C + 1) / 2;
+    const bool regs = !getenv("DSR_PF_MEMSTATE");
+#define ZREG(CC) if (regs && p->C == CC) { hipLaunchKernelGGL(k_zelinski_reg<CC>, dim3((unsigned) ((S + 63) / 64)), dim3(64), 0, st, (const float2*) X, (const float2*) Y, \
+      nframes_dev, p->wq.p, (float2*) out, wp1, U, Tmax, F, p->alpha, p->type, p->minFrames); DSR_HIP(hipGetLastError()); return; }
+    ZREG(2) ZREG(3) ZREG(4) ZREG(6) ZREG(8)
+#undef ZREG
     p->state.reserve(S * NE);
     hipLaunchKernelGGL(k_zelinski, dim3((unsigned) ((S + 127) / 128)), dim3(128), 0, st, (const float2*) X, (const float2*) Y, nframes_dev, p->wq.p, p->state.p,
                        (float2*) out, wp1, U, p->C, Tmax, F, p->alpha, p->type, p->minFrames);

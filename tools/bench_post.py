@@ -1,0 +1,26 @@
+#!/usr/bin/env python3
+"""Post-filter micro benchmark: B utterances x 8 ch, M=256 (129 bins), 1257 frames.  Algorithmic bytes per (frame, bin):
+(C + 1) x 8 read + 8 written."""
+import argparse, os, sys
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "distantspeechrecognition-mirror_amd"))
+import torch
+import dsr._capi as dsr
+ap = argparse.ArgumentParser(); ap.add_argument("--utts", type=int, default=512); ap.add_argument("--reps", type=int, default=5)
+a = ap.parse_args()
+dsr.load(); dev = torch.device("cuda:0")
+U, Cn, T, M = a.utts, 8, 1257, 256; F = M // 2 + 1
+X = torch.view_as_complex(torch.randn((U, Cn, T, F, 2), device=dev)); Y = torch.view_as_complex(torch.randn((U, T, F, 2), device=dev))
+wq = np.exp(-1j * np.random.default_rng(0).uniform(0, 6, (F, Cn))) / Cn
+pf = dsr.ZelinskiPostFilter(M, Cn, wq)
+nf = torch.full((U,), T, dtype=torch.int32, device=dev)
+out = torch.zeros((U, T, F), dtype=torch.complex64, device=dev)
+def run():
+    dsr.check(dsr._lib.dsr_zelinski_apply(pf.h, dsr._dev(X), dsr._dev(Y), dsr._dev(nf), U, T, dsr._dev(out), None, dsr.cur_stream()))
+run(); torch.cuda.synchronize()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
+for _ in range(a.reps): run()
+e1.record(); torch.cuda.synchronize(); ms = e0.elapsed_time(e1) / a.reps
+print("zelinski: %.3f ms  %.1f GB/s algorithmic (%d B x %d frame-bins)" % (ms, U * T * F * (Cn + 2) * 8 / ms / 1e6, (Cn + 2) * 8, U * T * F))
