@@ -65,6 +65,74 @@ __global__ __launch_bounds__(128) void k_zelinski(const float2* __restrict__ X, 
   }
 }
 
+// McCowanPostFilter (postfilter.cc:706-744,789-826,833-945): the same recursions, then the noise-coherence corrected estimate of the
+// clean-signal PSD averaged over the microphone pairs.  R: [F][C][C] noise coherence (fp64 complex), thr = _thresholdOfRij.
+__device__ __forceinline__ double2 cdiv_gsl(double ar, double ai, double br, double bi)
+{ const double s = 1.0 / hypot(br, bi); const double sbr = s * br, sbi = s * bi; return make_double2((ar * sbr + ai * sbi) * s, (ai * sbr - ar * sbi) * s); }
+
+__global__ __launch_bounds__(128) void k_mccowan(const float2* __restrict__ X, const float2* __restrict__ Y, const int* __restrict__ nframesArr,
+                                                 const double2* __restrict__ wq, const double2* __restrict__ R, double2* __restrict__ state,
+                                                 float2* __restrict__ out, float* __restrict__ wp1, int U, int C, int Tmax, int F, double alphaCfg, int type,
+                                                 int minFrames, double thr)
+{
+  const long n = (long) blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= (long) U * F) return;
+  const int u = (int) (n / F), f = (int) (n - (long) u * F);
+  const long S = (long) U * F;
+  const int T = nframesArr[u] < Tmax ? nframesArr[u] : Tmax;
+  const float2* Xu = X + (long) u * C * Tmax * F;
+  const float2* Yu = Y + (long) u * Tmax * F;
+  float2* Ou = out + (long) u * Tmax * F;
+  const double2* Rf = R + (long) f * C * C;
+  const int NPp = C * (C - 1) / 2;
+  double2 ta[16]; double psd[16];
+  for (int t = 0; t < Tmax; t++) {
+    if (t >= T) { Ou[(long) t * F + f] = make_float2(0.f, 0.f); if (wp1) wp1[((long) u * Tmax + t) * F + f] = 0.f; continue; }
+    const int frameX = t - 1;
+    const double alpha = (frameX > 0) ? alphaCfg : 0.0;
+    for (int i = 0; i < C; i++) {
+      const double2 d = wq[(long) f * C + i]; const float2 x = Xu[((long) i * Tmax + t) * F + f];
+      const double dr = d.x, di = -d.y, xr = (double) x.x, xi = (double) x.y;
+      ta[i] = make_double2(dr * xr - di * xi, dr * xi + di * xr);
+    }
+    int e = 0;
+    for (int i = 0; i < C - 1; i++)
+      for (int j = i + 1; j < C; j++, e++) {
+        const double ar = ta[i].x, ai = ta[i].y, br = ta[j].x, bi = -ta[j].y;
+        const double pr = ar * br - ai * bi, pi = ar * bi + ai * br;
+        double er = pr, ei = pi;
+        if (alpha > 0.0) { const double2 p = state[(long) e * S + n]; er = p.x * alpha + pr * (1.0 - alpha); ei = p.y * alpha + pi * (1.0 - alpha); }
+        state[(long) e * S + n] = make_double2(er, ei);
+      }
+    double sumOfPSD = 0.0;
+    for (int i = 0; i < C; i++) {
+      const double a2 = ta[i].x * ta[i].x + ta[i].y * ta[i].y;
+      double est = a2;
+      if (alpha > 0.0) est = alpha * state[(long) (NPp + i) * S + n].x + (1.0 - alpha) * a2;
+      sumOfPSD += est; psd[i] = est; state[(long) (NPp + i) * S + n] = make_double2(est, 0.0);
+    }
+    const double de = sumOfPSD / (double) C;
+    double sr = 0.0, si = 0.0; e = 0;
+    for (int i = 0; i < C - 1; i++)
+      for (int j = i + 1; j < C; j++, e++) {
+        const double2 phi = state[(long) e * S + n];
+        double2 r = Rf[i * C + j];
+        if (r.x > thr && r.y <= 0.0) r = make_double2(thr, 0.0);
+        const double hs = 0.5 * (psd[i] + psd[j]);
+        const double2 q = cdiv_gsl(phi.x - r.x * hs, phi.y - r.y * hs, -r.x + 1.0, -r.y);
+        sr += q.x; si += q.y;
+      }
+    const double avg = (1 & type) ? sr : hypot(sr, si);
+    const double nu = 2.0 * avg / (double) (C * (C - 1));
+    double W = nu / de;
+    if (W > 1.0) W = 1.0;
+    if (W < 0.0001) W = 0.0001;
+    if (wp1) wp1[((long) u * Tmax + t) * F + f] = (float) W;
+    const float2 y = Yu[(long) t * F + f];
+    Ou[(long) t * F + f] = (frameX >= minFrames) ? make_float2((float) ((double) y.x * W), (float) ((double) y.y * W)) : y;
+  }
+}
+
 // the same with the densities in registers (C(C-1)/2 complex + C real fp64 values per thread), for the usual small arrays:
 // no state traffic at all, the kernel then moves the algorithmic (C + 2) x 8 bytes per (frame, bin)
 template <int C>
@@ -134,7 +202,8 @@ __global__ __launch_bounds__(64) void k_zelinski_reg(const float2* __restrict__ 
   }
 }
 
-struct ZelinskiPlan { int M = 0, C = 0, type = 2, minFrames = 0; double alpha = 0.6; std::vector<double> h_wq; bool dirty = true; DevBuf<double2> wq, state; };
+struct ZelinskiPlan { int M = 0, C = 0, type = 2, minFrames = 0; double alpha = 0.6; std::vector<double> h_wq; bool dirty = true; DevBuf<double2> wq, state;
+                      int kind = 0; double threshold = 0.99; std::vector<double> h_R; bool haveR = false, dirtyR = true; DevBuf<double2> R; };   // kind 1: McCowan
 
 }  // namespace dsr
 
@@ -157,6 +226,66 @@ dsr_status dsr_zelinski_create(int fftLen, int chanN, double alpha, int type, in
   });
 }
 void dsr_zelinski_destroy(dsr_zelinski* p) { delete p; }
+
+// McCowanPostFilter (postfilter.h:128-..., postfilter.cc:502-945): a Zelinski object with a noise coherence matrix per bin
+dsr_status dsr_mccowan_create(int fftLen, int chanN, double alpha, int type, int minFrames, float threshold, dsr_zelinski** out)
+{
+  const dsr_status s = dsr_zelinski_create(fftLen, chanN, alpha, type, minFrames, out);
+  if (s != DSR_OK) return s;
+  (*out)->kind = 1; (*out)->threshold = (double) threshold; (*out)->h_R.assign((size_t) (fftLen / 2 + 1) * chanN * chanN * 2, 0.0);
+  return DSR_OK;
+}
+dsr_status dsr_mccowan_set_noise_matrix(dsr_zelinski* p, int fbinX, const double* Rnn)
+{
+  return guard([&] {
+    if (!p || !Rnn || p->kind != 1) throw Error(DSR_E_PARAMETER, "not a McCowan post-filter");
+    if (fbinX < 0 || fbinX > p->M / 2) throw Error(DSR_E_DIMENSION, "fbinX %d out of range", fbinX);
+    memcpy(&p->h_R[(size_t) fbinX * p->C * p->C * 2], Rnn, sizeof(double) * 2 * p->C * p->C); p->haveR = true; p->dirtyR = true;
+  });
+}
+dsr_status dsr_mccowan_set_diffuse_noise_model(dsr_zelinski* p, const double* micPos, double sampleRate, double sspeed)
+{
+  return guard([&] {                                            // postfilter.cc:568-626
+    if (!p || !micPos || p->kind != 1) throw Error(DSR_E_PARAMETER, "not a McCowan post-filter");
+    const int C = p->C, F = p->M / 2 + 1;
+    for (int f = 0; f < F; f++) {
+      const double omega_d_c = 2.0 * sampleRate * f / (p->M * sspeed);
+      double* Rf = &p->h_R[(size_t) f * C * C * 2];
+      for (int m = 0; m < C; m++)
+        for (int n = 0; n < m; n++) {
+          const double dx = micPos[3 * m] - micPos[3 * n], dy = micPos[3 * m + 1] - micPos[3 * n + 1], dz = micPos[3 * m + 2] - micPos[3 * n + 2];
+          const double x = omega_d_c * sqrt(dx * dx + dy * dy + dz * dz);
+          Rf[(m * C + n) * 2] = (x == 0.0) ? 1.0 : sin(M_PI * x) / (M_PI * x); Rf[(m * C + n) * 2 + 1] = 0.0;     // gsl_sf_sinc
+        }
+      for (int m = 0; m < C; m++) { Rf[(m * C + m) * 2] = 1.0; Rf[(m * C + m) * 2 + 1] = 0.0; }
+      for (int m = 0; m < C; m++) for (int n = m + 1; n < C; n++) { Rf[(m * C + n) * 2] = Rf[(n * C + m) * 2]; Rf[(m * C + n) * 2 + 1] = Rf[(n * C + m) * 2 + 1]; }
+    }
+    p->haveR = true; p->dirtyR = true;
+  });
+}
+dsr_status dsr_mccowan_diagonal_loading(dsr_zelinski* p, int fbinX, float diagonalWeight)
+{
+  return guard([&] {                                            // setAllLevelsOfDiagonalLoading (fbinX < 0) / setLevelOfDiagonalLoading, :628-657
+    if (!p || p->kind != 1) throw Error(DSR_E_PARAMETER, "not a McCowan post-filter");
+    if (!p->haveR) throw Error(DSR_E_ERROR, "Construct/set first a noise coherence matrix");
+    const int C = p->C, F = p->M / 2 + 1;
+    for (int f = (fbinX < 0 ? 0 : fbinX); f < (fbinX < 0 ? F : fbinX + 1); f++) for (int c = 0; c < C; c++) p->h_R[((size_t) f * C * C + c * C + c) * 2] += (double) diagonalWeight;
+    p->dirtyR = true;
+  });
+}
+dsr_status dsr_mccowan_divide_nondiagonal(dsr_zelinski* p, float myu)
+{
+  return guard([&] {                                            // divideAllNonDiagonalElements, :664-682 (gsl_complex_div by (1 + myu, 0))
+    if (!p || p->kind != 1) throw Error(DSR_E_PARAMETER, "not a McCowan post-filter");
+    const int C = p->C, F = p->M / 2 + 1; const double br = 1.0 + (double) myu;
+    for (int f = 0; f < F; f++) for (int a = 0; a < C; a++) for (int b = 0; b < C; b++) if (a != b) {
+      double* z = &p->h_R[((size_t) f * C * C + a * C + b) * 2];
+      const double s = 1.0 / hypot(br, 0.0), sbr = s * br, sbi = s * 0.0; const double zr = (z[0] * sbr + z[1] * sbi) * s, zi = (z[1] * sbr - z[0] * sbi) * s;
+      z[0] = zr; z[1] = zi;
+    }
+    p->dirtyR = true;
+  });
+}
 dsr_status dsr_zelinski_set_manifold(dsr_zelinski* p, int fbinX, const double* vec)
 {
   return guard([&] {
@@ -175,6 +304,15 @@ dsr_status dsr_zelinski_apply(dsr_zelinski* p, const float* X, const float* Y, c
     const int F = p->M / 2 + 1;
     if (p->dirty) { std::vector<double2> w((size_t) F * p->C); for (size_t i = 0; i < w.size(); i++) w[i] = make_double2(p->h_wq[2 * i], p->h_wq[2 * i + 1]); p->wq.upload(w); p->dirty = false; }
     const size_t S = (size_t) U * F, NE = (size_t) p->C * (p->C + 1) / 2;
+    if (p->kind == 1) {
+      if (!p->haveR) throw Error(DSR_E_ERROR, "McCowanPostFilter: construct/set a noise coherence matrix");             // postfilter.cc:835-838
+      if (p->dirtyR) { std::vector<double2> r((size_t) F * p->C * p->C); for (size_t i = 0; i < r.size(); i++) r[i] = make_double2(p->h_R[2 * i], p->h_R[2 * i + 1]); p->R.upload(r); p->dirtyR = false; }
+      p->state.reserve(S * NE);
+      hipLaunchKernelGGL(k_mccowan, dim3((unsigned) ((S + 127) / 128)), dim3(128), 0, st, (const float2*) X, (const float2*) Y, nframes_dev, p->wq.p, p->R.p, p->state.p,
+                         (float2*) out, wp1, U, p->C, Tmax, F, p->alpha, p->type, p->minFrames, p->threshold);
+      DSR_HIP(hipGetLastError());
+      return;
+    }
     const bool regs = !getenv("DSR_PF_MEMSTATE");
 #define ZREG(CC) if (regs && p->C == CC) { hipLaunchKernelGGL(k_zelinski_reg<CC>, dim3((unsigned) ((S + 63) / 64)), dim3(64), 0, st, (const float2*) X, (const float2*) Y, \
       nframes_dev, p->wq.p, (float2*) out, wp1, U, Tmax, F, p->alpha, p->type, p->minFrames); DSR_HIP(hipGetLastError()); return; }

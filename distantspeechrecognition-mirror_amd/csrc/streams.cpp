@@ -191,6 +191,12 @@ struct BfOp : dsr_stream {           // SubbandDS / SubbandGSC / SubbandMVDR as 
 
 struct ZelinskiOp : dsr_stream {     // ZelinskiPostFilter (postfilter.cc:350-493): ups[0] = beamformer output, ups[1..] = the snapshot array's channels
   dsr_zelinski* plan = nullptr; int M = 0; double alpha = 0.6; int ptype = 2, minFrames = 0; std::vector<std::vector<double>> manifold; int chanSet = 0;
+  int kind = 0; float threshold = 0.99f;                   // kind 1: McCowanPostFilter (the plan then also carries the noise coherence matrices)
+  void ensure_plan(int C) {
+    if (plan) return;
+    dsr_status s = kind ? dsr_mccowan_create(M, C, alpha, ptype, minFrames, threshold, &plan) : dsr_zelinski_create(M, C, alpha, ptype, minFrames, &plan);
+    if (s) throw Error(s, "%s", dsr_last_error());
+  }
   DevBuf<float2> X, Y, O; DevBuf<int> nf;
   ~ZelinskiOp() override { if (plan) dsr_zelinski_destroy(plan); }
   void compute() override {
@@ -199,8 +205,7 @@ struct ZelinskiOp : dsr_stream {     // ZelinskiPostFilter (postfilter.cc:350-49
     if (chanSet != C) throw Error(DSR_E_DIMENSION, "array manifold has %d channels, the snapshot array %d", chanSet, C);
     int T = ups[0]->nFrames; for (int c = 1; c <= C; c++) if (ups[c]->nFrames < T) T = ups[c]->nFrames;
     alloc(T); if (T <= 0) return;
-    if (plan) { dsr_zelinski_destroy(plan); plan = nullptr; }
-    dsr_status s = dsr_zelinski_create(M, C, alpha, ptype, minFrames, &plan); if (s) throw Error(s, "%s", dsr_last_error());
+    ensure_plan(C); dsr_status s;
     for (int f = 0; f <= M / 2; f++) if (!manifold[f].empty()) dsr_zelinski_set_manifold(plan, f, manifold[f].data());
     const int F = M / 2 + 1; X.reserve((size_t) C * T * F); Y.reserve((size_t) T * F); O.reserve((size_t) T * F);
     for (int c = 0; c < C; c++) op_pack_bins(ups[c + 1]->d<double2>(), T, F, M, X.p + (size_t) c * T * F, S0);
@@ -334,6 +339,30 @@ dsr_status dsr_zelinski_stream_create(dsr_stream* output, int fftLen, double alp
     ZelinskiOp* s = mk<ZelinskiOp>(name, "ZelinskPostFilter", fftLen, DSR_T_COMPLEX); s->M = fftLen; s->alpha = alpha; s->ptype = type; s->minFrames = minFrames;
     s->manifold.assign((size_t) fftLen / 2 + 1, std::vector<double>()); s->checkOrder = false;
     s->add_up(output); *out = s;
+  });
+}
+dsr_status dsr_mccowan_stream_create(dsr_stream* output, int fftLen, double alpha, int type, int minFrames, float threshold, const char* name, dsr_stream** out)
+{
+  const dsr_status s0 = dsr_zelinski_stream_create(output, fftLen, alpha, type, minFrames, (name && *name) ? name : "McCowanPostFilterPtr", out);
+  if (s0 != DSR_OK) return s0;
+  ZelinskiOp* q = static_cast<ZelinskiOp*>(*out); q->kind = 1; q->threshold = threshold;
+  return DSR_OK;
+}
+// noise coherence setters of McCowanPostFilter (postfilter.cc:546-682); chanN fixes the array size at the first call
+dsr_status dsr_mccowan_stream_set_noise(dsr_stream* pf, int what, int fbinX, const double* data, int chanN, double a, double b)
+{
+  return guard([&] {
+    ZelinskiOp* q = dynamic_cast<ZelinskiOp*>(pf); if (!q || q->kind != 1) throw Error(DSR_E_PARAMETER, "not a McCowan post-filter");
+    q->ensure_plan(chanN); dsr_status s = DSR_OK;
+    switch (what) {
+    case 0: s = dsr_mccowan_set_noise_matrix(q->plan, fbinX, data); break;
+    case 1: s = dsr_mccowan_set_diffuse_noise_model(q->plan, data, a, b); break;
+    case 2: s = dsr_mccowan_diagonal_loading(q->plan, fbinX, (float) a); break;
+    case 3: s = dsr_mccowan_divide_nondiagonal(q->plan, (float) a); break;
+    default: throw Error(DSR_E_PARAMETER, "bad selector %d", what);
+    }
+    if (s) throw Error(s, "%s", dsr_last_error());
+    q->ready = false;
   });
 }
 dsr_status dsr_zelinski_stream_set_channel(dsr_stream* pf, dsr_stream* chan)

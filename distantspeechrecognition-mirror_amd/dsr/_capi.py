@@ -77,6 +77,8 @@ def load():
         "dsr_stft_create": [C.c_int, C.c_int, C.c_int, vp], "dsr_stft_destroy": [vp], "dsr_stft_frames": [vp, C.c_int], "dsr_stft_block_len": [vp],
         "dsr_stft_analysis": [vp, vp, vp, C.c_int, C.c_int, i64, C.c_int, vp, vp],
         "dsr_zelinski_create": [C.c_int, C.c_int, f64, C.c_int, C.c_int, vp], "dsr_zelinski_destroy": [vp], "dsr_zelinski_set_manifold": [vp, C.c_int, vp],
+        "dsr_mccowan_create": [C.c_int, C.c_int, f64, C.c_int, C.c_int, f32, vp], "dsr_mccowan_set_noise_matrix": [vp, C.c_int, vp],
+        "dsr_mccowan_set_diffuse_noise_model": [vp, vp, f64, f64], "dsr_mccowan_diagonal_loading": [vp, C.c_int, f32], "dsr_mccowan_divide_nondiagonal": [vp, f32],
         "dsr_zelinski_apply": [vp, vp, vp, vp, C.c_int, C.c_int, vp, vp, vp],
         "dsr_lpc_create": [C.c_int, C.c_int, C.c_int, f32, C.c_int, C.c_int, vp], "dsr_lpc_destroy": [vp], "dsr_lpc_size": [vp],
         "dsr_lpc_run": [vp, vp, i64, vp, vp],
@@ -337,6 +339,32 @@ class ZelinskiPostFilter:
         w = torch.zeros((U, T, F), dtype=torch.float32, device=X.device) if want_weights else None
         check(_lib.dsr_zelinski_apply(self.h, _dev(X.contiguous()), _dev(Y.contiguous()), _dev(nframes), U, T, _dev(out), _dev(w) if want_weights else None, cur_stream()))
         return (out, w) if want_weights else out
+
+
+class McCowanPostFilter(ZelinskiPostFilter):
+    """McCowan post-filter (postfilter.cc:502-945): Zelinski's recursions + a noise coherence matrix per bin."""
+
+    def __init__(self, fftLen, chanN, manifold, alpha=0.6, type=2, minFrames=0, threshold=0.99):
+        L = load(); self.h = vp(); self.M, self.C = fftLen, chanN
+        check(L.dsr_mccowan_create(fftLen, chanN, alpha, type, minFrames, threshold, C.byref(self.h)))
+        m = np.ascontiguousarray(manifold, np.complex128)
+        for f in range(fftLen // 2 + 1):
+            check(L.dsr_zelinski_set_manifold(self.h, f, _ptr(m[f])))
+
+    def setDiffuseNoiseModel(self, micPositions, sampleRate, sspeed=343740.0):
+        mp = _np(micPositions, np.float64); check(_lib.dsr_mccowan_set_diffuse_noise_model(self.h, _ptr(mp), sampleRate, sspeed)); return True
+
+    def setNoiseSpatialSpectralMatrix(self, fbinX, Rnn):
+        r = np.ascontiguousarray(Rnn, np.complex128); check(_lib.dsr_mccowan_set_noise_matrix(self.h, fbinX, _ptr(r))); return True
+
+    def setAllLevelsOfDiagonalLoading(self, w):
+        check(_lib.dsr_mccowan_diagonal_loading(self.h, -1, w))
+
+    def setLevelOfDiagonalLoading(self, fbinX, w):
+        check(_lib.dsr_mccowan_diagonal_loading(self.h, fbinX, w))
+
+    def divideAllNonDiagonalElements(self, myu):
+        check(_lib.dsr_mccowan_divide_nondiagonal(self.h, myu))
 
 
 class LpcEnvelope:

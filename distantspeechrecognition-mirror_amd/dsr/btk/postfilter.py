@@ -32,3 +32,32 @@ class ZelinskiPostFilterPtr(FeatureStreamPtr):
             raise K.DsrError(2, "halfBandShift==true is not supported")
         v = np.ascontiguousarray(arrayManifoldVector, np.complex128)
         K.check(lib().dsr_zelinski_stream_set_manifold(self._h, int(fbinX), v.ctypes.data_as(C.c_void_p), v.size))
+
+
+class McCowanPostFilterPtr(ZelinskiPostFilterPtr):
+    """postfilter.i:113-126 (McCowanPostFilter, postfilter.cc:502-945)."""
+
+    def __init__(self, output, fftLen, alpha=0.6, type=2, minFrames=0, threshold=0.99, nm="McCowanPostFilterPtr"):
+        h, _ = _new(lib().dsr_mccowan_stream_create, output._h, int(fftLen), float(alpha), int(type), int(minFrames), float(threshold), nm.encode())
+        FeatureStreamPtr.__init__(self, h, keep=(output,)); self._M = fftLen; self._type = type; self._chans = []; self._C = None
+
+    def _noise(self, what, fbinX, data, chanN, a=0.0, b=0.0):
+        d = None if data is None else np.ascontiguousarray(data)
+        K.check(lib().dsr_mccowan_stream_set_noise(self._h, what, int(fbinX), None if d is None else d.ctypes.data_as(C.c_void_p), int(chanN), float(a), float(b)))
+
+    def setDiffuseNoiseModel(self, micPositions, sampleRate, sspeed=343740.0):
+        mp = np.ascontiguousarray(micPositions, np.float64); self._C = mp.shape[0]
+        self._noise(1, 0, mp, self._C, sampleRate, sspeed); return True
+
+    def setNoiseSpatialSpectralMatrix(self, fbinX, Rnn):
+        r = np.ascontiguousarray(Rnn, np.complex128); self._C = r.shape[0]
+        self._noise(0, fbinX, r, self._C); return True
+
+    def setAllLevelsOfDiagonalLoading(self, diagonalWeight):
+        self._noise(2, -1, None, self._C or 0, diagonalWeight)
+
+    def setLevelOfDiagonalLoading(self, fbinX, diagonalWeight):
+        self._noise(2, fbinX, None, self._C or 0, diagonalWeight)
+
+    def divideAllNonDiagonalElements(self, myu):
+        self._noise(3, 0, None, self._C or 0, myu)

@@ -302,6 +302,12 @@ typedef struct dsr_zelinski dsr_zelinski;
 dsr_status dsr_zelinski_create(int fftLen, int chanN, double alpha, int type, int minFrames, dsr_zelinski** out);
 void       dsr_zelinski_destroy(dsr_zelinski*);
 dsr_status dsr_zelinski_set_manifold(dsr_zelinski*, int fbinX, const double* vec /* chanN complex128 */);   /* setArrayManifoldVector */
+/* McCowanPostFilter (postfilter.cc:502-945): same handle type and apply; noise coherence per bin as in SubbandMVDR's setters */
+dsr_status dsr_mccowan_create(int fftLen, int chanN, double alpha, int type, int minFrames, float threshold, dsr_zelinski** out);
+dsr_status dsr_mccowan_set_noise_matrix(dsr_zelinski*, int fbinX, const double* Rnn /* [C][C] complex128 */);
+dsr_status dsr_mccowan_set_diffuse_noise_model(dsr_zelinski*, const double* micPos /* [C][3] */, double sampleRate, double sspeed);
+dsr_status dsr_mccowan_diagonal_loading(dsr_zelinski*, int fbinX /* < 0: all bins */, float diagonalWeight);
+dsr_status dsr_mccowan_divide_nondiagonal(dsr_zelinski*, float myu);
 dsr_status dsr_zelinski_apply(dsr_zelinski*, const float* X_dev, const float* Y_dev, const int32_t* nframes_dev, int U, int Tmax,
                               float* out_dev, float* wp1_dev, void* stream);
 
@@ -357,6 +363,11 @@ dsr_status dsr_normal_fft_bank_create(dsr_stream* samp, int M, int r, int window
    streams (setSnapShotArray / setBeamformer), manifold = setArrayManifoldVector per bin */
 dsr_status dsr_zelinski_stream_create(dsr_stream* output, int fftLen, double alpha, int type, int minFrames, const char* name, dsr_stream** out);
 dsr_status dsr_zelinski_stream_set_channel(dsr_stream* pf, dsr_stream* chan);
+/* McCowanPostFilter(output, fftLen, alpha, type, minFrames, threshold) (postfilter.i:113-126) on the same operator; its noise
+   coherence setters: what 0 setNoiseSpatialSpectralMatrix(fbinX, data [C][C] complex), 1 setDiffuseNoiseModel(data = micPos [C][3],
+   a = sampleRate, b = sspeed), 2 set(All)Level(s)OfDiagonalLoading(fbinX or -1, a), 3 divideAllNonDiagonalElements(a) */
+dsr_status dsr_mccowan_stream_create(dsr_stream* output, int fftLen, double alpha, int type, int minFrames, float threshold, const char* name, dsr_stream** out);
+dsr_status dsr_mccowan_stream_set_noise(dsr_stream* pf, int what, int fbinX, const double* data, int chanN, double a, double b);
 dsr_status dsr_zelinski_stream_set_manifold(dsr_stream* pf, int fbinX, const double* vec, int chanN);
 /* SubbandDS/GSC/MVDR as a stream: channels are analysis-bank streams (setChannel) */
 dsr_status dsr_subband_bf_create(dsr_bf* weights, const char* name, dsr_stream** out);

@@ -256,6 +256,26 @@ def zelinski_postfilter(X, Y, wq, alpha=0.6, type=2, minFrames=0):
     return out, wp1
 
 
+def pf_diffuse_noise_model(micpos, M, fs, sspeed=343740.0):
+    mp = np.ascontiguousarray(micpos, np.float64); Cn = mp.shape[0]
+    R = np.zeros((M // 2 + 1, Cn, Cn), np.complex128)
+    lib().orc_pf_diffuse_noise_model(_p(mp), Cn, M, C.c_double(fs), C.c_double(sspeed), _p(R))
+    return R
+
+
+def mccowan_postfilter(X, Y, wq, R, alpha=0.6, type=2, minFrames=0, threshold=0.99):
+    """McCowanPostFilter (postfilter.cc:568-945): X [C][T][F], Y [T][F], wq [F][C], R [F][C][C] -> (out, wp1)."""
+    X = np.ascontiguousarray(X, np.complex128); Y = np.ascontiguousarray(Y, np.complex128); wq = np.ascontiguousarray(wq, np.complex128)
+    R = np.ascontiguousarray(R, np.complex128)
+    Cn, T, F = X.shape
+    out = np.zeros((T, F), np.complex128); wp1 = np.zeros((T, F), np.float64)
+    L = lib(); L.orc_mccowan_postfilter.restype = C.c_int
+    rc = L.orc_mccowan_postfilter(_p(X), _p(Y), _p(wq), _p(R), Cn, T, F, C.c_double(alpha), type, minFrames, C.c_double(threshold), _p(out), _p(wp1))
+    if rc != 0:
+        raise ValueError("The number of channels %d is <= 1" % Cn)
+    return out, wp1
+
+
 def lpc_feature(frames, order, warp=0.0, method=0, kind=0):
     """WarpMVDR/BurgMVDR (kind 0) and WarpLPC/BurgLPC (kind 1) spectral envelopes, lpc.h:134-195,291-331."""
     L = lib(); fr = _f32(frames); T, dim = fr.shape

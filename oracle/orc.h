@@ -30,6 +30,10 @@ extern "C" {
 int  orc_zelinski_postfilter(const double* X, const double* Y, const double* wq, int C, int T, int F, double alpha, int type, int minFrames,
                              double* out, double* wp1);
 
+void orc_pf_diffuse_noise_model(const double* micPos, int C, int M, double sampleRate, double sspeed, double* R);
+int  orc_mccowan_postfilter(const double* X, const double* Y, const double* wq, const double* R, int C, int T, int F, double alpha, int type,
+                            int minFrames, double threshold, double* out, double* wp1);
+
 /* ---------------- LPC / MVDR spectral envelopes (btk/feature/lpc.cc, lpc.h) ---------------- */
 int  orc_lpc_npoints(int dim);
 void orc_lpc_fft_power(float* power, int dim);

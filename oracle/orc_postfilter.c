@@ -7,7 +7,8 @@
  *   ZelinskiFilter_f            :56-139   (Eq. (4) of the cited paper; spectral floor 1e-4, clamp at 1)
  *   ZelinskiFilter              :157-221  (halfBandShift == false: bins 0..M/2, conjugate mirror)
  *   ZelinskiPostFilter::next    :428-493  (alpha = 0 for the first two frames, minFrames, TYPE_ZELINSKI2 uses wq)
- * Parity unpinned: the reference holds no outputs for this operator; restated from the source text.
+ *   McCowanPostFilter           :568-945  (noise-coherence corrected estimate of the clean-signal PSD; gsl_complex_div restated)
+ * Parity unpinned: the reference holds no outputs for these operators; restated from the source text.
  * All arithmetic is fp64 as in the reference (gsl_complex).
  */
 #include "orc.h"
@@ -65,6 +66,99 @@ int orc_zelinski_postfilter(const double* X, const double* Y, const double* wq, 
       const double yr = Y[((size_t) t * F + f) * 2], yi = Y[((size_t) t * F + f) * 2 + 1];
       if (pfType == 0) { out[((size_t) t * F + f) * 2] = yr; out[((size_t) t * F + f) * 2 + 1] = yi; }
       else { out[((size_t) t * F + f) * 2] = W * yr - 0.0 * yi; out[((size_t) t * F + f) * 2 + 1] = W * yi + 0.0 * yr; }   /* polar(W, 0) * y */
+    }
+  }
+  free(csd); free(ta);
+  return 0;
+}
+
+/* McCowanPostFilter::setDiffuseNoiseModel (postfilter.cc:568-626): Gamma_mn = sinc(2 fs f d_mn / (M c)), gsl_sf_sinc(x) = sin(pi x)/(pi x).
+ * R: [F][C][C] complex double */
+void orc_pf_diffuse_noise_model(const double* micPos, int C, int M, double sampleRate, double sspeed, double* R)
+{
+  const int F = M / 2 + 1;
+  for (int f = 0; f < F; f++) {
+    const double omega_d_c = 2.0 * sampleRate * f / (M * sspeed);
+    double* Rf = R + (size_t) f * C * C * 2;
+    for (int m = 0; m < C; m++)
+      for (int n = 0; n < m; n++) {
+        const double dx = micPos[3*m] - micPos[3*n], dy = micPos[3*m+1] - micPos[3*n+1], dz = micPos[3*m+2] - micPos[3*n+2];
+        const double x = omega_d_c * sqrt(dx * dx + dy * dy + dz * dz);
+        const double g = (x == 0.0) ? 1.0 : sin(M_PI * x) / (M_PI * x);
+        Rf[(m * C + n) * 2] = g; Rf[(m * C + n) * 2 + 1] = 0.0;
+      }
+    for (int m = 0; m < C; m++) { Rf[(m * C + m) * 2] = 1.0; Rf[(m * C + m) * 2 + 1] = 0.0; }
+    for (int m = 0; m < C; m++) for (int n = m + 1; n < C; n++) { Rf[(m * C + n) * 2] = Rf[(n * C + m) * 2]; Rf[(m * C + n) * 2 + 1] = Rf[(n * C + m) * 2 + 1]; }
+  }
+}
+
+static void cdiv_gsl(double ar, double ai, double br, double bi, double* zr, double* zi)
+{ /* gsl_complex_div: s = 1/|b|, scaled operands (gsl complex/math.c) */
+  const double s = 1.0 / hypot(br, bi);
+  const double sbr = s * br, sbi = s * bi;
+  *zr = (ar * sbr + ai * sbi) * s; *zi = (ai * sbr - ar * sbi) * s;
+}
+
+/* McCowanPostFilter::{calculateSpectralDensities_f, estimateAverageOfCleanSignalPSD (the non-ORIGINAL_IAIN_PAPER build), PostFiltering, next}
+ * (postfilter.cc:706-744,789-826,833-945).  R: [F][C][C] complex double (noise coherence), threshold = _thresholdOfRij. */
+int orc_mccowan_postfilter(const double* X, const double* Y, const double* wq, const double* R, int C, int T, int F, double alpha_, int type,
+                           int minFrames, double threshold, double* out, double* wp1)
+{
+  if (C <= 1) return -1;
+  const int NP = C * C;
+  double* csd = (double*) calloc((size_t) F * NP * 2, sizeof(double));
+  double* ta = (double*) calloc((size_t) C * 2, sizeof(double));
+  for (int t = 0; t < T; t++) {
+    const int frameX = t - 1;
+    const double alpha = (frameX > 0) ? alpha_ : 0.0;
+    for (int f = 0; f < F; f++) {
+      double* prev = csd + (size_t) f * NP * 2; const double* Rf = R + (size_t) f * NP * 2;
+      for (int i = 0; i < C; i++) {
+        const double dr = wq[((size_t) f * C + i) * 2], di = -wq[((size_t) f * C + i) * 2 + 1];
+        const double xr = X[(((size_t) i * T + t) * F + f) * 2], xi = X[(((size_t) i * T + t) * F + f) * 2 + 1];
+        ta[2*i] = dr * xr - di * xi; ta[2*i+1] = dr * xi + di * xr;
+      }
+      for (int i = 0; i < C - 1; i++)
+        for (int j = i + 1; j < C; j++) {
+          const int idx = i * C + j;
+          const double ar = ta[2*i], ai = ta[2*i+1], br = ta[2*j], bi = -ta[2*j+1];
+          const double pr = ar * br - ai * bi, pi = ar * bi + ai * br;
+          if (alpha > 0.0) { prev[2*idx] = prev[2*idx] * alpha + pr * (1.0 - alpha); prev[2*idx+1] = prev[2*idx+1] * alpha + pi * (1.0 - alpha); }
+          else { prev[2*idx] = pr; prev[2*idx+1] = pi; }
+        }
+      double sumOfPSD = 0.0;
+      for (int i = 0; i < C; i++) {
+        const int idx = i * C + i;
+        const double a2 = ta[2*i] * ta[2*i] + ta[2*i+1] * ta[2*i+1];
+        double est;
+        if (alpha > 0.0) est = alpha * prev[2*idx] + (1.0 - alpha) * a2; else est = a2;
+        sumOfPSD += est; prev[2*idx] = est; prev[2*idx+1] = 0.0;
+      }
+      const double de = sumOfPSD / C;
+      double sr = 0.0, si = 0.0;
+      for (int i = 0; i < C - 1; i++) {
+        const double phi_ii = prev[2 * (i * C + i)];
+        for (int j = i + 1; j < C; j++) {
+          const double pr = prev[2 * (i * C + j)], pi = prev[2 * (i * C + j) + 1];
+          const double phi_jj = prev[2 * (j * C + j)];
+          double Rr = Rf[2 * (i * C + j)], Ri = Rf[2 * (i * C + j) + 1];
+          if (Rr > threshold && Ri <= 0.0) { Rr = threshold; Ri = 0.0; }
+          const double hs = 0.5 * (phi_ii + phi_jj);
+          const double nr = pr - Rr * hs, ni = pi - Ri * hs;                   /* phi_ij - R_ij * 0.5 (phi_ii + phi_jj) */
+          const double dr = -Rr + 1.0, di = -Ri;                               /* 1 - R_ij */
+          double qr, qi; cdiv_gsl(nr, ni, dr, di, &qr, &qi);
+          sr += qr; si += qi;
+        }
+      }
+      const double avg = (1 & type) ? sr : hypot(sr, si);
+      const double nu = 2.0 * avg / (C * (C - 1));
+      double W = nu / de;
+      if (W > 1.0) W = 1.0;
+      if (W < 0.0001) W = 0.0001;
+      if (wp1) wp1[(size_t) t * F + f] = W;
+      const double yr = Y[((size_t) t * F + f) * 2], yi = Y[((size_t) t * F + f) * 2 + 1];
+      if (frameX >= minFrames) { out[((size_t) t * F + f) * 2] = yr * W; out[((size_t) t * F + f) * 2 + 1] = yi * W; }
+      else { out[((size_t) t * F + f) * 2] = yr; out[((size_t) t * F + f) * 2 + 1] = yi; }
     }
   }
   free(csd); free(ta);

@@ -676,3 +676,42 @@ def test_zelinski_postfilter_stream(dsr, oracle, cuda, protos, headset):
     sc = np.abs(wo).max()
     assert np.abs(rows[:, :Fh] - wo).max() < 5e-5 * sc                  # fp32 snapshots and beamformer output on the device
     assert np.abs(rows[:, Fh:] - np.conj(rows[:, 1:Fh - 1][:, ::-1])).max() < 1e-12      # conjugate mirror (postfilter.cc:194-196,213-215)
+    # McCowanPostFilterPtr on the same chain
+    mc = P.McCowanPostFilterPtr(bf, M, alpha=0.7, type=2, minFrames=1)
+    mc.setDiffuseNoiseModel(mp, 16000.0); mc.divideAllNonDiagonalElements(0.01)
+    mc.setBeamformer(bf)
+    rows2 = np.array([np.array(v) for v in mc])
+    R = oracle.pf_diffuse_noise_model(mp, M, 16000.0); off = ~np.eye(Cn, dtype=bool); R[:, off] = R[:, off] / (1.0 + np.float32(0.01))
+    wo2, _ = oracle.mccowan_postfilter(Xc[:, :, :Fh], Yo, wq, R, 0.7, 2, 1, 0.99)
+    assert np.abs(rows2[:, :Fh] - wo2).max() < 5e-5 * np.abs(wo2).max()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("Cn,ptype,alpha,minFrames,myu", [(8, 2, 0.6, 0, 0.01), (4, 1, 0.8, 2, 0.0), (6, 2, 0.0, 0, 0.1)])
+def test_mccowan_postfilter(dsr, oracle, cuda, Cn, ptype, alpha, minFrames, myu):
+    """postfilter.cc:568-945: McCowan's noise-coherence corrected estimate on top of the same density recursions."""
+    import torch
+    rng = np.random.default_rng(50 + Cn)
+    U, T, M = 2, 30, 64
+    F = M // 2 + 1
+    mp = synth.linear_array(Cn)
+    wq = (np.exp(-1j * rng.uniform(0, 6, (F, Cn))) / Cn).astype(np.complex128)
+    s = rng.standard_normal((U, T, F)) + 1j * rng.standard_normal((U, T, F))
+    X = np.stack([s * np.conj(wq[:, c]) * Cn + 0.8 * (rng.standard_normal((U, T, F)) + 1j * rng.standard_normal((U, T, F))) for c in range(Cn)], axis=1).astype(np.complex64)
+    Y = np.einsum("fc,uctf->utf", np.conj(wq), X.astype(np.complex128)).astype(np.complex64)
+    pf = dsr.McCowanPostFilter(M, Cn, wq, alpha=alpha, type=ptype, minFrames=minFrames, threshold=0.99)
+    with pytest.raises(dsr.DsrError):
+        pf.apply(torch.from_numpy(X).to(cuda), torch.from_numpy(Y).to(cuda))         # no noise coherence matrix yet (postfilter.cc:835-838)
+    pf.setDiffuseNoiseModel(mp, 16000.0)
+    R = oracle.pf_diffuse_noise_model(mp, M, 16000.0)
+    if myu > 0:
+        pf.divideAllNonDiagonalElements(myu)
+        off = ~np.eye(Cn, dtype=bool); R[:, off] = R[:, off] / (1.0 + np.float32(myu))
+    pf.setLevelOfDiagonalLoading(3, 0.05); R[3][np.eye(Cn, dtype=bool)] += np.float32(0.05)
+    got, w = pf.apply(torch.from_numpy(X).to(cuda), torch.from_numpy(Y).to(cuda), want_weights=True)
+    got, w = got.cpu().numpy(), w.cpu().numpy()
+    for u in range(U):
+        wo, ww = oracle.mccowan_postfilter(X[u].astype(np.complex128), Y[u].astype(np.complex128), wq, R, alpha, ptype, minFrames, 0.99)
+        np.testing.assert_allclose(w[u], ww, rtol=1e-6)
+        assert np.abs(got[u] - wo).max() <= 1e-6 * np.abs(wo).max()
+    assert w.min() < 0.9                                               # the case is not saturated everywhere
