@@ -189,6 +189,17 @@ struct BfOp : dsr_stream {           // SubbandDS / SubbandGSC / SubbandMVDR as 
   }
 };
 
+struct WpeOp : dsr_stream {          // SingleChannelWPEDereverberationFeature (dereverberation.cc:28-300)
+  int M = 0, lowerN = 0, upperN = 0, iterationsN = 2; double loadDb = -20.0, bandWidth = 0.0, sampleRate = 16000.0; DevBuf<float2> Y, O; DevBuf<int> nf;
+  void compute() override {
+    const int T = ups[0]->nFrames; alloc(T); if (T <= 0) return;
+    const int F = M / 2 + 1; Y.reserve((size_t) T * F); O.reserve((size_t) T * F);
+    op_pack_bins(ups[0]->d<double2>(), T, F, M, Y.p, S0); nf.upload(&T, 1);
+    dsr_status s = dsr_wpe_single((const float*) Y.p, nf.p, 1, T, M, lowerN, upperN, iterationsN, loadDb, bandWidth, sampleRate, (float*) O.p, nullptr, S0);
+    if (s) throw Error(s, "%s", dsr_last_error());
+    op_expand_bins(O.p, T, F, M, d<double2>(), S0);
+  }
+};
 struct ZelinskiOp : dsr_stream {     // ZelinskiPostFilter (postfilter.cc:350-493): ups[0] = beamformer output, ups[1..] = the snapshot array's channels
   dsr_zelinski* plan = nullptr; int M = 0; double alpha = 0.6; int ptype = 2, minFrames = 0; std::vector<std::vector<double>> manifold; int chanSet = 0;
   int kind = 0; float threshold = 0.99f;                   // kind 1: McCowanPostFilter (the plan then also carries the noise coherence matrices)
@@ -329,6 +340,18 @@ dsr_status dsr_synthesis_bank_create(dsr_stream* samp, const double* prototype, 
     SynthesisOp* s = mk<SynthesisOp>(name, "OverSampledDFTSynthesisBank", M >> r, DSR_T_FLOAT); s->M = M; s->D = M >> r; s->checkOrder = false;
     dsr_status st = dsr_fb_create(prototype, M, m, r, 1, dct, gain, &s->fb); if (st) { delete s; throw Error(st, "%s", dsr_last_error()); }
     s->add_up(samp); *out = s;
+  });
+}
+dsr_status dsr_wpe_single_stream_create(dsr_stream* samples, int lowerN, int upperN, int iterationsN, double loadDb, double bandWidth, double sampleRate,
+                                        const char* name, dsr_stream** out)
+{
+  return guard([&] {
+    need(samples, DSR_T_COMPLEX, "SingleChannelWPEDereverberationFeature"); if (!out) throw Error(DSR_E_PARAMETER, "null argument");
+    if (upperN < lowerN) throw Error(DSR_E_PARAMETER, "bad prediction range [%d, %d]", lowerN, upperN);
+    if (bandWidth > sampleRate / 2.0) throw Error(DSR_E_DIMENSION, "Bandwidth is greater than the Nyquist rate.");
+    WpeOp* s = mk<WpeOp>(name, "SingleChannelWPEDereverberationFeature", samples->size_, DSR_T_COMPLEX);
+    s->M = samples->size_; s->lowerN = lowerN; s->upperN = upperN; s->iterationsN = iterationsN; s->loadDb = loadDb; s->bandWidth = bandWidth; s->sampleRate = sampleRate;
+    s->add_up(samples); *out = s;
   });
 }
 dsr_status dsr_zelinski_stream_create(dsr_stream* output, int fftLen, double alpha, int type, int minFrames, const char* name, dsr_stream** out)

@@ -76,6 +76,7 @@ def load():
         "dsr_prfb_analysis": [vp, vp, vp, C.c_int, C.c_int, i64, C.c_int, vp, vp], "dsr_prfb_synthesis": [vp, vp, vp, C.c_int, C.c_int, i64, vp, vp],
         "dsr_stft_create": [C.c_int, C.c_int, C.c_int, vp], "dsr_stft_destroy": [vp], "dsr_stft_frames": [vp, C.c_int], "dsr_stft_block_len": [vp],
         "dsr_stft_analysis": [vp, vp, vp, C.c_int, C.c_int, i64, C.c_int, vp, vp],
+        "dsr_wpe_single": [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, f64, f64, f64, vp, vp, vp],
         "dsr_zelinski_create": [C.c_int, C.c_int, f64, C.c_int, C.c_int, vp], "dsr_zelinski_destroy": [vp], "dsr_zelinski_set_manifold": [vp, C.c_int, vp],
         "dsr_mccowan_create": [C.c_int, C.c_int, f64, C.c_int, C.c_int, f32, vp], "dsr_mccowan_set_noise_matrix": [vp, C.c_int, vp],
         "dsr_mccowan_set_diffuse_noise_model": [vp, vp, f64, f64], "dsr_mccowan_diagonal_loading": [vp, C.c_int, f32], "dsr_mccowan_divide_nondiagonal": [vp, f32],
@@ -313,6 +314,20 @@ class NormalFFTBank:
         X = torch.zeros((U, Cn, T, self.M), dtype=torch.complex64, device=x.device)
         check(_lib.dsr_stft_analysis(self.h, _dev(x), _dev(nsamp), U, Cn, N, T, _dev(X), cur_stream()))
         return X
+
+
+def wpe_single(Y, fftLen, lowerN, upperN, iterationsN=2, loadDb=-20.0, bandWidth=0.0, sampleRate=16000.0, nframes=None, want_filters=False):
+    """Single-channel WPE (dereverberation.cc:28-300): Y cuda complex64 [U][N][M/2+1] -> out (and the filters [U][M/2+1][P] complex128)."""
+    import torch
+    load()
+    U, N, F = Y.shape
+    if nframes is None:
+        nframes = torch.full((U,), N, dtype=torch.int32, device=Y.device)
+    out = torch.zeros((U, N, F), dtype=torch.complex64, device=Y.device)
+    gn = torch.zeros((U, F, upperN - lowerN + 1), dtype=torch.complex128, device=Y.device) if want_filters else None
+    check(_lib.dsr_wpe_single(_dev(Y.contiguous()), _dev(nframes), U, N, fftLen, lowerN, upperN, iterationsN, loadDb, bandWidth, sampleRate, _dev(out),
+                              _dev(gn) if want_filters else None, cur_stream()))
+    return (out, gn) if want_filters else out
 
 
 class ZelinskiPostFilter:

@@ -24,6 +24,7 @@ def lib():
                "dsr_synthesis_bank_create": [vp, vp, ci, ci, ci, ci, ci, C.c_char_p, vp],
                "dsr_normal_fft_bank_create": [vp, ci, ci, ci, C.c_char_p, vp],
                "dsr_pr_analysis_bank_create": [vp, vp, ci, ci, ci, C.c_char_p, vp], "dsr_pr_synthesis_bank_create": [vp, vp, ci, ci, ci, C.c_char_p, vp],
+               "dsr_wpe_single_stream_create": [vp, ci, ci, ci, C.c_double, C.c_double, C.c_double, C.c_char_p, vp],
                "dsr_zelinski_stream_create": [vp, ci, C.c_double, ci, ci, C.c_char_p, vp], "dsr_zelinski_stream_set_channel": [vp, vp],
                "dsr_zelinski_stream_set_manifold": [vp, ci, vp, ci],
                "dsr_mccowan_stream_create": [vp, ci, C.c_double, ci, ci, C.c_float, C.c_char_p, vp],

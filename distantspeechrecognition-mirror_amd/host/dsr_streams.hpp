@@ -152,6 +152,16 @@ DSR_LPC_OP(WarpLPCFeature, 0, 1, "LPC")
 DSR_LPC_OP(BurgLPCFeature, 1, 1, "LPC")
 #undef DSR_LPC_OP
 
+// ---- btk/dereverberation/dereverberation.h
+class SingleChannelWPEDereverberationFeature : public VectorComplexFeatureStream {
+ public:
+  SingleChannelWPEDereverberationFeature(VectorComplexFeatureStreamPtr& samples, unsigned lowerN, unsigned upperN, unsigned iterationsN = 2, double loadDb = -20.0,
+                                         double bandWidth = 0.0, double sampleRate = 16000.0, const String& nm = "SingleChannelWPEDereverberationFeature")
+  : _s(samples) { DSR_OP(SingleChannelWPEDereverberationFeature, cplx, dsr_wpe_single_stream_create(samples->handle(), (int) lowerN, (int) upperN, (int) iterationsN, loadDb, bandWidth, sampleRate, nm.c_str(), &h)) }
+  void nextSpeaker() { reset(); }
+ private: VectorComplexFeatureStreamPtr _s;
+};
+
 // ---- btk/postfilter/postfilter.h:95-126
 class ZelinskiPostFilter : public VectorComplexFeatureStream {
  public:

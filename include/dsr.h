@@ -311,6 +311,13 @@ dsr_status dsr_mccowan_divide_nondiagonal(dsr_zelinski*, float myu);
 dsr_status dsr_zelinski_apply(dsr_zelinski*, const float* X_dev, const float* Y_dev, const int32_t* nframes_dev, int U, int Tmax,
                               float* out_dev, float* wp1_dev, void* stream);
 
+/* Single-channel WPE dereverberation of a subband sequence (SingleChannelWPEDereverberationFeature, btk/dereverberation/
+ * dereverberation.cc:28-300; SWIG defaults iterationsN 2, loadDb -20, bandWidth 0, sampleRate 16000).  Y_dev [U][Nmax][M/2+1]
+ * complex64 -> out_dev same shape; gn_dev (optional) [U][M/2+1][upperN-lowerN+1] complex128 = the prediction filters.  The
+ * filters start from zero for every utterance (nextSpeaker() semantics). */
+dsr_status dsr_wpe_single(const float* Y_dev, const int32_t* nframes_dev, int U, int Nmax, int fftLen, int lowerN, int upperN,
+                          int iterationsN, double loadDb, double bandWidth, double sampleRate, float* out_dev, double* gn_dev, void* stream);
+
 /* =====================================================================================
  * 6b. LPC / MVDR spectral envelopes  (btk/feature/lpc.cc:44-207, lpc.h:134-195,291-331:
  *     WarpMVDRFeature, BurgMVDRFeature, WarpLPCFeature, BurgLPCFeature)
@@ -369,6 +376,9 @@ dsr_status dsr_zelinski_stream_set_channel(dsr_stream* pf, dsr_stream* chan);
 dsr_status dsr_mccowan_stream_create(dsr_stream* output, int fftLen, double alpha, int type, int minFrames, float threshold, const char* name, dsr_stream** out);
 dsr_status dsr_mccowan_stream_set_noise(dsr_stream* pf, int what, int fbinX, const double* data, int chanN, double a, double b);
 dsr_status dsr_zelinski_stream_set_manifold(dsr_stream* pf, int fbinX, const double* vec, int chanN);
+/* SingleChannelWPEDereverberationFeature(samples, lowerN, upperN, iterationsN, loadDb, bandWidth, sampleRate) (dereverberation.i:67-81) */
+dsr_status dsr_wpe_single_stream_create(dsr_stream* samples, int lowerN, int upperN, int iterationsN, double loadDb, double bandWidth,
+                                        double sampleRate, const char* name, dsr_stream** out);
 /* SubbandDS/GSC/MVDR as a stream: channels are analysis-bank streams (setChannel) */
 dsr_status dsr_subband_bf_create(dsr_bf* weights, const char* name, dsr_stream** out);
 dsr_status dsr_subband_bf_set_channel(dsr_stream* bf, dsr_stream* chan);

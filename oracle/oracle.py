@@ -276,6 +276,17 @@ def mccowan_postfilter(X, Y, wq, R, alpha=0.6, type=2, minFrames=0, threshold=0.
     return out, wp1
 
 
+def wpe_single(Y, lowerN, upperN, iterationsN=2, loadDb=-20.0, bandWidth=0.0, sampleRate=16000.0):
+    """SingleChannelWPEDereverberationFeature (dereverberation.cc:28-300): Y [N][M] complex -> (out [N][M], gn [M][P])."""
+    Y = np.ascontiguousarray(Y, np.complex128); N, M = Y.shape; P = upperN - lowerN + 1
+    out = np.zeros((N, M), np.complex128); gn = np.zeros((M, P), np.complex128)
+    L = lib(); L.orc_wpe_single.restype = C.c_int
+    rc = L.orc_wpe_single(_p(Y), N, M, lowerN, upperN, iterationsN, C.c_double(loadDb), C.c_double(bandWidth), C.c_double(sampleRate), _p(out), _p(gn))
+    if rc != 0:
+        raise ValueError("wpe_single failed (%d)" % rc)
+    return out, gn
+
+
 def lpc_feature(frames, order, warp=0.0, method=0, kind=0):
     """WarpMVDR/BurgMVDR (kind 0) and WarpLPC/BurgLPC (kind 1) spectral envelopes, lpc.h:134-195,291-331."""
     L = lib(); fr = _f32(frames); T, dim = fr.shape

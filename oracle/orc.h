@@ -34,6 +34,10 @@ void orc_pf_diffuse_noise_model(const double* micPos, int C, int M, double sampl
 int  orc_mccowan_postfilter(const double* X, const double* Y, const double* wq, const double* R, int C, int T, int F, double alpha, int type,
                             int minFrames, double threshold, double* out, double* wp1);
 
+/* ---------------- single-channel WPE dereverberation (btk/dereverberation/dereverberation.cc:28-300) ---------------- */
+int  orc_wpe_single(const double* Y, int N, int M, int lowerN, int upperN, int iterationsN, double loadDb, double bandWidth, double sampleRate,
+                    double* out, double* gnOut);
+
 /* ---------------- LPC / MVDR spectral envelopes (btk/feature/lpc.cc, lpc.h) ---------------- */
 int  orc_lpc_npoints(int dim);
 void orc_lpc_fft_power(float* power, int dim);

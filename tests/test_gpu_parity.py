@@ -715,3 +715,49 @@ def test_mccowan_postfilter(dsr, oracle, cuda, Cn, ptype, alpha, minFrames, myu)
         np.testing.assert_allclose(w[u], ww, rtol=1e-6)
         assert np.abs(got[u] - wo).max() <= 1e-6 * np.abs(wo).max()
     assert w.min() < 0.9                                               # the case is not saturated everywhere
+
+
+# ------------------------------------------------------------------------------------------- single-channel WPE
+@pytest.mark.gpu
+@pytest.mark.parametrize("lowerN,upperN,iters,loadDb,bw", [(2, 9, 2, -20.0, 0.0), (1, 16, 3, -10.0, 0.0), (3, 6, 1, -30.0, 4000.0), (0, 3, 2, -20.0, 0.0)])
+def test_wpe_single(dsr, oracle, cuda, lowerN, upperN, iters, loadDb, bw):
+    """dereverberation.cc:28-300: per (utterance, subband) weighted correlation matrix, Cholesky, prediction filter, fp64 on the device;
+    terms are weighted with 1/theta_n (one division per frame): 1e-8 relative on the filters, 1e-6 of the magnitude on the fp32 output."""
+    import torch
+    rng = np.random.default_rng(lowerN + upperN)
+    U, N, M = 2, 160, 32
+    F = M // 2 + 1
+    s = rng.standard_normal((U, N, F)) + 1j * rng.standard_normal((U, N, F))
+    for k in range(1, 12):
+        s[:, k:] += 0.6 ** k * np.roll(s, k, axis=1)[:, k:] * np.exp(1j * k)          # a decaying tail
+    Y = s.astype(np.complex64)
+    nfr = [N, N - 33]
+    out, gn = dsr.wpe_single(torch.from_numpy(Y).to(cuda), M, lowerN, upperN, iters, loadDb, bw, 16000.0,
+                             nframes=torch.tensor(nfr, dtype=torch.int32, device=cuda), want_filters=True)
+    out, gn = out.cpu().numpy(), gn.cpu().numpy()
+    for u in range(U):
+        n = nfr[u]
+        full = np.zeros((n, M), np.complex128); full[:, :F] = Y[u, :n]; full[:, F:] = np.conj(Y[u, :n, 1:F - 1][:, ::-1])
+        wo, wg = oracle.wpe_single(full, lowerN, upperN, iters, loadDb, bw, 16000.0)
+        np.testing.assert_allclose(gn[u], wg[:F], rtol=1e-8, atol=1e-12)
+        assert np.abs(out[u, :n] - wo[:, :F]).max() <= 1e-6 * np.abs(wo).max()
+        assert not out[u, n:].any()
+        assert np.abs(wo[:, F:] - np.conj(wo[:, 1:F - 1][:, ::-1])).max() < 1e-9       # the mirrored half of the reference's output is redundant
+    # the operator behind the stream protocol: a Python iterable of frames as the source (pyStream.h:44-152)
+    from dsr.btk import stream as S, dereverberation as Dv
+
+    class Frames(object):
+        def __init__(self, a):
+            self.a = a
+
+        def size(self):
+            return self.a.shape[1]
+
+        def __iter__(self):
+            return iter(self.a)
+
+    full = np.zeros((N, M), np.complex128); full[:, :F] = Y[0]; full[:, F:] = np.conj(Y[0, :, 1:F - 1][:, ::-1])
+    src = S.PyVectorComplexFeatureStreamPtr(Frames(full))
+    rows = np.array([np.array(v) for v in Dv.SingleChannelWPEDereverberationFeaturePtr(src, lowerN, upperN, iters, loadDb, bw, 16000.0)])
+    wo, _ = oracle.wpe_single(full, lowerN, upperN, iters, loadDb, bw, 16000.0)
+    assert rows.shape == wo.shape and np.abs(rows - wo).max() <= 2e-6 * np.abs(wo).max()

@@ -401,3 +401,24 @@ def test_zelinski_postfilter_against_numpy(oracle):
                 assert abs(out[t, f] - ref) < 1e-12
     with pytest.raises(ValueError):
         oracle.zelinski_postfilter(X[:1], Y, wq[:, :1])
+
+
+def test_wpe_single_against_numpy(oracle):
+    """dereverberation.cc:93-226 restated vs numpy normal equations (first iteration: theta_n = max(|y_n|, 1e-3)^2)."""
+    rng = np.random.default_rng(9)
+    N, M, lowerN, upperN, loadDb = 80, 8, 2, 6, -20.0
+    P = upperN - lowerN + 1
+    Y = rng.standard_normal((N, M)) + 1j * rng.standard_normal((N, M))
+    out, gn = oracle.wpe_single(Y, lowerN, upperN, 1, loadDb, 0.0, 16000.0)
+    for b in (0, 3, 7):
+        y = Y[:, b]
+        th = np.maximum(np.abs(y), 1e-3) ** 2
+        R = np.zeros((P, P), complex); r = np.zeros(P, complex)
+        for n in range(lowerN, N):
+            lag = np.array([y[n - lowerN - l] if n - lowerN - l >= 0 else 0.0 for l in range(P)])
+            R += np.outer(lag, np.conj(lag)) / th[n]; r += np.conj(y[n]) * lag / th[n]
+        d = np.abs(np.diag(R)); R[np.diag_indices(P)] = d + d.max() * 10 ** (loadDb / 10)
+        g = np.linalg.solve(R, r)
+        assert np.abs(g - gn[b]).max() < 1e-10 * max(1.0, np.abs(g).max())
+        pred = np.array([sum(np.conj(g[l]) * (y[n - lowerN - l] if n - lowerN - l >= 0 else 0.0) for l in range(P)) if n >= lowerN else 0.0 for n in range(N)])
+        assert np.abs(out[:, b] - (y - pred)).max() < 1e-10
