@@ -144,13 +144,9 @@ __global__ __launch_bounds__(kThreads) void k_viterbi(GraphDev G, DecDev Dd, con
   TokB* tokB0 = Dd.tokB + (size_t) slot * 2 * Dd.maxTok; TokB* tokB1 = tokB0 + Dd.maxTok;
   TokA* ctok = Dd.ctok + (size_t) slot * 8192;
   Side* side = Dd.side + (size_t) slot * kFastC;
-  int* tokOff = Dd.tokOff + (size_t) slot * (Dd.maxTok + 1);
-  int* tokCnt = Dd.tokCnt + (size_t) slot * (Dd.maxTok + 1);
-  int* chead = Dd.chead + (size_t) slot * Dd.maxCand;
-  int* owner = Dd.owner + (size_t) slot * Dd.maxCand;
-  int* rank = Dd.rank + (size_t) slot * Dd.maxCand;
+  // (the staging arrays of the memory path are addressed where that path starts: their base pointers would otherwise sit in
+  // scalar registers through every frame of the register path, which is short of them)
   CandA* cA = Dd.cA + (size_t) slot * Dd.maxCand; CandB* cB = Dd.cB + (size_t) slot * Dd.maxCand;
-  unsigned* first = Dd.first + (size_t) slot * G.nNodes;
   // first[] holds (tag << 24 | slot); tags count DOWN so every entry of an older frame compares larger and never
   // needs resetting; the table is wiped when the 8-bit tag runs out (and on the very first use of a slot)
   unsigned tag = Dd.tags[slot];
@@ -191,7 +187,7 @@ __global__ __launch_bounds__(kThreads) void k_viterbi(GraphDev G, DecDev Dd, con
       const int mode = (fr == T) ? 1 : 0;
       if (mode == 0 && useLdsRow) { for (int i = tid; i < nDist; i += nthr) srow[i] = sc[(size_t) fr * nDist + i]; }
       const float* rowG = sc + (size_t) fr * nDist;                            // the frame's score row in memory
-      int numNew = 0;
+      int numNew = 0, numStat = -1;                                           // tokens written to the new list / tokens the reference's list would hold
       if (Dd.prof && tid == 0) s_tlast = (long long) wall_clock64();
       bool fast = fastOK && mode == 0 && n <= fastCapN;
 
@@ -482,11 +478,34 @@ __global__ __launch_bounds__(kThreads) void k_viterbi(GraphDev G, DecDev Dd, con
             }
           }
           if (s_err) { status = DSR_E_ALLOCATION; break; }                     // (uniform: written before the barriers above)
-          // count the new tokens per (k, wave) group of 64 slots
-          for (int k = 0; k < K; k++) {
-            const unsigned long long bal = __ballot((firstMask >> k) & 1ull);
-            if (lq == 0) s_cnt[k * nw + wq] = __popcll(bal);
+          // A token whose score is above (this frame's best emitting total + beam) fails the beam test of the next frame
+          // (decoder.h:586-588) and is never looked at again: it is counted (activeHypos, maxActive) but neither written to the list
+          // nor to the back-pointer arena.  The order of the tokens that stay is unchanged, so the next frame's arrival slots are too.
+          // Not on the last frame (the end expansion takes every token) and not when the lists are dumped.
+          const double threshNext = __dadd_rn(topScore, Dd.beam);
+          const bool prune = !dump && (fr + 1 < T);
+          unsigned long long keepMask = 0ull;
+#pragma unroll
+          for (int k = 0; k < kFastK; k++) if (k < K && ((firstMask >> k) & 1ull)) {
+            const float sc1 = __fadd_rn(qac[k], qlm[k]);
+            if (!prune || !((double) sc1 > threshNext)) keepMask |= 1ull << k;
           }
+          for (int kb = kFastK; kb < K; kb += 8) {
+            float oac[8], olm[8]; int orec[8]; unsigned oek[8]; park_load(kb, oac, olm, orec, oek);
+#pragma unroll
+            for (int i = 0; i < 8; i++) if (kb + i < K && ((firstMask >> (kb + i)) & 1ull)) {
+              const float sc1 = __fadd_rn(oac[i], olm[i]);
+              if (!prune || !((double) sc1 > threshNext)) keepMask |= 1ull << (kb + i);
+            }
+          }
+          // count the tokens that stay per (k, wave) group of 64 slots, and all new tokens for the statistics
+          int allFirst = 0;
+          for (int k = 0; k < K; k++) {
+            const unsigned long long bal = __ballot((keepMask >> k) & 1ull);
+            if (lq == 0) s_cnt[k * nw + wq] = __popcll(bal);
+            allFirst += __popcll(__ballot((firstMask >> k) & 1ull));
+          }
+          if (lq == 0) s_waveTotE[wq] = allFirst;
           __syncthreads();
           if (wq == 0) {                                                       // exclusive prefix over (k, wave) = slot order of the groups
             const int nG = K * nw;                                             // <= 6 * 64
@@ -501,15 +520,17 @@ __global__ __launch_bounds__(kThreads) void k_viterbi(GraphDev G, DecDev Dd, con
           __syncthreads();
           TICK(6);
           numNew = uni(s_waveTot[0]);
+          { int a = 0; for (int w = 0; w < nw; w++) a += s_waveTotE[w]; numStat = uni(a); }
           if (numNew > Dd.maxTok || arenaOff + numNew > Dd.arenaCap) { status = DSR_E_ALLOCATION; break; }
           // ---- P6: the new list in reverse first-arrival order + back pointers; the state table is wiped for the next frame
           auto write4 = [&](const int g4, const float* ac4, const float* lm4, const int* rec4, const unsigned* ek4) __attribute__((always_inline)) {
             int4 dx[4]; uint32_t pv[4];
 #pragma unroll
-            for (int i = 0; i < 4; i++) {                                      // unconditional loads (every index is in bounds), in flight together
-              dx[i] = *reinterpret_cast<const int4*>(&G.xrecD[rec4[i] & 0x3FFFFFFF].dst);                  // same state for every arrival
-              const bool sw = (ek4[i] & 0x80000000u) != 0u; const unsigned si = ek4[i] & 0x7FFFFFFFu;
-              const uint32_t* pb = (sw && si >= (unsigned) sideLds) ? &side[si].prevBp : &ctok[sw ? 0u : (ek4[i] & 0x1FFFu)].bp;
+            for (int i = 0; i < 4; i++) {                                      // unconditional loads (every index is in bounds), in flight together;
+              const bool kp = (keepMask >> (g4 + i)) & 1ull;                   // placements that are not written all read record 0 / token 0 (one line)
+              dx[i] = *reinterpret_cast<const int4*>(&G.xrecD[kp ? (rec4[i] & 0x3FFFFFFF) : 0].dst);       // same state for every arrival
+              const bool sw = kp && (ek4[i] & 0x80000000u) != 0u; const unsigned si = ek4[i] & 0x7FFFFFFFu;
+              const uint32_t* pb = (sw && si >= (unsigned) sideLds) ? &side[si].prevBp : &ctok[(sw || !kp) ? 0u : (ek4[i] & 0x1FFFu)].bp;
               pv[i] = *pb;
               if (sw && si < (unsigned) sideLds) pv[i] = sideL[si].prevBp;
             }
@@ -517,7 +538,7 @@ __global__ __launch_bounds__(kThreads) void k_viterbi(GraphDev G, DecDev Dd, con
             for (int i = 0; i < 4; i++) {
               const int k = g4 + i;
               if (k < K) {
-                const bool isFirst = (firstMask >> k) & 1ull;
+                const bool isFirst = (keepMask >> k) & 1ull;
                 const unsigned long long bal = __ballot(isFirst);
                 if (isFirst) {
                   const int pos = numNew - 1 - (s_cnt[k * nw + wq] + __popcll(bal & ((1ull << lq) - 1ull)));
@@ -544,6 +565,12 @@ __global__ __launch_bounds__(kThreads) void k_viterbi(GraphDev G, DecDev Dd, con
       }
       if (!fast) {
       // ======================= memory path =======================
+      int* tokOff = Dd.tokOff + (size_t) slot * (Dd.maxTok + 1);
+      int* tokCnt = Dd.tokCnt + (size_t) slot * (Dd.maxTok + 1);
+      int* chead = Dd.chead + (size_t) slot * Dd.maxCand;
+      int* owner = Dd.owner + (size_t) slot * Dd.maxCand;
+      int* rank = Dd.rank + (size_t) slot * Dd.maxCand;
+      unsigned* first = Dd.first + (size_t) slot * G.nNodes;
       if (tag <= 1u) { for (int i = tid; i < G.nNodes; i += nthr) first[i] = 0xFFFFFFFFu; tag = 255u; __syncthreads(); } else tag--;
       const unsigned tagw = tag << 24;
       // ---------------- phase A: per-token placement counts, wave-local exclusive scan
@@ -736,10 +763,11 @@ __global__ __launch_bounds__(kThreads) void k_viterbi(GraphDev G, DecDev Dd, con
           __syncthreads();
           if (tid == 0) { Dd.dumpFrameOff[fr] = o; Dd.dumpFrameOff[fr + 1] = o + numNew; cnt[0] = o + numNew; cnt[1] = fr + 1; }
         }
-        if (numNew == 0) { status = DSR_E_CONSISTENCY; break; }                // the reference never terminates from here
+        if (numStat < 0) numStat = numNew;                                     // memory path: every new token is written
+        if (numStat == 0 || numNew == 0) { status = DSR_E_CONSISTENCY; break; } // no token can be expanded in the next frame: the reference never terminates from here
         { TokA* tmp = curA; curA = nxtA; nxtA = tmp; TokB* tmb = curB; curB = nxtB; nxtB = tmb; }
         n = numNew; arenaOff += numNew;
-        activeHypos += numNew; if (numNew > maxActive) maxActive = numNew;
+        activeHypos += numStat; if (numStat > maxActive) maxActive = numStat;
         thresh = __dadd_rn(topScore, Dd.beam);
       } else {
         // ---------------- best token (decoder.h:639-685): list order, strict '<' on the float score
