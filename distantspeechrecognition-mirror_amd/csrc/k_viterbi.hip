@@ -41,12 +41,13 @@ struct Bp { uint32_t prev; uint32_t rec; };
 
 static constexpr uint32_t kNone = 0xFFFFFFFFu;
 static constexpr uint32_t kEndBit = 0x80000000u;
-static constexpr int kThreads = 512;              // 8 waves: 256 VGPRs per thread for the register path
+static constexpr int kThreads = 1024;             // 16 waves per CU at 128 VGPRs (512 x 256 VGPRs: 22 % slower, 768 x 168: 4 % slower)             // 8 waves: 256 VGPRs per thread for the register path
 static constexpr int kWaves = kThreads / 64;
-static constexpr int kFastK = 16;                  // placements a thread keeps in registers on the register path
+static constexpr int kFastK = 8;
+static constexpr int kB = 2;                        // placements whose loads are in flight together (batch of the register-path phases)                  // placements a thread keeps in registers on the register path
 static constexpr int kFastC = 24576;               // most placements per frame on the register path (those beyond kFastK per thread are parked in memory)
 static constexpr int kFastE = 8190;                // most expanding tokens per frame on the register path
-static constexpr int kP1 = 32;                     // token rounds per wave in the register path's beam pass
+static constexpr int kP1 = 16;                     // token rounds per wave in the register path's beam pass
 static constexpr int kSideLds = 528;               // later arrivals kept in LDS (the region also holds the slot offsets, dead by then)               // most placements / expanding tokens per frame on the register path
 
 struct GraphDev {
@@ -286,9 +287,9 @@ __global__ __launch_bounds__(kThreads) void k_viterbi(GraphDev G, DecDev Dd, con
             return h;
           };
           auto expand8 = [&](const int g8, float* ac8, float* lm8, int* rec8, unsigned* ek8) __attribute__((always_inline)) {
-            int4 xr[8]; int xd[8]; bool tsil[8];
+            int4 xr[kB]; int xd[kB]; bool tsil[kB];
 #pragma unroll
-            for (int i = 0; i < 8; i++) {                                      // slot -> (token, position in its expansion list)
+            for (int i = 0; i < kB; i++) {                                      // slot -> (token, position in its expansion list)
               const int k = g8 + i; const int c = k * nthr + tq; const int grp = k * nw + wq;
               unsigned e = 0u; int j = 0;
               if (c < C) {
@@ -299,16 +300,16 @@ __global__ __launch_bounds__(kThreads) void k_viterbi(GraphDev G, DecDev Dd, con
               ek8[i] = e; rec8[i] = j;
             }
 #pragma unroll
-            for (int i = 0; i < 8; i++) {                                      // eight token loads in flight
+            for (int i = 0; i < kB; i++) {                                      // eight token loads in flight
               const TokA t = ctok[ek8[i]];
               ac8[i] = t.ac; lm8[i] = t.lm; rec8[i] += (int) (t.xs & 0x7FFFFFFFu); tsil[i] = (t.xs >> 31) != 0u;
             }
 #pragma unroll
-            for (int i = 0; i < 8; i++) {                                      // eight record loads in flight
+            for (int i = 0; i < kB; i++) {                                      // eight record loads in flight
               xr[i] = *reinterpret_cast<const int4*>(&G.xrecD[rec8[i]]); xd[i] = G.xrecD[rec8[i]].dst;
             }
 #pragma unroll
-            for (int i = 0; i < 8; i++) {
+            for (int i = 0; i < kB; i++) {
               const int c = (g8 + i) * nthr + tq;
               if (c < C) {
                 const int xdist = xr[i].x; const float xcost = __int_as_float(xr[i].y); const uint32_t xmeta = (uint32_t) xr[i].z;
@@ -351,22 +352,22 @@ __global__ __launch_bounds__(kThreads) void k_viterbi(GraphDev G, DecDev Dd, con
               }
             }
           };
-          expand8(0, &qac[0], &qlm[0], &qrec[0], &ek[0]);
-          if constexpr (kFastK > 8) { if (K > 8) expand8(8, &qac[8], &qlm[8], &qrec[8], &ek[8]); }
+#pragma unroll
+          for (int g8 = 0; g8 < kFastK; g8 += kB) if (g8 < K) expand8(g8, &qac[g8], &qlm[g8], &qrec[g8], &ek[g8]);
           auto park_store = [&](const int kb, const float* oac, const float* olm, const int* orec, const unsigned* oek) __attribute__((always_inline)) {
 #pragma unroll
-            for (int i = 0; i < 8; i++) { const int c = (kb + i) * nthr + tq; if (c < C) ovf[c - kFastK * nthr] = make_uint4(__float_as_uint(oac[i]), __float_as_uint(olm[i]), (unsigned) orec[i], oek[i]); }
+            for (int i = 0; i < kB; i++) { const int c = (kb + i) * nthr + tq; if (c < C) ovf[c - kFastK * nthr] = make_uint4(__float_as_uint(oac[i]), __float_as_uint(olm[i]), (unsigned) orec[i], oek[i]); }
           };
           auto park_load = [&](const int kb, float* oac, float* olm, int* orec, unsigned* oek) __attribute__((always_inline)) {
 #pragma unroll
-            for (int i = 0; i < 8; i++) {
+            for (int i = 0; i < kB; i++) {
               int c = (kb + i) * nthr + tq; c = (c < C) ? c : kFastK * nthr;                // K > kFastK: that slot exists
               const uint4 v = ovf[c - kFastK * nthr];
               oac[i] = __uint_as_float(v.x); olm[i] = __uint_as_float(v.y); orec[i] = (int) v.z; oek[i] = v.w;
             }
           };
-          for (int kb = kFastK; kb < K; kb += 8) {
-            float oac[8], olm[8]; int orec[8]; unsigned oek[8];
+          for (int kb = kFastK; kb < K; kb += kB) {
+            float oac[kB], olm[kB]; int orec[kB]; unsigned oek[kB];
             expand8(kb, oac, olm, orec, oek); park_store(kb, oac, olm, orec, oek);
           }
           TICK(2);
@@ -382,14 +383,14 @@ __global__ __launch_bounds__(kThreads) void k_viterbi(GraphDev G, DecDev Dd, con
           // the chain head), then every first arrival folds its chain in slot order (decoder.h:519-528)
           unsigned long long firstMask = 0ull;
           auto later8 = [&](const int g8, const int pass, const float* ac8, const float* lm8, const int* rec8, const unsigned* ek8) __attribute__((always_inline)) {
-            double tt[8]; uint32_t pb[8];
+            double tt[kB]; uint32_t pb[kB];
 #pragma unroll
-            for (int i = 0; i < 8; i++) {                                      // what a later arrival hands over; loaded for all (coalesced, in flight together)
+            for (int i = 0; i < kB; i++) {                                      // what a later arrival hands over; loaded for all (coalesced, in flight together)
               int c = (g8 + i) * nthr + tq; c = (c < C) ? c : 0;
               tt[i] = ttlS[c]; pb[i] = ctok[ek8[i] & 0x1FFFu].bp;
             }
 #pragma unroll
-            for (int i = 0; i < 8; i++) {
+            for (int i = 0; i < kB; i++) {
               const int c = (g8 + i) * nthr + tq;
               if (c < C && (ek8[i] & (1u << 28)) && (int) ((ek8[i] >> 27) & 1u) == pass && !((firstMask >> (g8 + i)) & 1ull)) {
                 const unsigned h = (ek8[i] >> 13) & 0x3FFFu;
@@ -440,11 +441,11 @@ __global__ __launch_bounds__(kThreads) void k_viterbi(GraphDev G, DecDev Dd, con
           };
           // second pass: the waiting half of the states enters the (wiped) table
           auto insert8 = [&](const int g8, const int* rec8, unsigned* ek8) __attribute__((always_inline)) {
-            int xd[8];
+            int xd[kB];
 #pragma unroll
-            for (int i = 0; i < 8; i++) xd[i] = G.xrecD[rec8[i] & 0x3FFFFFFF].dst;
+            for (int i = 0; i < kB; i++) xd[i] = G.xrecD[rec8[i] & 0x3FFFFFFF].dst;
 #pragma unroll
-            for (int i = 0; i < 8; i++) {
+            for (int i = 0; i < kB; i++) {
               const int c = (g8 + i) * nthr + tq;
               if (c < C && (ek8[i] & (1u << 27)) && !(ek8[i] & 0x80000000u)) ek8[i] |= (table_insert((unsigned) xd[i], (unsigned) xd[i] * 2654435761u, c) << 13) | (1u << 28);
             }
@@ -455,25 +456,25 @@ __global__ __launch_bounds__(kThreads) void k_viterbi(GraphDev G, DecDev Dd, con
               { uint4* h4 = reinterpret_cast<uint4*>(hkey); const int q4 = hashN >> 2;
                 for (int i = tq; i < 2 * q4; i += nthr) h4[i] = (i < q4) ? make_uint4(0u, 0u, 0u, 0u) : make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu); }
               __syncthreads();
-              insert8(0, &qrec[0], &ek[0]);
-              if constexpr (kFastK > 8) { if (K > 8) insert8(8, &qrec[8], &ek[8]); }
-              for (int kb = kFastK; kb < K; kb += 8) {
-                float oac[8], olm[8]; int orec[8]; unsigned oek[8]; park_load(kb, oac, olm, orec, oek);
+#pragma unroll
+              for (int g8 = 0; g8 < kFastK; g8 += kB) if (g8 < K) insert8(g8, &qrec[g8], &ek[g8]);
+              for (int kb = kFastK; kb < K; kb += kB) {
+                float oac[kB], olm[kB]; int orec[kB]; unsigned oek[kB]; park_load(kb, oac, olm, orec, oek);
                 insert8(kb, orec, oek); park_store(kb, oac, olm, orec, oek);
               }
               __syncthreads();
             }
-            later8(0, pass, &qac[0], &qlm[0], &qrec[0], &ek[0]);
-            if constexpr (kFastK > 8) { if (K > 8) later8(8, pass, &qac[8], &qlm[8], &qrec[8], &ek[8]); }
-            for (int kb = kFastK; kb < K; kb += 8) { float oac[8], olm[8]; int orec[8]; unsigned oek[8]; park_load(kb, oac, olm, orec, oek); later8(kb, pass, oac, olm, orec, oek); }
+#pragma unroll
+            for (int g8 = 0; g8 < kFastK; g8 += kB) if (g8 < K) later8(g8, pass, &qac[g8], &qlm[g8], &qrec[g8], &ek[g8]);
+            for (int kb = kFastK; kb < K; kb += kB) { float oac[kB], olm[kB]; int orec[kB]; unsigned oek[kB]; park_load(kb, oac, olm, orec, oek); later8(kb, pass, oac, olm, orec, oek); }
             __syncthreads();
             if (pass == 0) TICK(5);
 #pragma unroll
             for (int k = 0; k < kFastK; k++) if (k < K) fold1(k, pass, qac[k], qlm[k], qrec[k], ek[k]);
-            for (int kb = kFastK; kb < K; kb += 8) {
-              float oac[8], olm[8]; int orec[8]; unsigned oek[8]; park_load(kb, oac, olm, orec, oek);
+            for (int kb = kFastK; kb < K; kb += kB) {
+              float oac[kB], olm[kB]; int orec[kB]; unsigned oek[kB]; park_load(kb, oac, olm, orec, oek);
 #pragma unroll
-              for (int i = 0; i < 8; i++) if (kb + i < K) fold1(kb + i, pass, oac[i], olm[i], orec[i], oek[i]);
+              for (int i = 0; i < kB; i++) if (kb + i < K) fold1(kb + i, pass, oac[i], olm[i], orec[i], oek[i]);
               park_store(kb, oac, olm, orec, oek);
             }
           }
@@ -490,10 +491,10 @@ __global__ __launch_bounds__(kThreads) void k_viterbi(GraphDev G, DecDev Dd, con
             const float sc1 = __fadd_rn(qac[k], qlm[k]);
             if (!prune || !((double) sc1 > threshNext)) keepMask |= 1ull << k;
           }
-          for (int kb = kFastK; kb < K; kb += 8) {
-            float oac[8], olm[8]; int orec[8]; unsigned oek[8]; park_load(kb, oac, olm, orec, oek);
+          for (int kb = kFastK; kb < K; kb += kB) {
+            float oac[kB], olm[kB]; int orec[kB]; unsigned oek[kB]; park_load(kb, oac, olm, orec, oek);
 #pragma unroll
-            for (int i = 0; i < 8; i++) if (kb + i < K && ((firstMask >> (kb + i)) & 1ull)) {
+            for (int i = 0; i < kB; i++) if (kb + i < K && ((firstMask >> (kb + i)) & 1ull)) {
               const float sc1 = __fadd_rn(oac[i], olm[i]);
               if (!prune || !((double) sc1 > threshNext)) keepMask |= 1ull << (kb + i);
             }
@@ -552,10 +553,10 @@ __global__ __launch_bounds__(kThreads) void k_viterbi(GraphDev G, DecDev Dd, con
           };
 #pragma unroll
           for (int g4 = 0; g4 < kFastK; g4 += 4) if (g4 < K) write4(g4, &qac[g4], &qlm[g4], &qrec[g4], &ek[g4]);
-          for (int kb = kFastK; kb < K; kb += 8) {
-            float oac[8], olm[8]; int orec[8]; unsigned oek[8]; park_load(kb, oac, olm, orec, oek);
-            write4(kb, &oac[0], &olm[0], &orec[0], &oek[0]);
-            if (K > kb + 4) write4(kb + 4, &oac[4], &olm[4], &orec[4], &oek[4]);
+          for (int kb = kFastK; kb < K; kb += kB) {
+            float oac[kB], olm[kB]; int orec[kB]; unsigned oek[kB]; park_load(kb, oac, olm, orec, oek);
+#pragma unroll
+            for (int h4 = 0; h4 < kB; h4 += 4) if (K > kb + h4) write4(kb + h4, &oac[h4], &olm[h4], &orec[h4], &oek[h4]);
           }
           {
             uint4* h4 = reinterpret_cast<uint4*>(hkey); const int q4 = hashN >> 2;
@@ -690,11 +691,14 @@ __global__ __launch_bounds__(kThreads) void k_viterbi(GraphDev G, DecDev Dd, con
       if (useHash) for (int i = tid; i < 2 * hashN; i += nthr) hkey[i] = (i < hashN) ? 0u : 0xFFFFFFFFu;   // ready for the next frame
       // ---------------- phase C1: fold per destination state (by its first-arrival thread), count new tokens
       const int chunkC = ((C + nw * 64 - 1) / (nw * 64)) * 64;
+      // (as on the register path: tokens above this frame's best emitting total + beam are counted but not written)
+      const double threshNextM = __dadd_rn(topScore, Dd.beam);
+      const bool pruneM = !dump && mode == 0 && (fr + 1 < T);
       {
-        int running = 0;
+        int running = 0, runAll = 0;
         const int b0 = wave * chunkC, b1 = (b0 + chunkC < C) ? b0 + chunkC : C;
         for (int base = b0; base < b1; base += 64) {
-          const int c = base + lane; bool isFirst = false;
+          const int c = base + lane; bool isFirst = false, isAny = false;
           if (c < b1) {
             const int h0 = ld_i32(&chead[c]);
             isFirst = (h0 != -2);
@@ -708,17 +712,20 @@ __global__ __launch_bounds__(kThreads) void k_viterbi(GraphDev G, DecDev Dd, con
                 if (best == 0x7FFFFFFF) break;
                 w = best; aw = cA[w]; fw = (double) __fadd_rn(aw.ac, aw.lm);
               }
+              isAny = true;
+              if (pruneM && ((double) __fadd_rn(aw.ac, aw.lm) > threshNextM)) { isFirst = false; w = -3; }    // -3: a new token that is not written
               chead[c] = w;                                                    // winner of this state
             }
           }
           const unsigned long long bal = __ballot(isFirst);
           if (isFirst) rank[c] = running + __popcll(bal & ((1ull << lane) - 1ull));
-          running += __popcll(bal);
+          running += __popcll(bal); runAll += __popcll(__ballot(isAny));
         }
-        if (lane == 0) s_waveTot[wave] = running;
+        if (lane == 0) { s_waveTot[wave] = running; s_waveTotE[wave] = runAll; }
       }
       __syncthreads();
-      for (int w = 0; w < nw; w++) numNew += s_waveTot[w];
+      numStat = 0;
+      for (int w = 0; w < nw; w++) { numNew += s_waveTot[w]; numStat += s_waveTotE[w]; }
       if (numNew > Dd.maxTok || arenaOff + numNew > Dd.arenaCap) { status = DSR_E_ALLOCATION; break; }
       // ---------------- phase C2: write the new token list (reverse first-arrival order) + back pointers
       {
@@ -890,7 +897,7 @@ dsr_status dsr_decoder_create(const dsr_decoder_cfg* cfg, dsr_decoder** out)
     if (d->cfg.maxActive <= 0) d->cfg.maxActive = 65536;
     if (d->cfg.maxCandidates <= 0) d->cfg.maxCandidates = 8 * d->cfg.maxActive;
     if (d->cfg.maxCandidates >= (1 << 24)) throw Error(DSR_E_PARAMETER, "maxCandidates must be < 2^24");
-    if (const char* e = getenv("DSR_VITERBI_THREADS")) { const int t = atoi(e); if (t == 256 || t == 512) d->threads = t; }
+    if (const char* e = getenv("DSR_VITERBI_THREADS")) { const int t = atoi(e); if (t == 256 || t == 512 || t == 768 || t == 1024) d->threads = t; }
     if (d->cfg.streams <= 0) {
       hipDeviceProp_t prop; int dev = 0; DSR_HIP(hipGetDevice(&dev)); DSR_HIP(hipGetDeviceProperties(&prop, dev));
       if (const char* e = getenv("DSR_VITERBI_TWO")) d->twoPerCu = atoi(e) != 0;
