@@ -25,6 +25,7 @@
 #include "common.h"
 #include "wfst_graph.h"
 #include <cmath>
+#include <type_traits>
 
 namespace dsr {
 
@@ -33,7 +34,10 @@ struct Tok { int32_t node; float ac; float lm; uint32_t bp; };        // registe
 struct TokA { float ac; float lm; uint32_t bp; uint32_t xs; };        // xs: first expansion record of the node | bit31: edge input == silenceX
 struct TokB { int32_t node; int32_t cnt; };                           // cnt: number of expansion records of the node
 // expansion record as the register path reads it: what the expansion needs in the first 16 bytes, what the new token needs in the second
-struct XRecD { int32_t dist; float cost; uint32_t meta; float eps1; int32_t dst; int32_t dstXoff; int32_t dstCnt; int32_t pathOff; };   // eps1: cost of the first epsilon hop (meta bit17: it has an output)
+// eps1: cost of the first epsilon hop (meta bit17: it has an output).  Further hops (meta bits 18..30: hop h = 1..13 has an output):
+// a two-hop path carries the second cost in p2 (float bits), longer ones the offset of their hop costs in GraphDev::pathCost;
+// meta bit31: more than 14 hops, walked through the path/arc arrays instead.
+struct XRecD { int32_t dist; float cost; uint32_t meta; float eps1; int32_t dst; int32_t p2; int32_t dstXoff; int32_t dstCnt; };
 struct Side { double ttl; float ac; float lm; int32_t rec; uint32_t prevBp; int32_t c; uint32_t next; };   // a later arrival at an occupied state
 struct CandA { double ttl; float ac; float lm; };
 struct CandB { int32_t dst; int32_t next; int32_t rec; uint32_t prevBp; };   // rec bit30: the emitting arc's input is the silence symbol
@@ -48,12 +52,13 @@ static constexpr int kB = 2;                        // placements whose loads ar
 static constexpr int kFastC = 24576;               // most placements per frame on the register path (those beyond kFastK per thread are parked in memory)
 static constexpr int kFastE = 8190;                // most expanding tokens per frame on the register path
 static constexpr int kP1 = 16;                     // token rounds per wave in the register path's beam pass
+static constexpr int kW = 8;                        // register placements whose P6 loads are in flight together (parked ones: kB)
 static constexpr int kSideLds = 528;               // later arrivals kept in LDS (the region also holds the slot offsets, dead by then)               // most placements / expanding tokens per frame on the register path
 
 struct GraphDev {
   int nNodes, initial;
   const int* xoff; const XRec* xrec; const XRecD* xrecD; const int* xarc; const int* xpathOff;
-  const int* eoff; const ERec* erec; const int* path;
+  const int* eoff; const ERec* erec; const int* path; const float* pathCost;
   const float* arcCost; const uint32_t* arcOut; const uint32_t* arcIn;
   const int* nodeFinal; const float* nodeCost;
 };
@@ -185,6 +190,12 @@ __global__ __launch_bounds__(kThreads) void k_viterbi(GraphDev G, DecDev Dd, con
     TICK(11);
     // frames 0..T-1 (mode 0), then the end expansion (mode 1)
     for (int fr = 0; fr <= T && status == DSR_OK; fr++) {
+#ifndef DSR_V_NOOPAQUE
+      // the thread index behind an opaque copy, once per frame: nothing derived from it (lane masks, per-thread addresses of any
+      // phase or of the memory path) can be hoisted out of the frame loop, where it would sit in scratch memory and be re-read
+      int tidO = (int) threadIdx.x; asm volatile("" : "+v"(tidO));
+      const int tid = tidO, lane = tid & 63, wave = tid >> 6;
+#endif
       const int mode = (fr == T) ? 1 : 0;
       if (mode == 0 && useLdsRow) { for (int i = tid; i < nDist; i += nthr) srow[i] = sc[(size_t) fr * nDist + i]; }
       const float* rowG = sc + (size_t) fr * nDist;                            // the frame's score row in memory
@@ -244,11 +255,15 @@ __global__ __launch_bounds__(kThreads) void k_viterbi(GraphDev G, DecDev Dd, con
           // ---- P2: compact list of the expanding tokens (their slot offsets in LDS, the tokens themselves in memory); a bitmap
           // of the slots where a token's run starts and the token count before every group of 64 slots turn "slot -> token"
           // into a population count
+          // (when every token expands -- the rule once the lists are pruned at write time -- compact index == list index and the
+          // list itself serves as the compact list: no copy)
+          const bool ident = (E == n);
+          const TokA* __restrict__ ctk = ident ? curA : ctok;
 #pragma unroll
           for (int it = 0; it < kP1; it++) if (pk[it] & 0x80000000u) {
             const int e = ebase + (int) ((pk[it] >> 15) & 0xFFFFu); const int off = cbase + (int) (pk[it] & 0x7FFFu);
             eoff[e] = (unsigned short) off;
-            ctok[e] = curA[wave * chunkT + it * 64 + lane];
+            if (!ident) ctok[e] = curA[wave * chunkT + it * 64 + lane];
             atomicOr(&s_bm[off >> 5], 1u << (off & 31));
             for (int g = (off >> 6) + 1; g <= ((off + pcn[it]) >> 6); g++) s_gbase[g] = (unsigned short) (e + 1);   // this token covers slot 64g-1
           }
@@ -287,7 +302,7 @@ __global__ __launch_bounds__(kThreads) void k_viterbi(GraphDev G, DecDev Dd, con
             return h;
           };
           auto expand8 = [&](const int g8, float* ac8, float* lm8, int* rec8, unsigned* ek8) __attribute__((always_inline)) {
-            int4 xr[kB]; int xd[kB]; bool tsil[kB];
+            int4 xr[kB]; int2 xd[kB]; bool tsil[kB];
 #pragma unroll
             for (int i = 0; i < kB; i++) {                                      // slot -> (token, position in its expansion list)
               const int k = g8 + i; const int c = k * nthr + tq; const int grp = k * nw + wq;
@@ -301,12 +316,12 @@ __global__ __launch_bounds__(kThreads) void k_viterbi(GraphDev G, DecDev Dd, con
             }
 #pragma unroll
             for (int i = 0; i < kB; i++) {                                      // eight token loads in flight
-              const TokA t = ctok[ek8[i]];
+              const TokA t = ctk[ek8[i]];
               ac8[i] = t.ac; lm8[i] = t.lm; rec8[i] += (int) (t.xs & 0x7FFFFFFFu); tsil[i] = (t.xs >> 31) != 0u;
             }
 #pragma unroll
             for (int i = 0; i < kB; i++) {                                      // eight record loads in flight
-              xr[i] = *reinterpret_cast<const int4*>(&G.xrecD[rec8[i]]); xd[i] = G.xrecD[rec8[i]].dst;
+              xr[i] = *reinterpret_cast<const int4*>(&G.xrecD[rec8[i]]); xd[i] = *reinterpret_cast<const int2*>(&G.xrecD[rec8[i]].dst);
             }
 #pragma unroll
             for (int i = 0; i < kB; i++) {
@@ -329,12 +344,21 @@ __global__ __launch_bounds__(kThreads) void k_viterbi(GraphDev G, DecDev Dd, con
                 const bool pnull = has ? false : prevNull0;
                 const bool pinSil = has ? sil0 : tsil[i];                      // after an epsilon hop the edge input is 0
                 if (plen > 1) {
-                  const int* pp = G.path + G.xrecD[rec8[i]].pathOff;
-                  for (int h = 1; h < plen; h++) {
-                    const int a = pp[h];
-                    double l = __dadd_rn(lmNode, __dmul_rn(lmS, (double) G.arcCost[a]));
-                    if (G.arcOut[a] != 0) l = __dadd_rn(l, lsPen);
-                    lmNode = (double) (float) l;                                // (the edge before is an epsilon edge: no silence penalty possible here)
+                  if (!(xmeta & 0x80000000u)) {
+                    for (int h = 1; h < plen; h++) {                           // hop costs: inline (two hops) or one independent load per hop
+                      const float ch = (plen == 2) ? __int_as_float(xd[i].y) : G.pathCost[xd[i].y + h - 1];
+                      double l = __dadd_rn(lmNode, __dmul_rn(lmS, (double) ch));
+                      if ((xmeta >> (17 + h)) & 1u) l = __dadd_rn(l, lsPen);
+                      lmNode = (double) (float) l;                              // (the edge before is an epsilon edge: no silence penalty possible here)
+                    }
+                  } else {
+                    const int* pp = G.path + G.xpathOff[rec8[i]];
+                    for (int h = 1; h < plen; h++) {
+                      const int a = pp[h];
+                      double l = __dadd_rn(lmNode, __dmul_rn(lmS, (double) G.arcCost[a]));
+                      if (G.arcOut[a] != 0) l = __dadd_rn(l, lsPen);
+                      lmNode = (double) (float) l;
+                    }
                   }
                 }
                 double lm = __dadd_rn(lmNode, __dmul_rn(lmS, (double) xcost));
@@ -346,9 +370,9 @@ __global__ __launch_bounds__(kThreads) void k_viterbi(GraphDev G, DecDev Dd, con
                 ttlS[c] = ttl; ac8[i] = (float) ac; lm8[i] = (float) lm; rec8[i] |= (silArc ? 0x40000000 : 0);
                 if (ttl < locMin) locMin = ttl;                                // _topScore
                 // state table: claim the bucket, keep the smallest slot (with two passes, the other half of the states waits)
-                const unsigned prod = (unsigned) xd[i] * 2654435761u;
+                const unsigned prod = (unsigned) xd[i].x * 2654435761u;
                 if (nPass > 1 && (prod >> 31)) ek8[i] |= 1u << 27;
-                else ek8[i] |= (table_insert((unsigned) xd[i], prod, c) << 13) | (1u << 28);      // bit28: in the table, not folded yet
+                else ek8[i] |= (table_insert((unsigned) xd[i].x, prod, c) << 13) | (1u << 28);      // bit28: in the table, not folded yet
               }
             }
           };
@@ -387,7 +411,7 @@ __global__ __launch_bounds__(kThreads) void k_viterbi(GraphDev G, DecDev Dd, con
 #pragma unroll
             for (int i = 0; i < kB; i++) {                                      // what a later arrival hands over; loaded for all (coalesced, in flight together)
               int c = (g8 + i) * nthr + tq; c = (c < C) ? c : 0;
-              tt[i] = ttlS[c]; pb[i] = ctok[ek8[i] & 0x1FFFu].bp;
+              tt[i] = ttlS[c]; pb[i] = ctk[ek8[i] & 0x1FFFu].bp;
             }
 #pragma unroll
             for (int i = 0; i < kB; i++) {
@@ -478,6 +502,7 @@ __global__ __launch_bounds__(kThreads) void k_viterbi(GraphDev G, DecDev Dd, con
               park_store(kb, oac, olm, orec, oek);
             }
           }
+          TICK(12);
           if (s_err) { status = DSR_E_ALLOCATION; break; }                     // (uniform: written before the barriers above)
           // A token whose score is above (this frame's best emitting total + beam) fails the beam test of the next frame
           // (decoder.h:586-588) and is never looked at again: it is counted (activeHypos, maxActive) but neither written to the list
@@ -507,7 +532,9 @@ __global__ __launch_bounds__(kThreads) void k_viterbi(GraphDev G, DecDev Dd, con
             allFirst += __popcll(__ballot((firstMask >> k) & 1ull));
           }
           if (lq == 0) s_waveTotE[wq] = allFirst;
+          TICK(13);
           __syncthreads();
+          TICK(14);
           if (wq == 0) {                                                       // exclusive prefix over (k, wave) = slot order of the groups
             const int nG = K * nw;                                             // <= 6 * 64
             int a[6], tot = 0;
@@ -524,27 +551,28 @@ __global__ __launch_bounds__(kThreads) void k_viterbi(GraphDev G, DecDev Dd, con
           { int a = 0; for (int w = 0; w < nw; w++) a += s_waveTotE[w]; numStat = uni(a); }
           if (numNew > Dd.maxTok || arenaOff + numNew > Dd.arenaCap) { status = DSR_E_ALLOCATION; break; }
           // ---- P6: the new list in reverse first-arrival order + back pointers; the state table is wiped for the next frame
-          auto write4 = [&](const int g4, const float* ac4, const float* lm4, const int* rec4, const unsigned* ek4) __attribute__((always_inline)) {
-            int4 dx[4]; uint32_t pv[4];
+          auto write4 = [&](auto NB, const int g4, const float* ac4, const float* lm4, const int* rec4, const unsigned* ek4) __attribute__((always_inline)) {
+            constexpr int nb = decltype(NB)::value;
+            int4 dx[nb]; uint32_t pv[nb];
 #pragma unroll
-            for (int i = 0; i < 4; i++) {                                      // unconditional loads (every index is in bounds), in flight together;
+            for (int i = 0; i < nb; i++) {                                      // unconditional loads (every index is in bounds), in flight together;
               const bool kp = (keepMask >> (g4 + i)) & 1ull;                   // placements that are not written all read record 0 / token 0 (one line)
               dx[i] = *reinterpret_cast<const int4*>(&G.xrecD[kp ? (rec4[i] & 0x3FFFFFFF) : 0].dst);       // same state for every arrival
               const bool sw = kp && (ek4[i] & 0x80000000u) != 0u; const unsigned si = ek4[i] & 0x7FFFFFFFu;
-              const uint32_t* pb = (sw && si >= (unsigned) sideLds) ? &side[si].prevBp : &ctok[(sw || !kp) ? 0u : (ek4[i] & 0x1FFFu)].bp;
+              const uint32_t* pb = (sw && si >= (unsigned) sideLds) ? &side[si].prevBp : &ctk[(sw || !kp) ? 0u : (ek4[i] & 0x1FFFu)].bp;
               pv[i] = *pb;
               if (sw && si < (unsigned) sideLds) pv[i] = sideL[si].prevBp;
             }
 #pragma unroll
-            for (int i = 0; i < 4; i++) {
+            for (int i = 0; i < nb; i++) {
               const int k = g4 + i;
               if (k < K) {
                 const bool isFirst = (keepMask >> k) & 1ull;
                 const unsigned long long bal = __ballot(isFirst);
                 if (isFirst) {
                   const int pos = numNew - 1 - (s_cnt[k * nw + wq] + __popcll(bal & ((1ull << lq) - 1ull)));
-                  TokA na; na.ac = ac4[i]; na.lm = lm4[i]; na.bp = (uint32_t) (arenaOff + pos); na.xs = (uint32_t) dx[i].y | ((rec4[i] & 0x40000000) ? 0x80000000u : 0u);
-                  TokB nb; nb.node = dx[i].x; nb.cnt = dx[i].z;
+                  TokA na; na.ac = ac4[i]; na.lm = lm4[i]; na.bp = (uint32_t) (arenaOff + pos); na.xs = (uint32_t) dx[i].z | ((rec4[i] & 0x40000000) ? 0x80000000u : 0u);
+                  TokB nb; nb.node = dx[i].x; nb.cnt = dx[i].w;
                   Bp bp; bp.prev = pv[i]; bp.rec = (uint32_t) (rec4[i] & 0x3FFFFFFF);
                   nxtA[pos] = na; nxtB[pos] = nb; arena[arenaOff + pos] = bp;
                 }
@@ -552,11 +580,10 @@ __global__ __launch_bounds__(kThreads) void k_viterbi(GraphDev G, DecDev Dd, con
             }
           };
 #pragma unroll
-          for (int g4 = 0; g4 < kFastK; g4 += 4) if (g4 < K) write4(g4, &qac[g4], &qlm[g4], &qrec[g4], &ek[g4]);
+          for (int g4 = 0; g4 < kFastK; g4 += kW) if (g4 < K) write4(std::integral_constant<int, kW>{}, g4, &qac[g4], &qlm[g4], &qrec[g4], &ek[g4]);
           for (int kb = kFastK; kb < K; kb += kB) {
             float oac[kB], olm[kB]; int orec[kB]; unsigned oek[kB]; park_load(kb, oac, olm, orec, oek);
-#pragma unroll
-            for (int h4 = 0; h4 < kB; h4 += 4) if (K > kb + h4) write4(kb + h4, &oac[h4], &olm[h4], &orec[h4], &oek[h4]);
+            write4(std::integral_constant<int, kB>{}, kb, oac, olm, orec, oek);
           }
           {
             uint4* h4 = reinterpret_cast<uint4*>(hkey); const int q4 = hashN >> 2;
@@ -843,7 +870,7 @@ __global__ __launch_bounds__(kThreads) void k_viterbi(GraphDev G, DecDev Dd, con
 struct DecoderState {
   dsr_decoder_cfg cfg; bool haveGraph = false; int nSlots = 0; int nNodes = 0;
   WfstGraph::Csr csr; WfstGraph::Tables tab;
-  DevBuf<int> d_xoff, d_xarc, d_xpathOff, d_eoff, d_path, d_nodeFinal, d_queue;
+  DevBuf<int> d_xoff, d_xarc, d_xpathOff, d_eoff, d_path, d_nodeFinal, d_queue; DevBuf<float> d_pathCost;
   DevBuf<XRec> d_xrec; DevBuf<ERec> d_erec; DevBuf<float> d_arcCost, d_nodeCost; DevBuf<uint32_t> d_arcOut, d_arcIn;
   DevBuf<TokA> d_tokA, d_ctok; DevBuf<TokB> d_tokB; DevBuf<Side> d_side; DevBuf<XRecD> d_xrecD; int fastOK = 0; DevBuf<int> d_tokOff, d_tokCnt, d_owner, d_rank, d_chead; DevBuf<unsigned> d_tags; DevBuf<CandA> d_cA; DevBuf<CandB> d_cB; DevBuf<unsigned> d_first; DevBuf<Bp> d_arena;
   DevBuf<long long> d_prof; DevBuf<dsr_decode_result> d_res; DevBuf<int> d_arcs; DevBuf<unsigned> d_words;
@@ -924,15 +951,22 @@ dsr_status dsr_decoder_set(dsr_decoder* d, const dsr_wfst* g)
     d->d_xrec.upload(d->tab.xrec); d->d_xarc.upload(d->tab.xarc); d->d_xpathOff.upload(d->tab.xpathOff);
     {
       // expansion records with the destination's own expansion range folded in (the register path never reads xoff)
-      const size_t nx = d->tab.xrec.size(); std::vector<XRecD> xd(nx); int maxCnt = 0;
+      const size_t nx = d->tab.xrec.size(); std::vector<XRecD> xd(nx); int maxCnt = 0; std::vector<float> pc(1, 0.0f);
       for (size_t r = 0; r < nx; r++) {
         const XRec& x = d->tab.xrec[r]; XRecD& o = xd[r];
         o.dst = x.dst; o.dist = x.dist; o.cost = x.cost; o.meta = x.meta; o.dstXoff = d->tab.xoff[x.dst]; o.dstCnt = d->tab.xoff[x.dst + 1] - d->tab.xoff[x.dst];
-        o.pathOff = d->tab.xpathOff[r]; o.eps1 = 0.0f;
-        if (x.meta & 0xFFFFu) { const int a0 = d->tab.path[o.pathOff]; o.eps1 = d->csr.cost[a0]; if (d->csr.out[a0] != 0) o.meta |= 0x20000u; }
+        const int po = d->tab.xpathOff[r], plen = (int) (x.meta & 0xFFFFu); o.p2 = 0; o.eps1 = 0.0f;
+        if (x.meta >> 18) throw Error(DSR_E_CONSISTENCY, "expansion record %zu: meta bits above 17 are in use", r);
+        if (plen) { const int a0 = d->tab.path[po]; o.eps1 = d->csr.cost[a0]; if (d->csr.out[a0] != 0) o.meta |= 0x20000u; }
+        if (plen > 14) o.meta |= 0x80000000u;
+        else if (plen > 1) {
+          if (plen == 2) { const float c1 = d->csr.cost[d->tab.path[po + 1]]; memcpy(&o.p2, &c1, 4); }
+          else { o.p2 = (int) pc.size(); for (int h = 1; h < plen; h++) pc.push_back(d->csr.cost[d->tab.path[po + h]]); }
+          for (int h = 1; h < plen; h++) if (d->csr.out[d->tab.path[po + h]] != 0) o.meta |= 1u << (17 + h);
+        }
         if (o.dstCnt > maxCnt) maxCnt = o.dstCnt;
       }
-      d->d_xrecD.upload(xd);
+      d->d_xrecD.upload(xd); d->d_pathCost.upload(pc);
       d->fastOK = (maxCnt < (1 << 19) && nx < ((size_t) 1 << 30)) ? 1 : 0;
       if (getenv("DSR_VITERBI_NOFAST")) d->fastOK = 0;
     }
@@ -994,7 +1028,7 @@ dsr_status dsr_decoder_decode_launch(dsr_decoder* d, const float* score, const i
       DSR_HIP(hipMemsetAsync(d->d_dumpCount.p, 0, 2 * sizeof(long), st));
     }
     GraphDev G; G.nNodes = d->nNodes; G.initial = d->initial; G.xoff = d->d_xoff.p; G.xrec = d->d_xrec.p; G.xrecD = d->d_xrecD.p; G.xarc = d->d_xarc.p;
-    G.xpathOff = d->d_xpathOff.p; G.eoff = d->d_eoff.p; G.erec = d->d_erec.p; G.path = d->d_path.p; G.arcCost = d->d_arcCost.p;
+    G.xpathOff = d->d_xpathOff.p; G.eoff = d->d_eoff.p; G.erec = d->d_erec.p; G.path = d->d_path.p; G.pathCost = d->d_pathCost.p; G.arcCost = d->d_arcCost.p;
     G.arcOut = d->d_arcOut.p; G.arcIn = d->d_arcIn.p; G.nodeFinal = d->d_nodeFinal.p; G.nodeCost = d->d_nodeCost.p;
     DecDev D; D.beam = d->cfg.beam; D.lmScale = d->cfg.lmScale; D.lmPenalty = d->cfg.lmPenalty; D.silPenalty = d->cfg.silPenalty;
     D.silenceX = d->cfg.silenceX; D.maxTok = d->cfg.maxActive; D.maxCand = d->cfg.maxCandidates; D.arenaCap = d->arenaCap;
@@ -1049,7 +1083,7 @@ dsr_status dsr_decoder_decode_collect(dsr_decoder* d, dsr_decode_result* res, in
       std::vector<long long> hp((size_t) slots * 16); DSR_HIP(hipMemcpy(hp.data(), prof, hp.size() * sizeof(long long), hipMemcpyDeviceToHost));
       double acc[16] = {0}; for (int s2 = 0; s2 < slots; s2++) for (int i = 0; i < 16; i++) acc[i] += (double) hp[(size_t) s2 * 16 + i];
       fprintf(stderr, "[dsr viterbi prof] mean us per slot:");
-      for (int i = 0; i < 12; i++) fprintf(stderr, " p%d=%.0f", i, acc[i] / slots / 100.0);
+      for (int i = 0; i < 15; i++) fprintf(stderr, " p%d=%.0f", i, acc[i] / slots / 100.0);
       fprintf(stderr, "\n");
     }
     if (d->dumpOn) {

@@ -3,6 +3,8 @@
 Tolerances: filterbank/beamformer complex64 vs the reference's complex128 -- relative 1e-5 of
 the frame RMS; MFCC -- abs 1e-4; GMM nearest-Gaussian scores and every WFST index/score -- bit exact.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -368,6 +370,44 @@ def test_viterbi_token_lists(dsr, oracle, cuda):
     assert np.array_equal(d["arc"], ro["dumpArc"])
     assert np.array_equal(d["ac"].view(np.uint32), ro["dumpAc"].view(np.uint32))
     assert np.array_equal(d["lm"].view(np.uint32), ro["dumpLm"].view(np.uint32))
+
+
+def test_viterbi_long_epsilon_paths(dsr, oracle, cuda):
+    """Epsilon chains of 1, 2, 3, 14, 15 and 20 hops (outputs on some hops) in front of emitting arcs: the expansion records carry
+    one and two hops inline, up to 14 through the hop-cost table, longer ones through the path arrays -- all against the oracle."""
+    import torch
+    nDist = 6
+    arcs = []; nxt = [1]
+    def new():
+        nxt[0] += 1; return nxt[0] - 1
+    hub = 0
+    rng = np.random.default_rng(5)
+    for hops in (0, 1, 2, 3, 14, 15, 20):
+        for rep in range(2):
+            cur = hub
+            for h in range(hops):
+                n2 = new(); arcs.append((cur, n2, 0, int(rng.integers(0, 3)) if (h % 3 == rep) else 0, float(np.float32(rng.uniform(0.1, 1.5))))); cur = n2
+            n2 = new(); arcs.append((cur, n2, 1 + int(rng.integers(0, nDist)), int(rng.integers(0, 4)), float(np.float32(rng.uniform(0.1, 1.5)))))
+            arcs.append((n2, n2, 1 + int(rng.integers(0, nDist)), 0, float(np.float32(rng.uniform(0.1, 1.5)))))        # self loop
+            arcs.append((n2, hub, 1 + int(rng.integers(0, nDist)), 0, float(np.float32(rng.uniform(0.1, 1.5)))))       # back to the hub
+    fin = [(hub, 0.0)]
+    go, gd = _graphs(dsr, oracle, arcs, fin)
+    sc = rng.uniform(0, 3, (1, 40, nDist)).astype(np.float32)
+    ro = go.decode(sc[0], beam=1e9, lmScale=3.0, lmPenalty=0.7, dump=True)
+    assert ro["rc"] == 0
+    for env in (None, "1"):
+        if env:
+            os.environ["DSR_VITERBI_NOFAST"] = env
+        try:
+            dec = dsr.Decoder(beam=1e9, lmScale=3.0, lmPenalty=0.7, maxActive=8192, streams=1); dec.set(gd); dec.enable_dump(True)
+        finally:
+            os.environ.pop("DSR_VITERBI_NOFAST", None)
+        out = dec.decode_batch(torch.from_numpy(sc).to(cuda))
+        _check_decode(ro, out[0])
+        d = dec.get_dump()
+        assert np.array_equal(d["node"], ro["dumpNode"]) and np.array_equal(d["arc"], ro["dumpArc"])
+        assert np.array_equal(d["lm"].view(np.uint32), ro["dumpLm"].view(np.uint32))
+        assert (out[0]["registerFrames"] > 0) == (env is None)
 
 
 def test_viterbi_errors(dsr, oracle, cuda):

@@ -1,0 +1,10 @@
+#!/bin/bash
+# usage: tools/build_variants.sh name1 "-DFLAGS" name2 "-DFLAGS" ...   -> distantspeechrecognition-mirror_amd/lib/var/<name>/libdsr_hip.so
+cd /root/repo/distantspeechrecognition-mirror_amd
+OTHERS=$(ls lib/*.o | grep -v k_viterbi.o)
+while [ $# -gt 1 ]; do
+  n=$1; fl=$2; shift 2; mkdir -p lib/var/$n
+  ( /opt/rocm/bin/hipcc -O3 -fPIC -std=c++17 --offload-arch=gfx950 -Wno-unused-function -Wno-unused-result -I../include -ffp-contract=off $fl -Rpass-analysis=kernel-resource-usage -c csrc/k_viterbi.hip -o lib/var/$n/k_viterbi.o 2>&1 | grep -A12 "Function Name: _ZN3dsr9k_viterbi" | grep -E "VGPRs Spill|ScratchSize" | tr '\n' ' '; echo " <- $n";
+    /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o lib/var/$n/libdsr_hip.so lib/var/$n/k_viterbi.o $OTHERS -Wl,-rpath,/opt/rocm/lib ) &
+done
+wait
