@@ -134,6 +134,7 @@ __global__ __launch_bounds__(kThreads) void k_viterbi(GraphDev G, DecDev Dd, con
   __shared__ double s_waveMin[kWaves];
   __shared__ unsigned long long s_waveKey[kWaves];
   __shared__ int s_sideN;
+  __shared__ int s_tb[2];            // traceback: hops, words
   __shared__ unsigned s_bm[kFastC / 32];             // register path: slots where an expanding token's run starts
   __shared__ unsigned short s_gbase[kFastC / 64 + 4]; // register path: expanding tokens that start before each group of 64 slots
   __shared__ int s_cnt[(kFastK + 32) * kWaves];
@@ -144,7 +145,7 @@ __global__ __launch_bounds__(kThreads) void k_viterbi(GraphDev G, DecDev Dd, con
   const int nthr = blockDim.x, nw = nthr >> 6;      // 256 or 512 threads
   __shared__ int s_u;
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x;
   const int slot = blockIdx.x;
   TokA* tokA0 = Dd.tokA + (size_t) slot * 2 * Dd.maxTok; TokA* tokA1 = tokA0 + Dd.maxTok;
   TokB* tokB0 = Dd.tokB + (size_t) slot * 2 * Dd.maxTok; TokB* tokB1 = tokB0 + Dd.maxTok;
@@ -429,32 +430,42 @@ __global__ __launch_bounds__(kThreads) void k_viterbi(GraphDev G, DecDev Dd, con
             }
           };
           // (a first arrival that has been folded carries neither bucket nor pass bit any more: ek = token index, or bit31 | side index)
-          auto fold1 = [&](const int k, const int pass, float& ac, float& lm, int& rec, unsigned& ekk) __attribute__((always_inline)) {
+          // The replay of a state with two or more later arrivals: next replacement = smallest later slot that beats the incumbent,
+          // until none does.  Returns the winning side record or -1.
+          auto fold_multi = [&](const int wslot0, const unsigned head, const float ac, const float lm) __attribute__((always_inline)) -> int {
+            int wslot = wslot0, wIdx = -1; double fw = (double) __fadd_rn(ac, lm);
+            for (;;) {
+              int best = 0x7FFFFFFF, bi = -1, steps = 0;
+              for (unsigned p = head; (p & 0x80000000u) && steps <= C; steps++) {
+                const int pi = (int) (p & 0x7FFFFFFFu);
+                int pc; double pt; unsigned pn;
+                if (pi < sideLds) { pc = sideL[pi].c; pt = sideL[pi].ttl; pn = sideL[pi].next; } else { pc = side[pi].c; pt = side[pi].ttl; pn = side[pi].next; }
+                if (pc > wslot && pc < best && pt < fw) { best = pc; bi = pi; }
+                p = pn;
+              }
+              if (bi < 0) break;
+              wslot = best; wIdx = bi;
+              fw = (bi < sideLds) ? (double) __fadd_rn(sideL[bi].ac, sideL[bi].lm) : (double) __fadd_rn(side[bi].ac, side[bi].lm);
+            }
+            return wIdx;
+          };
+          // One placement's fold.  defer == nullptr: everything in place.  Otherwise a chain of two or more later arrivals is left for
+          // the deferred round (its head goes to *defer): there the lanes of a wave replay their chains side by side instead of one
+          // placement slot after the other with a single lane at work.
+          auto fold1 = [&](const int k, const int pass, float& ac, float& lm, int& rec, unsigned& ekk, unsigned* defer) __attribute__((always_inline)) {
             const bool mine = ((firstMask >> k) & 1ull) && !(ekk & 0x80000000u) && (ekk & (1u << 28)) && (int) ((ekk >> 27) & 1u) == pass;
             if (mine) {
               const unsigned head = hkey[(ekk >> 13) & 0x3FFFu];
               ekk &= 0x1FFFu;
               if (head & 0x80000000u) {
-                int wslot = k * nthr + tq, wIdx = -1; double fw = (double) __fadd_rn(ac, lm);
+                int wIdx = -1;
                 const int hi = (int) (head & 0x7FFFFFFFu);
-                const unsigned hnext = (hi < sideLds) ? sideL[hi].next : side[hi].next;
+                unsigned hnext; double pt;
+                if (hi < sideLds) { hnext = sideL[hi].next; pt = sideL[hi].ttl; } else { hnext = side[hi].next; pt = side[hi].ttl; }
                 if (!(hnext & 0x80000000u)) {                                  // one later arrival (the usual case): a single comparison
-                  const double pt = (hi < sideLds) ? sideL[hi].ttl : side[hi].ttl;
-                  if (pt < fw) wIdx = hi;
-                } else
-                for (;;) {                                                     // next replacement = smallest later slot that beats the incumbent
-                  int best = 0x7FFFFFFF, bi = -1, steps = 0;
-                  for (unsigned p = head; (p & 0x80000000u) && steps <= C; steps++) {
-                    const int pi = (int) (p & 0x7FFFFFFFu);
-                    int pc; double pt; unsigned pn;
-                    if (pi < sideLds) { pc = sideL[pi].c; pt = sideL[pi].ttl; pn = sideL[pi].next; } else { pc = side[pi].c; pt = side[pi].ttl; pn = side[pi].next; }
-                    if (pc > wslot && pc < best && pt < fw) { best = pc; bi = pi; }
-                    p = pn;
-                  }
-                  if (bi < 0) break;
-                  wslot = best; wIdx = bi;
-                  fw = (bi < sideLds) ? (double) __fadd_rn(sideL[bi].ac, sideL[bi].lm) : (double) __fadd_rn(side[bi].ac, side[bi].lm);
-                }
+                  if (pt < (double) __fadd_rn(ac, lm)) wIdx = hi;
+                } else if (defer) *defer = head;
+                else wIdx = fold_multi(k * nthr + tq, head, ac, lm);
                 if (wIdx >= 0) {
                   if (wIdx < sideLds) { ac = sideL[wIdx].ac; lm = sideL[wIdx].lm; rec = sideL[wIdx].rec; }
                   else { ac = side[wIdx].ac; lm = side[wIdx].lm; rec = side[wIdx].rec; }
@@ -493,12 +504,31 @@ __global__ __launch_bounds__(kThreads) void k_viterbi(GraphDev G, DecDev Dd, con
             for (int kb = kFastK; kb < K; kb += kB) { float oac[kB], olm[kB]; int orec[kB]; unsigned oek[kB]; park_load(kb, oac, olm, orec, oek); later8(kb, pass, oac, olm, orec, oek); }
             __syncthreads();
             if (pass == 0) TICK(5);
+            {
+              unsigned pend = 0u, dh[kFastK];
 #pragma unroll
-            for (int k = 0; k < kFastK; k++) if (k < K) fold1(k, pass, qac[k], qlm[k], qrec[k], ek[k]);
+              for (int k = 0; k < kFastK; k++) { dh[k] = 0u; if (k < K) { fold1(k, pass, qac[k], qlm[k], qrec[k], ek[k], &dh[k]); if (dh[k]) pend |= 1u << k; } }
+              while (__any(pend != 0u)) {                                     // deferred round(s): one chain per lane at a time
+                if (pend) {
+                  const int k = __ffs((int) pend) - 1; pend &= pend - 1u;
+                  unsigned head = dh[0]; float ac = qac[0], lm = qlm[0];
+#pragma unroll
+                  for (int j = 1; j < kFastK; j++) { const bool is = (k == j); head = is ? dh[j] : head; ac = is ? qac[j] : ac; lm = is ? qlm[j] : lm; }
+                  const int wIdx = fold_multi(k * nthr + tq, head, ac, lm);
+                  if (wIdx >= 0) {
+                    float wac, wlm; int wrec;
+                    if (wIdx < sideLds) { wac = sideL[wIdx].ac; wlm = sideL[wIdx].lm; wrec = sideL[wIdx].rec; }
+                    else { wac = side[wIdx].ac; wlm = side[wIdx].lm; wrec = side[wIdx].rec; }
+#pragma unroll
+                    for (int j = 0; j < kFastK; j++) if (k == j) { qac[j] = wac; qlm[j] = wlm; qrec[j] = wrec; ek[j] = 0x80000000u | (unsigned) wIdx; }
+                  }
+                }
+              }
+            }
             for (int kb = kFastK; kb < K; kb += kB) {
               float oac[kB], olm[kB]; int orec[kB]; unsigned oek[kB]; park_load(kb, oac, olm, orec, oek);
 #pragma unroll
-              for (int i = 0; i < kB; i++) if (kb + i < K) fold1(kb + i, pass, oac[i], olm[i], orec[i], oek[i]);
+              for (int i = 0; i < kB; i++) if (kb + i < K) fold1(kb + i, pass, oac[i], olm[i], orec[i], oek[i], nullptr);
               park_store(kb, oac, olm, orec, oek);
             }
           }
@@ -814,41 +844,69 @@ __global__ __launch_bounds__(kThreads) void k_viterbi(GraphDev G, DecDev Dd, con
         key = wave_min_u64(key);
         if (lane == 0) s_waveKey[wave] = key;
         __syncthreads();
+        // traceback (bestHypo, decoder.h:748-773).  One thread follows the back pointers (one dependent 8-byte load per frame) and
+        // leaves the hop records in scratch memory; everything else -- arcs per hop, their places in the list, the word sequence --
+        // is done by the whole workgroup with two prefix sums.
+        int* hopRec = reinterpret_cast<int*>(cB); const int hopCap = 2 * Dd.maxCand; int* hopOff = hopRec + hopCap;
+        dsr_decode_result r; memset(&r, 0, sizeof(r));
         if (tid == 0) {
           unsigned long long k = ~0ull; for (int w = 0; w < nw; w++) if (s_waveKey[w] < k) k = s_waveKey[w];
-          dsr_decode_result r; memset(&r, 0, sizeof(r));
           r.frames = T - 1; r.reachedFinal = numNew > 0 ? 1 : 0; r.activeHypos = activeHypos; r.placements = placements; r.registerFrames = regFrames; r.maxActiveSeen = maxActive; r.status = DSR_OK;
+          int nH = 0;
           if (k != ~0ull) {
             const TokA bt = lst[(unsigned) (k & 0xFFFFFFFFu)];
             r.ac = bt.ac; r.lm = bt.lm; r.score = __dadd_rn((double) bt.ac, (double) bt.lm);
-            // traceback (bestHypo, decoder.h:748-773): count, then fill first..last
-            int nA = 0;
-            for (uint32_t b = bt.bp; b != kNone; b = arena[b].prev) {
-              const uint32_t rc = arena[b].rec;
-              nA += (rc & kEndBit) ? G.erec[rc & ~kEndBit].pathLen : (int) (G.xrec[rc].meta & 0xFFFFu) + 1;
-            }
-            r.nArcs = nA;
-            int pos = nA; int nW = 0;
-            int* ao = arcsOut ? arcsOut + (size_t) u * maxPath : nullptr;
-            for (uint32_t b = bt.bp; b != kNone; b = arena[b].prev) {
-              const uint32_t rc = arena[b].rec;
-              if (rc & kEndBit) {
-                const ERec e = G.erec[rc & ~kEndBit];
-                for (int h = e.pathLen - 1; h >= 0; h--) { const int a = G.path[e.pathOff + h]; pos--; if (ao && pos < maxPath) ao[pos] = a; if (G.arcOut[a] != 0) nW++; }
-              } else {
-                const int a = G.xarc[rc]; pos--; if (ao && pos < maxPath) ao[pos] = a; if (G.arcOut[a] != 0) nW++;
-                const int pl = (int) (G.xrec[rc].meta & 0xFFFFu); const int po = G.xpathOff[rc];
-                for (int h = pl - 1; h >= 0; h--) { const int a2 = G.path[po + h]; pos--; if (ao && pos < maxPath) ao[pos] = a2; if (G.arcOut[a2] != 0) nW++; }
-              }
-            }
-            r.nWords = nW;
-            if (wordsOut && ao) {          // second walk over the arc list, in order
-              unsigned* wo = wordsOut + (size_t) u * maxPath; int q = 0;
-              const int lim = nA < maxPath ? nA : maxPath;
-              for (int i = 0; i < lim; i++) { const unsigned o = G.arcOut[ao[i]]; if (o != 0 && q < maxPath) wo[q++] = o; }
-            }
-            if (nA > maxPath && arcsOut) r.status = DSR_E_DIMENSION;
+            for (uint32_t bq = bt.bp; bq != kNone && nH < hopCap; ) { const uint2 e = *reinterpret_cast<const uint2*>(&arena[bq]); hopRec[nH++] = (int) e.y; bq = e.x; }
           } else r.status = DSR_E_CONSISTENCY;
+          s_tb[0] = nH; s_tb[1] = 0;
+        }
+        __syncthreads();
+        const int nH = s_tb[0];
+        auto block_excl = [&](const int v, int& total) -> int {
+          const int incl = wave_incl_scan(v, lane);
+          if (lane == 63) s_waveTot[wave] = incl;
+          __syncthreads();
+          int base = 0, tot = 0;
+          for (int w = 0; w < nw; w++) { const int q = s_waveTot[w]; if (w < wave) base += q; tot += q; }
+          __syncthreads();
+          total = tot; return base + incl - v;
+        };
+        int nA = 0;
+        for (int b0 = 0; b0 < nH; b0 += nthr) {                                  // arcs per hop; hopOff = arcs of the hops walked before (= later in time)
+          const int i = b0 + tid; int len = 0;
+          if (i < nH) { const uint32_t rc = (uint32_t) hopRec[i]; len = (rc & kEndBit) ? G.erec[rc & ~kEndBit].pathLen : (int) (G.xrec[rc].meta & 0xFFFFu) + 1; }
+          int total; const int ex = block_excl(len, total);
+          if (i < nH) hopOff[i] = nA + ex;
+          nA += total;
+        }
+        int* ao = arcsOut ? arcsOut + (size_t) u * maxPath : nullptr;
+        int nWloc = 0;
+        for (int i = tid; i < nH; i += nthr) {                                   // every hop writes its arcs, first..last
+          const uint32_t rc = (uint32_t) hopRec[i]; int pos = nA - hopOff[i];
+          if (rc & kEndBit) {
+            const ERec e = G.erec[rc & ~kEndBit];
+            for (int h = e.pathLen - 1; h >= 0; h--) { const int a = G.path[e.pathOff + h]; pos--; if (ao && pos < maxPath) ao[pos] = a; if (G.arcOut[a] != 0) nWloc++; }
+          } else {
+            const int a = G.xarc[rc]; pos--; if (ao && pos < maxPath) ao[pos] = a; if (G.arcOut[a] != 0) nWloc++;
+            const int pl = (int) (G.xrec[rc].meta & 0xFFFFu); const int po = G.xpathOff[rc];
+            for (int h = pl - 1; h >= 0; h--) { const int a2 = G.path[po + h]; pos--; if (ao && pos < maxPath) ao[pos] = a2; if (G.arcOut[a2] != 0) nWloc++; }
+          }
+        }
+        if (nWloc) atomicAdd(&s_tb[1], nWloc);
+        __syncthreads();
+        if (wordsOut && ao) {                                                    // the words of the arc list, in order
+          unsigned* wo = wordsOut + (size_t) u * maxPath; int q = 0;
+          const int lim = nA < maxPath ? nA : maxPath;
+          for (int b0 = 0; b0 < lim; b0 += nthr) {
+            const int i = b0 + tid; unsigned o = 0u;
+            if (i < lim) o = G.arcOut[ao[i]];
+            int total; const int ex = block_excl(o != 0u ? 1 : 0, total);
+            if (o != 0u && q + ex < maxPath) wo[q + ex] = o;
+            q += total;
+          }
+        }
+        if (tid == 0) {
+          if (r.status == DSR_OK) { r.nArcs = nA; r.nWords = s_tb[1]; if (nH >= hopCap) r.status = DSR_E_ALLOCATION; else if (nA > maxPath && arcsOut) r.status = DSR_E_DIMENSION; }
           res[u] = r;
         }
         __syncthreads();
