@@ -52,7 +52,7 @@ static constexpr int kB = 2;                        // placements whose loads ar
 static constexpr int kFastC = 24576;               // most placements per frame on the register path (those beyond kFastK per thread are parked in memory)
 static constexpr int kFastE = 8190;                // most expanding tokens per frame on the register path
 static constexpr int kP1 = 16;                     // token rounds per wave in the register path's beam pass
-static constexpr int kW = 8;                        // register placements whose P6 loads are in flight together (parked ones: kB)
+static constexpr int kW = 4;                        // register placements whose P6 loads are in flight together (8: 3 % slower; parked ones: kB)
 static constexpr int kSideLds = 528;               // later arrivals kept in LDS (the region also holds the slot offsets, dead by then)               // most placements / expanding tokens per frame on the register path
 
 struct GraphDev {
