@@ -9,6 +9,7 @@
 // so that a wave's accesses to one entry are contiguous.  Arithmetic is fp64 in the reference's order (this file is
 // compiled with -ffp-contract=off); the snapshots and the beamformer output are the pipe's complex64 arrays.
 #include "common.h"
+#include <complex>
 #include <cmath>
 
 namespace dsr {
@@ -73,8 +74,10 @@ __device__ __forceinline__ double2 cdiv_gsl(double ar, double ai, double br, dou
 __global__ __launch_bounds__(128) void k_mccowan(const float2* __restrict__ X, const float2* __restrict__ Y, const int* __restrict__ nframesArr,
                                                  const double2* __restrict__ wq, const double2* __restrict__ R, double2* __restrict__ state,
                                                  float2* __restrict__ out, float* __restrict__ wp1, int U, int C, int Tmax, int F, double alphaCfg, int type,
-                                                 int minFrames, double thr)
+                                                 int minFrames, double thr, const double2* __restrict__ lambda, int fbinX1)
 {
+  // lambda != nullptr: LefkimmiatisPostFilter (postfilter.cc:1065-1176) -- McCowan's clean-signal estimate against the noise estimate
+  // sum (0.5 (phi_ii + phi_jj) - phi_ij) / (1 - R_ij), divided by d^H pinv(R) d from bin fbinX1 on
   const long n = (long) blockIdx.x * blockDim.x + threadIdx.x;
   if (n >= (long) U * F) return;
   const int u = (int) (n / F), f = (int) (n - (long) u * F);
@@ -125,6 +128,20 @@ __global__ __launch_bounds__(128) void k_mccowan(const float2* __restrict__ X, c
     const double avg = (1 & type) ? sr : hypot(sr, si);
     const double nu = 2.0 * avg / (double) (C * (C - 1));
     double W = nu / de;
+    if (lambda) {
+      double vr = 0.0, vi = 0.0; e = 0;
+      for (int i = 0; i < C - 1; i++)
+        for (int j = i + 1; j < C; j++, e++) {
+          const double2 phi = state[(long) e * S + n];
+          double2 r = Rf[i * C + j];
+          if (r.x > thr) r = make_double2(thr, 0.0); else if (r.x == 1.0) r = make_double2(0.99, 0.0);
+          const double2 q = cdiv_gsl((psd[i] + psd[j]) * 0.5 - phi.x, 0.0 - phi.y, -r.x + 1.0, -r.y);
+          vr += q.x; vi += q.y;
+        }
+      const double phi_vv = 2.0 * ((1 & type) ? vr : hypot(vr, vi)) / (double) (C * (C - 1));
+      if (f < fbinX1) W = nu / (nu + phi_vv);
+      else { const double2 l = lambda[f]; W = nu / (nu + phi_vv / ((1 & type) ? l.x : hypot(l.x, l.y))); }
+    }
     if (W > 1.0) W = 1.0;
     if (W < 0.0001) W = 0.0001;
     if (wp1) wp1[((long) u * Tmax + t) * F + f] = (float) W;
@@ -203,12 +220,57 @@ __global__ __launch_bounds__(64) void k_zelinski_reg(const float2* __restrict__ 
 }
 
 struct ZelinskiPlan { int M = 0, C = 0, type = 2, minFrames = 0; double alpha = 0.6; std::vector<double> h_wq; bool dirty = true; DevBuf<double2> wq, state;
-                      int kind = 0; double threshold = 0.99; std::vector<double> h_R; bool haveR = false, dirtyR = true; DevBuf<double2> R; };   // kind 1: McCowan
+                      int kind = 0; double threshold = 0.99; std::vector<double> h_R; bool haveR = false, dirtyR = true; DevBuf<double2> R;       // kind 1: McCowan
+                      double minSV = 1e-8; int fbinX1 = 0; bool dirtyL = true; DevBuf<double2> lambda; };                                               // kind 2: Lefkimmiatis
 
 }  // namespace dsr
 
 using namespace dsr;
 struct dsr_zelinski : ZelinskiPlan {};
+
+
+// d^H pinv(R) d with the Moore-Penrose pseudo-inverse through a one-sided Jacobi SVD in double precision (columns of A V are
+// orthogonalised by complex plane rotations; singular values = column norms), singular values below minSV dropped as in the
+// reference's pseudoinverse (beamformer.cc:253-300; there: LINPACK csvdc in single precision).
+static double2 lefkimmiatis_lambda(const double* Rf, const double* df, int C, double minSV)
+{
+  typedef std::complex<double> cd;
+  std::vector<cd> A((size_t) C * C), V((size_t) C * C, cd(0.0, 0.0));      // column major: A[i + j*C]
+  for (int i = 0; i < C; i++) { V[i + (size_t) i * C] = 1.0; for (int j = 0; j < C; j++) A[i + (size_t) j * C] = cd(Rf[2 * (i * C + j)], Rf[2 * (i * C + j) + 1]); }
+  for (int sweep = 0; sweep < 60; sweep++) {
+    double off = 0.0;
+    for (int p = 0; p < C - 1; p++)
+      for (int q = p + 1; q < C; q++) {
+        double al = 0.0, be = 0.0; cd g(0.0, 0.0);
+        for (int i = 0; i < C; i++) { al += std::norm(A[i + (size_t) p * C]); be += std::norm(A[i + (size_t) q * C]); g += std::conj(A[i + (size_t) p * C]) * A[i + (size_t) q * C]; }
+        const double ag = std::abs(g);
+        if (ag <= 1e-300 || ag <= 1e-15 * std::sqrt(al * be)) continue;
+        off += ag;
+        const cd ph = g / ag;                                                  // a_q e^{-i phi}: the inner product becomes real
+        const double zeta = (be - al) / (2.0 * ag);
+        const double t = (zeta >= 0.0 ? 1.0 : -1.0) / (std::fabs(zeta) + std::sqrt(1.0 + zeta * zeta));
+        const double c = 1.0 / std::sqrt(1.0 + t * t), sn = c * t;
+        for (int i = 0; i < C; i++) {
+          const cd ap = A[i + (size_t) p * C], aq = A[i + (size_t) q * C] * std::conj(ph);
+          A[i + (size_t) p * C] = c * ap - sn * aq; A[i + (size_t) q * C] = sn * ap + c * aq;
+          const cd vp = V[i + (size_t) p * C], vq = V[i + (size_t) q * C] * std::conj(ph);
+          V[i + (size_t) p * C] = c * vp - sn * vq; V[i + (size_t) q * C] = sn * vp + c * vq;
+        }
+      }
+    if (off == 0.0) break;
+  }
+  // pinv = V diag(1/s) U^H with U_k = A_k / s_k  =>  pinv = sum_k V_k A_k^H / s_k^2 ;  Lambda = (pinv^H d)^H d = d^H pinv d
+  cd lam(0.0, 0.0);
+  for (int k = 0; k < C; k++) {
+    double s2 = 0.0; for (int i = 0; i < C; i++) s2 += std::norm(A[i + (size_t) k * C]);
+    const double sv = std::sqrt(s2);
+    if (sv < minSV || sv == 0.0) continue;
+    cd dv(0.0, 0.0), ad(0.0, 0.0);                                             // d^H V_k  and  A_k^H d
+    for (int i = 0; i < C; i++) { const cd d(df[2 * i], df[2 * i + 1]); dv += std::conj(d) * V[i + (size_t) k * C]; ad += std::conj(A[i + (size_t) k * C]) * d; }
+    lam += dv * ad / s2;
+  }
+  return make_double2(lam.real(), lam.imag());
+}
 
 extern "C" {
 
@@ -235,10 +297,19 @@ dsr_status dsr_mccowan_create(int fftLen, int chanN, double alpha, int type, int
   (*out)->kind = 1; (*out)->threshold = (double) threshold; (*out)->h_R.assign((size_t) (fftLen / 2 + 1) * chanN * chanN * 2, 0.0);
   return DSR_OK;
 }
+// LefkimmiatisPostFilter (postfilter.h:180-202, postfilter.cc:948-1210): a McCowan object with minSV / fbinX1; the per-bin
+// d^H pinv(R) d is recomputed on the host whenever the coherence matrices or the manifold change
+dsr_status dsr_lefkimmiatis_create(int fftLen, int chanN, double minSV, int fbinX1, double alpha, int type, int minFrames, float threshold, dsr_zelinski** out)
+{
+  const dsr_status s0 = dsr_mccowan_create(fftLen, chanN, alpha, type, minFrames, threshold, out);
+  if (s0 != DSR_OK) return s0;
+  (*out)->kind = 2; (*out)->minSV = minSV; (*out)->fbinX1 = fbinX1 < 0 ? 0 : fbinX1;
+  return DSR_OK;
+}
 dsr_status dsr_mccowan_set_noise_matrix(dsr_zelinski* p, int fbinX, const double* Rnn)
 {
   return guard([&] {
-    if (!p || !Rnn || p->kind != 1) throw Error(DSR_E_PARAMETER, "not a McCowan post-filter");
+    if (!p || !Rnn || p->kind < 1) throw Error(DSR_E_PARAMETER, "not a McCowan post-filter");
     if (fbinX < 0 || fbinX > p->M / 2) throw Error(DSR_E_DIMENSION, "fbinX %d out of range", fbinX);
     memcpy(&p->h_R[(size_t) fbinX * p->C * p->C * 2], Rnn, sizeof(double) * 2 * p->C * p->C); p->haveR = true; p->dirtyR = true;
   });
@@ -246,7 +317,7 @@ dsr_status dsr_mccowan_set_noise_matrix(dsr_zelinski* p, int fbinX, const double
 dsr_status dsr_mccowan_set_diffuse_noise_model(dsr_zelinski* p, const double* micPos, double sampleRate, double sspeed)
 {
   return guard([&] {                                            // postfilter.cc:568-626
-    if (!p || !micPos || p->kind != 1) throw Error(DSR_E_PARAMETER, "not a McCowan post-filter");
+    if (!p || !micPos || p->kind < 1) throw Error(DSR_E_PARAMETER, "not a McCowan post-filter");
     const int C = p->C, F = p->M / 2 + 1;
     for (int f = 0; f < F; f++) {
       const double omega_d_c = 2.0 * sampleRate * f / (p->M * sspeed);
@@ -266,7 +337,7 @@ dsr_status dsr_mccowan_set_diffuse_noise_model(dsr_zelinski* p, const double* mi
 dsr_status dsr_mccowan_diagonal_loading(dsr_zelinski* p, int fbinX, float diagonalWeight)
 {
   return guard([&] {                                            // setAllLevelsOfDiagonalLoading (fbinX < 0) / setLevelOfDiagonalLoading, :628-657
-    if (!p || p->kind != 1) throw Error(DSR_E_PARAMETER, "not a McCowan post-filter");
+    if (!p || p->kind < 1) throw Error(DSR_E_PARAMETER, "not a McCowan post-filter");
     if (!p->haveR) throw Error(DSR_E_ERROR, "Construct/set first a noise coherence matrix");
     const int C = p->C, F = p->M / 2 + 1;
     for (int f = (fbinX < 0 ? 0 : fbinX); f < (fbinX < 0 ? F : fbinX + 1); f++) for (int c = 0; c < C; c++) p->h_R[((size_t) f * C * C + c * C + c) * 2] += (double) diagonalWeight;
@@ -276,7 +347,7 @@ dsr_status dsr_mccowan_diagonal_loading(dsr_zelinski* p, int fbinX, float diagon
 dsr_status dsr_mccowan_divide_nondiagonal(dsr_zelinski* p, float myu)
 {
   return guard([&] {                                            // divideAllNonDiagonalElements, :664-682 (gsl_complex_div by (1 + myu, 0))
-    if (!p || p->kind != 1) throw Error(DSR_E_PARAMETER, "not a McCowan post-filter");
+    if (!p || p->kind < 1) throw Error(DSR_E_PARAMETER, "not a McCowan post-filter");
     const int C = p->C, F = p->M / 2 + 1; const double br = 1.0 + (double) myu;
     for (int f = 0; f < F; f++) for (int a = 0; a < C; a++) for (int b = 0; b < C; b++) if (a != b) {
       double* z = &p->h_R[((size_t) f * C * C + a * C + b) * 2];
@@ -302,14 +373,20 @@ dsr_status dsr_zelinski_apply(dsr_zelinski* p, const float* X, const float* Y, c
     if (U <= 0 || Tmax <= 0) return;
     hipStream_t st = (hipStream_t) stream;
     const int F = p->M / 2 + 1;
-    if (p->dirty) { std::vector<double2> w((size_t) F * p->C); for (size_t i = 0; i < w.size(); i++) w[i] = make_double2(p->h_wq[2 * i], p->h_wq[2 * i + 1]); p->wq.upload(w); p->dirty = false; }
+    if (p->dirty) { std::vector<double2> w((size_t) F * p->C); for (size_t i = 0; i < w.size(); i++) w[i] = make_double2(p->h_wq[2 * i], p->h_wq[2 * i + 1]); p->wq.upload(w); p->dirty = false; p->dirtyL = true; }
     const size_t S = (size_t) U * F, NE = (size_t) p->C * (p->C + 1) / 2;
-    if (p->kind == 1) {
+    if (p->kind >= 1) {
       if (!p->haveR) throw Error(DSR_E_ERROR, "McCowanPostFilter: construct/set a noise coherence matrix");             // postfilter.cc:835-838
+      const bool newR = p->dirtyR;
       if (p->dirtyR) { std::vector<double2> r((size_t) F * p->C * p->C); for (size_t i = 0; i < r.size(); i++) r[i] = make_double2(p->h_R[2 * i], p->h_R[2 * i + 1]); p->R.upload(r); p->dirtyR = false; }
+      if (p->kind == 2 && (newR || p->dirtyL)) {                                 // calcInverseNoiseSpatialSpectralMatrix + calcLambda (postfilter.cc:981-1009)
+        std::vector<double2> lam(F);
+        for (int f = 0; f < F; f++) lam[f] = lefkimmiatis_lambda(&p->h_R[(size_t) f * p->C * p->C * 2], &p->h_wq[(size_t) f * p->C * 2], p->C, p->minSV);
+        p->lambda.upload(lam); p->dirtyL = false;
+      }
       p->state.reserve(S * NE);
       hipLaunchKernelGGL(k_mccowan, dim3((unsigned) ((S + 127) / 128)), dim3(128), 0, st, (const float2*) X, (const float2*) Y, nframes_dev, p->wq.p, p->R.p, p->state.p,
-                         (float2*) out, wp1, U, p->C, Tmax, F, p->alpha, p->type, p->minFrames, p->threshold);
+                         (float2*) out, wp1, U, p->C, Tmax, F, p->alpha, p->type, p->minFrames, p->threshold, p->kind == 2 ? p->lambda.p : nullptr, p->fbinX1);
       DSR_HIP(hipGetLastError());
       return;
     }

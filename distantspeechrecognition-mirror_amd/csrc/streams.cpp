@@ -203,9 +203,11 @@ struct WpeOp : dsr_stream {          // SingleChannelWPEDereverberationFeature (
 struct ZelinskiOp : dsr_stream {     // ZelinskiPostFilter (postfilter.cc:350-493): ups[0] = beamformer output, ups[1..] = the snapshot array's channels
   dsr_zelinski* plan = nullptr; int M = 0; double alpha = 0.6; int ptype = 2, minFrames = 0; std::vector<std::vector<double>> manifold; int chanSet = 0;
   int kind = 0; float threshold = 0.99f;                   // kind 1: McCowanPostFilter (the plan then also carries the noise coherence matrices)
+  double minSV = 1e-8; int fbinX1 = 0;                     // kind 2: LefkimmiatisPostFilter
   void ensure_plan(int C) {
     if (plan) return;
-    dsr_status s = kind ? dsr_mccowan_create(M, C, alpha, ptype, minFrames, threshold, &plan) : dsr_zelinski_create(M, C, alpha, ptype, minFrames, &plan);
+    dsr_status s = kind == 2 ? dsr_lefkimmiatis_create(M, C, minSV, fbinX1, alpha, ptype, minFrames, threshold, &plan)
+                 : kind ? dsr_mccowan_create(M, C, alpha, ptype, minFrames, threshold, &plan) : dsr_zelinski_create(M, C, alpha, ptype, minFrames, &plan);
     if (s) throw Error(s, "%s", dsr_last_error());
   }
   DevBuf<float2> X, Y, O; DevBuf<int> nf;
@@ -371,11 +373,19 @@ dsr_status dsr_mccowan_stream_create(dsr_stream* output, int fftLen, double alph
   ZelinskiOp* q = static_cast<ZelinskiOp*>(*out); q->kind = 1; q->threshold = threshold;
   return DSR_OK;
 }
+dsr_status dsr_lefkimmiatis_stream_create(dsr_stream* output, int fftLen, double minSV, int fbinX1, double alpha, int type, int minFrames, float threshold,
+                                          const char* name, dsr_stream** out)
+{
+  const dsr_status s0 = dsr_zelinski_stream_create(output, fftLen, alpha, type, minFrames, (name && *name) ? name : "LefkimmiatisPostFilte", out);
+  if (s0 != DSR_OK) return s0;
+  ZelinskiOp* q = static_cast<ZelinskiOp*>(*out); q->kind = 2; q->threshold = threshold; q->minSV = minSV; q->fbinX1 = fbinX1;
+  return DSR_OK;
+}
 // noise coherence setters of McCowanPostFilter (postfilter.cc:546-682); chanN fixes the array size at the first call
 dsr_status dsr_mccowan_stream_set_noise(dsr_stream* pf, int what, int fbinX, const double* data, int chanN, double a, double b)
 {
   return guard([&] {
-    ZelinskiOp* q = dynamic_cast<ZelinskiOp*>(pf); if (!q || q->kind != 1) throw Error(DSR_E_PARAMETER, "not a McCowan post-filter");
+    ZelinskiOp* q = dynamic_cast<ZelinskiOp*>(pf); if (!q || q->kind < 1) throw Error(DSR_E_PARAMETER, "not a McCowan post-filter");
     q->ensure_plan(chanN); dsr_status s = DSR_OK;
     switch (what) {
     case 0: s = dsr_mccowan_set_noise_matrix(q->plan, fbinX, data); break;

@@ -78,7 +78,7 @@ def load():
         "dsr_stft_analysis": [vp, vp, vp, C.c_int, C.c_int, i64, C.c_int, vp, vp],
         "dsr_wpe_single": [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, f64, f64, f64, vp, vp, vp],
         "dsr_zelinski_create": [C.c_int, C.c_int, f64, C.c_int, C.c_int, vp], "dsr_zelinski_destroy": [vp], "dsr_zelinski_set_manifold": [vp, C.c_int, vp],
-        "dsr_mccowan_create": [C.c_int, C.c_int, f64, C.c_int, C.c_int, f32, vp], "dsr_mccowan_set_noise_matrix": [vp, C.c_int, vp],
+        "dsr_mccowan_create": [C.c_int, C.c_int, f64, C.c_int, C.c_int, f32, vp], "dsr_lefkimmiatis_create": [C.c_int, C.c_int, f64, C.c_int, f64, C.c_int, C.c_int, f32, vp], "dsr_mccowan_set_noise_matrix": [vp, C.c_int, vp],
         "dsr_mccowan_set_diffuse_noise_model": [vp, vp, f64, f64], "dsr_mccowan_diagonal_loading": [vp, C.c_int, f32], "dsr_mccowan_divide_nondiagonal": [vp, f32],
         "dsr_zelinski_apply": [vp, vp, vp, vp, C.c_int, C.c_int, vp, vp, vp],
         "dsr_lpc_create": [C.c_int, C.c_int, C.c_int, f32, C.c_int, C.c_int, vp], "dsr_lpc_destroy": [vp], "dsr_lpc_size": [vp],
@@ -380,6 +380,18 @@ class McCowanPostFilter(ZelinskiPostFilter):
 
     def divideAllNonDiagonalElements(self, myu):
         check(_lib.dsr_mccowan_divide_nondiagonal(self.h, myu))
+
+
+class LefkimmiatisPostFilter(McCowanPostFilter):
+    """Lefkimmiatis post-filter (postfilter.cc:948-1210): McCowan's clean-signal estimate against the coherence-based noise estimate,
+    divided by d^H pinv(R) d from bin fbinX1 on."""
+
+    def __init__(self, fftLen, chanN, manifold, minSV=1e-8, fbinX1=0, alpha=0.6, type=2, minFrames=0, threshold=0.99):
+        L = load(); self.h = vp(); self.M, self.C = fftLen, chanN
+        check(L.dsr_lefkimmiatis_create(fftLen, chanN, minSV, fbinX1, alpha, type, minFrames, threshold, C.byref(self.h)))
+        m = np.ascontiguousarray(manifold, np.complex128)
+        for f in range(fftLen // 2 + 1):
+            check(L.dsr_zelinski_set_manifold(self.h, f, _ptr(m[f])))
 
 
 class LpcEnvelope:

@@ -61,3 +61,16 @@ class McCowanPostFilterPtr(ZelinskiPostFilterPtr):
 
     def divideAllNonDiagonalElements(self, myu):
         self._noise(3, 0, None, self._C or 0, myu)
+
+
+class LefkimmiatisPostFilterPtr(McCowanPostFilterPtr):
+    """postfilter.i (LefkimmiatisPostFilter, postfilter.h:180-204, postfilter.cc:948-1210); calcInverseNoiseSpatialSpectralMatrix() is
+    implied: the inverse is refreshed whenever the coherence matrices or the manifold change."""
+
+    def __init__(self, output, fftLen, minSV=1.0E-8, fbinX1=0, alpha=0.6, type=2, minFrames=0, threshold=0.99, nm="LefkimmiatisPostFilte"):
+        h, _ = _new(lib().dsr_lefkimmiatis_stream_create, output._h, int(fftLen), float(minSV), int(fbinX1), float(alpha), int(type), int(minFrames),
+                    float(threshold), nm.encode())
+        FeatureStreamPtr.__init__(self, h, keep=(output,)); self._M = fftLen; self._type = type; self._chans = []; self._C = None
+
+    def calcInverseNoiseSpatialSpectralMatrix(self):
+        return None

@@ -308,6 +308,10 @@ dsr_status dsr_mccowan_set_noise_matrix(dsr_zelinski*, int fbinX, const double* 
 dsr_status dsr_mccowan_set_diffuse_noise_model(dsr_zelinski*, const double* micPos /* [C][3] */, double sampleRate, double sspeed);
 dsr_status dsr_mccowan_diagonal_loading(dsr_zelinski*, int fbinX /* < 0: all bins */, float diagonalWeight);
 dsr_status dsr_mccowan_divide_nondiagonal(dsr_zelinski*, float myu);
+/* LefkimmiatisPostFilter(output, fftLen, minSV, fbinX1, alpha, type, minFrames, threshold) (postfilter.h:180-202, postfilter.cc:948-1210):
+ * the McCowan handle and setters; the pseudo-inverse of every bin's coherence matrix (singular values < minSV dropped) and
+ * d^H pinv(R) d are computed inside apply when the matrices or the manifold have changed */
+dsr_status dsr_lefkimmiatis_create(int fftLen, int chanN, double minSV, int fbinX1, double alpha, int type, int minFrames, float threshold, dsr_zelinski** out);
 dsr_status dsr_zelinski_apply(dsr_zelinski*, const float* X_dev, const float* Y_dev, const int32_t* nframes_dev, int U, int Tmax,
                               float* out_dev, float* wp1_dev, void* stream);
 
@@ -375,6 +379,9 @@ dsr_status dsr_zelinski_stream_set_channel(dsr_stream* pf, dsr_stream* chan);
    a = sampleRate, b = sspeed), 2 set(All)Level(s)OfDiagonalLoading(fbinX or -1, a), 3 divideAllNonDiagonalElements(a) */
 dsr_status dsr_mccowan_stream_create(dsr_stream* output, int fftLen, double alpha, int type, int minFrames, float threshold, const char* name, dsr_stream** out);
 dsr_status dsr_mccowan_stream_set_noise(dsr_stream* pf, int what, int fbinX, const double* data, int chanN, double a, double b);
+/* LefkimmiatisPostFilter (postfilter.i, postfilter.h:180-204) on the same operator and setters */
+dsr_status dsr_lefkimmiatis_stream_create(dsr_stream* output, int fftLen, double minSV, int fbinX1, double alpha, int type, int minFrames, float threshold,
+                                          const char* name, dsr_stream** out);
 dsr_status dsr_zelinski_stream_set_manifold(dsr_stream* pf, int fbinX, const double* vec, int chanN);
 /* SingleChannelWPEDereverberationFeature(samples, lowerN, upperN, iterationsN, loadDb, bandWidth, sampleRate) (dereverberation.i:67-81) */
 dsr_status dsr_wpe_single_stream_create(dsr_stream* samples, int lowerN, int upperN, int iterationsN, double loadDb, double bandWidth,

@@ -276,6 +276,36 @@ def mccowan_postfilter(X, Y, wq, R, alpha=0.6, type=2, minFrames=0, threshold=0.
     return out, wp1
 
 
+def lefkimmiatis_lambda(R, d, minSV=1e-8):
+    """d^H pinv(R_f) d per bin (LefkimmiatisPostFilter::calcInverseNoiseSpatialSpectralMatrix + calcLambda, postfilter.cc:981-1009).
+    The reference's pseudoinverse (beamformer.cc:253-300) runs LINPACK csvdc in SINGLE precision and drops singular values below
+    minSV (absolute); this restatement uses numpy's SVD in double precision with the same rule, so for well-conditioned R the two agree
+    to single precision, and for rank-deficient R (where the reference's result is governed by float round-off in the singular values
+    that should be zero) parity is unpinned.  R [F][C][C], d [F][C] -> [F] complex128."""
+    R = np.asarray(R, np.complex128); d = np.asarray(d, np.complex128)
+    lam = np.zeros(R.shape[0], np.complex128)
+    for f in range(R.shape[0]):
+        U, sv, Vh = np.linalg.svd(R[f])
+        inv = np.where(sv < minSV, 0.0, 1.0 / np.where(sv == 0, 1.0, sv))
+        pinv = (Vh.conj().T * inv) @ U.conj().T
+        lam[f] = np.vdot(pinv.conj().T @ d[f], d[f])           # tmpH = invR^H d; Lambda = tmpH^H d
+    return lam
+
+
+def lefkimmiatis_postfilter(X, Y, wq, R, lam, alpha=0.6, type=2, minFrames=0, threshold=0.99, fbinX1=0):
+    """LefkimmiatisPostFilter (postfilter.cc:948-1210): X [C][T][F], Y [T][F], wq [F][C] (array manifold), R [F][C][C], lam [F] -> (out, wp1)."""
+    X = np.ascontiguousarray(X, np.complex128); Y = np.ascontiguousarray(Y, np.complex128); wq = np.ascontiguousarray(wq, np.complex128)
+    R = np.ascontiguousarray(R, np.complex128); lam = np.ascontiguousarray(lam, np.complex128)
+    Cn, T, F = X.shape
+    out = np.zeros((T, F), np.complex128); wp1 = np.zeros((T, F), np.float64)
+    L = lib(); L.orc_lefkimmiatis_postfilter.restype = C.c_int
+    rc = L.orc_lefkimmiatis_postfilter(_p(X), _p(Y), _p(wq), _p(R), _p(lam), Cn, T, F, C.c_double(alpha), type, minFrames, C.c_double(threshold), int(fbinX1),
+                                       _p(out), _p(wp1))
+    if rc != 0:
+        raise ValueError("The number of channels %d is <= 1" % Cn)
+    return out, wp1
+
+
 def wpe_single(Y, lowerN, upperN, iterationsN=2, loadDb=-20.0, bandWidth=0.0, sampleRate=16000.0):
     """SingleChannelWPEDereverberationFeature (dereverberation.cc:28-300): Y [N][M] complex -> (out [N][M], gn [M][P])."""
     Y = np.ascontiguousarray(Y, np.complex128); N, M = Y.shape; P = upperN - lowerN + 1

@@ -164,3 +164,97 @@ int orc_mccowan_postfilter(const double* X, const double* Y, const double* wq, c
   free(csd); free(ta);
   return 0;
 }
+
+/* LefkimmiatisPostFilter::{estimateAverageOfNoiseSignalPSD (the non-ORIGINAL_IAIN_PAPER build), PostFiltering, next} (postfilter.cc:1065-1210)
+ * on McCowan's density recursions.  lambda: [F] complex, d^H pinv(R_f) d -- the pseudo-inverse itself (beamformer.cc:253-300: LINPACK csvdc in
+ * single precision, singular values below minSV dropped) is computed by the caller (oracle.py: numpy SVD), see the note there. */
+int orc_lefkimmiatis_postfilter(const double* X, const double* Y, const double* wq, const double* R, const double* lambda, int C, int T, int F, double alpha_, int type,
+                                int minFrames, double threshold, int fbinX1, double* out, double* wp1)
+{
+  if (C <= 1) return -1;
+  const int NP = C * C;
+  double* csd = (double*) calloc((size_t) F * NP * 2, sizeof(double));
+  double* ta = (double*) calloc((size_t) C * 2, sizeof(double));
+  for (int t = 0; t < T; t++) {
+    const int frameX = t - 1;
+    const double alpha = (frameX > 0) ? alpha_ : 0.0;
+    for (int f = 0; f < F; f++) {
+      double* prev = csd + (size_t) f * NP * 2; const double* Rf = R + (size_t) f * NP * 2;
+      for (int i = 0; i < C; i++) {
+        const double dr = wq[((size_t) f * C + i) * 2], di = -wq[((size_t) f * C + i) * 2 + 1];
+        const double xr = X[(((size_t) i * T + t) * F + f) * 2], xi = X[(((size_t) i * T + t) * F + f) * 2 + 1];
+        ta[2*i] = dr * xr - di * xi; ta[2*i+1] = dr * xi + di * xr;
+      }
+      for (int i = 0; i < C - 1; i++)
+        for (int j = i + 1; j < C; j++) {
+          const int idx = i * C + j;
+          const double ar = ta[2*i], ai = ta[2*i+1], br = ta[2*j], bi = -ta[2*j+1];
+          const double pr = ar * br - ai * bi, pi = ar * bi + ai * br;
+          if (alpha > 0.0) { prev[2*idx] = prev[2*idx] * alpha + pr * (1.0 - alpha); prev[2*idx+1] = prev[2*idx+1] * alpha + pi * (1.0 - alpha); }
+          else { prev[2*idx] = pr; prev[2*idx+1] = pi; }
+        }
+      double sumOfPSD = 0.0;
+      for (int i = 0; i < C; i++) {
+        const int idx = i * C + i;
+        const double a2 = ta[2*i] * ta[2*i] + ta[2*i+1] * ta[2*i+1];
+        double est;
+        if (alpha > 0.0) est = alpha * prev[2*idx] + (1.0 - alpha) * a2; else est = a2;
+        sumOfPSD += est; prev[2*idx] = est; prev[2*idx+1] = 0.0;
+      }
+      const double de = sumOfPSD / C;
+      double sr = 0.0, si = 0.0;
+      for (int i = 0; i < C - 1; i++) {
+        const double phi_ii = prev[2 * (i * C + i)];
+        for (int j = i + 1; j < C; j++) {
+          const double pr = prev[2 * (i * C + j)], pi = prev[2 * (i * C + j) + 1];
+          const double phi_jj = prev[2 * (j * C + j)];
+          double Rr = Rf[2 * (i * C + j)], Ri = Rf[2 * (i * C + j) + 1];
+          if (Rr > threshold && Ri <= 0.0) { Rr = threshold; Ri = 0.0; }
+          const double hs = 0.5 * (phi_ii + phi_jj);
+          const double nr = pr - Rr * hs, ni = pi - Ri * hs;                   /* phi_ij - R_ij * 0.5 (phi_ii + phi_jj) */
+          const double dr = -Rr + 1.0, di = -Ri;                               /* 1 - R_ij */
+          double qr, qi; cdiv_gsl(nr, ni, dr, di, &qr, &qi);
+          sr += qr; si += qi;
+        }
+      }
+      const double avg = (1 & type) ? sr : hypot(sr, si);
+      const double phi_ss = 2.0 * avg / (C * (C - 1));                         /* estimateAverageOfCleanSignalPSD (McCowan's) */
+      (void) de;
+      /* estimateAverageOfNoiseSignalPSD (postfilter.cc:1065-1103): sum over the pairs of (0.5 (phi_ii + phi_jj) - phi_ij) / (1 - R_ij), the
+       * coherence clipped on its real part only */
+      double vr = 0.0, vi = 0.0;
+      for (int i = 0; i < C - 1; i++) {
+        const double phi_ii = prev[2 * (i * C + i)];
+        for (int j = i + 1; j < C; j++) {
+          const double pr = prev[2 * (i * C + j)], pi = prev[2 * (i * C + j) + 1];
+          const double phi_jj = prev[2 * (j * C + j)];
+          double Rr = Rf[2 * (i * C + j)], Ri = Rf[2 * (i * C + j) + 1];
+          if (Rr > threshold) { Rr = threshold; Ri = 0.0; }
+          else if (Rr == 1.0) { Rr = 0.99; Ri = 0.0; }
+          const double valr = (phi_ii + phi_jj) * 0.5, vali = 0.0 * 0.5;
+          const double nr = valr - pr, ni = vali - pi;
+          const double dr = -Rr + 1.0, di = -Ri;
+          double qr, qi; cdiv_gsl(nr, ni, dr, di, &qr, &qi);
+          vr += qr; vi += qi;
+        }
+      }
+      const double avgv = (1 & type) ? vr : hypot(vr, vi);
+      const double phi_vv = 2.0 * avgv / (C * (C - 1));
+      double W;
+      if (f < fbinX1) W = phi_ss / (phi_ss + phi_vv);
+      else {
+        const double lam = (1 & type) ? lambda[2 * f] : hypot(lambda[2 * f], lambda[2 * f + 1]);   /* d^H pinv(R) d (postfilter.cc:996-1009) */
+        const double phi_nn = phi_vv / lam;
+        W = phi_ss / (phi_ss + phi_nn);
+      }
+      if (W > 1.0) W = 1.0;
+      if (W < 0.0001) W = 0.0001;
+      if (wp1) wp1[(size_t) t * F + f] = W;
+      const double yr = Y[((size_t) t * F + f) * 2], yi = Y[((size_t) t * F + f) * 2 + 1];
+      if (frameX >= minFrames) { out[((size_t) t * F + f) * 2] = yr * W; out[((size_t) t * F + f) * 2 + 1] = yi * W; }
+      else { out[((size_t) t * F + f) * 2] = yr; out[((size_t) t * F + f) * 2 + 1] = yi; }
+    }
+  }
+  free(csd); free(ta);
+  return 0;
+}

@@ -757,6 +757,44 @@ def test_mccowan_postfilter(dsr, oracle, cuda, Cn, ptype, alpha, minFrames, myu)
     assert w.min() < 0.9                                               # the case is not saturated everywhere
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("Cn,ptype,alpha,minFrames,fbinX1,load", [(8, 2, 0.6, 0, 0, 0.05), (4, 1, 0.8, 2, 5, 0.2), (6, 2, 0.0, 0, 40, 0.01)])
+def test_lefkimmiatis_postfilter(dsr, oracle, cuda, Cn, ptype, alpha, minFrames, fbinX1, load):
+    """postfilter.cc:948-1210 on McCowan's recursions: noise estimate sum (0.5(phi_ii+phi_jj) - phi_ij)/(1 - R_ij), divided by d^H pinv(R) d
+    from bin fbinX1 on.  The pseudo-inverse (reference: single-precision LINPACK SVD) is a double-precision Jacobi SVD on the product
+    side and numpy's SVD in the oracle: with the diagonally loaded (full rank) coherence matrices used here the two agree to 1e-9."""
+    import torch
+    rng = np.random.default_rng(70 + Cn)
+    U, T, M = 2, 25, 64
+    F = M // 2 + 1
+    mp = synth.linear_array(Cn)
+    wq = (np.exp(-1j * rng.uniform(0, 6, (F, Cn))) / Cn).astype(np.complex128)
+    s = rng.standard_normal((U, T, F)) + 1j * rng.standard_normal((U, T, F))
+    X = np.stack([s * np.conj(wq[:, c]) * Cn + 0.8 * (rng.standard_normal((U, T, F)) + 1j * rng.standard_normal((U, T, F))) for c in range(Cn)], axis=1).astype(np.complex64)
+    Y = np.einsum("fc,uctf->utf", np.conj(wq), X.astype(np.complex128)).astype(np.complex64)
+    pf = dsr.LefkimmiatisPostFilter(M, Cn, wq, minSV=1e-8, fbinX1=fbinX1, alpha=alpha, type=ptype, minFrames=minFrames, threshold=0.99)
+    pf.setDiffuseNoiseModel(mp, 16000.0)
+    pf.setAllLevelsOfDiagonalLoading(load)
+    R = oracle.pf_diffuse_noise_model(mp, M, 16000.0)
+    R[:, np.eye(Cn, dtype=bool)] += np.float32(load)
+    lam = oracle.lefkimmiatis_lambda(R, wq, 1e-8)
+    got, w = pf.apply(torch.from_numpy(X).to(cuda), torch.from_numpy(Y).to(cuda), want_weights=True)
+    got, w = got.cpu().numpy(), w.cpu().numpy()
+    for u in range(U):
+        wo, ww = oracle.lefkimmiatis_postfilter(X[u].astype(np.complex128), Y[u].astype(np.complex128), wq, R, lam, alpha, ptype, minFrames, 0.99, fbinX1)
+        np.testing.assert_allclose(w[u], ww, rtol=2e-6)
+        assert np.abs(got[u] - wo).max() <= 2e-6 * np.abs(wo).max()
+    assert 0.0001 < w.min() < 0.9 or w.max() > 0.0001
+    # a rank-deficient matrix: the singular values below minSV are dropped, not inverted (bin 0 of the unloaded diffuse model is all ones)
+    pf2 = dsr.LefkimmiatisPostFilter(M, Cn, wq, minSV=1e-6, fbinX1=0, alpha=alpha, type=ptype)
+    pf2.setDiffuseNoiseModel(mp, 16000.0)
+    R2 = oracle.pf_diffuse_noise_model(mp, M, 16000.0)
+    lam2 = oracle.lefkimmiatis_lambda(R2, wq, 1e-6)
+    _, w2 = pf2.apply(torch.from_numpy(X).to(cuda), torch.from_numpy(Y).to(cuda), want_weights=True)
+    _, ww2 = oracle.lefkimmiatis_postfilter(X[0].astype(np.complex128), Y[0].astype(np.complex128), wq, R2, lam2, alpha, ptype, 0, 0.99, 0)
+    np.testing.assert_allclose(w2.cpu().numpy()[0][:, 0], ww2[:, 0], rtol=1e-5)
+
+
 # ------------------------------------------------------------------------------------------- single-channel WPE (SURVEY 8f, rank 1)
 @pytest.mark.gpu
 @pytest.mark.parametrize("lowerN,upperN,iters,loadDb,bw", [(2, 9, 2, -20.0, 0.0), (1, 16, 3, -10.0, 0.0), (3, 6, 1, -30.0, 4000.0), (0, 3, 2, -20.0, 0.0)])

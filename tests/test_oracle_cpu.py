@@ -422,3 +422,42 @@ def test_wpe_single_against_numpy(oracle):
         assert np.abs(g - gn[b]).max() < 1e-10 * max(1.0, np.abs(g).max())
         pred = np.array([sum(np.conj(g[l]) * (y[n - lowerN - l] if n - lowerN - l >= 0 else 0.0) for l in range(P)) if n >= lowerN else 0.0 for n in range(N)])
         assert np.abs(out[:, b] - (y - pred)).max() < 1e-10
+
+
+def test_lefkimmiatis_postfilter_against_numpy(oracle):
+    """postfilter.cc:981-1176 restated vs a direct numpy evaluation: pseudo-inverse with the absolute singular-value floor,
+    Lambda = d^H pinv(R) d, the coherence-based noise estimate and the weight rule on both sides of fbinX1."""
+    rng = np.random.default_rng(4)
+    Cn, T, F, alpha, fb1, thr = 4, 9, 6, 0.7, 3, 0.99
+    X = rng.standard_normal((Cn, T, F)) + 1j * rng.standard_normal((Cn, T, F))
+    d = np.exp(1j * rng.uniform(0, 6, (F, Cn))) / Cn
+    Y = np.einsum("fc,ctf->tf", np.conj(d), X)
+    R = np.zeros((F, Cn, Cn), complex)
+    for f in range(F):
+        A = rng.standard_normal((Cn, Cn)) + 1j * rng.standard_normal((Cn, Cn))
+        R[f] = np.eye(Cn) + 0.15 * (A + A.conj().T)
+    R[1] = np.ones((Cn, Cn))                                   # rank one: three singular values fall below the floor
+    lam = oracle.lefkimmiatis_lambda(R, d, 1e-8)
+    for f in range(F):
+        ref = np.conj(d[f]) @ np.linalg.pinv(R[f], rcond=1e-8 / np.linalg.svd(R[f], compute_uv=False)[0] * 1.0000001, hermitian=False) @ d[f]
+        assert abs(lam[f] - ref) <= 1e-10 * max(1.0, abs(ref))
+    out, wp = oracle.lefkimmiatis_postfilter(X, Y, d, R, lam, alpha, 2, 1, thr, fb1)
+    csd = np.zeros((F, Cn, Cn), complex)
+    for t in range(T):
+        a = alpha if t - 1 > 0 else 0.0
+        for f in range(F):
+            ta = np.conj(d[f]) * X[:, t, f]
+            new = np.outer(ta, np.conj(ta))
+            csd[f] = new if a == 0.0 else a * csd[f] + (1 - a) * new
+            iu = np.triu_indices(Cn, 1)
+            psd = np.real(np.diag(csd[f]))
+            Rc = R[f][iu].copy(); Rc[np.real(Rc) > thr] = thr
+            hs = 0.5 * (psd[iu[0]] + psd[iu[1]])
+            Rm = R[f][iu].copy(); clipm = (np.real(Rm) > thr) & (np.imag(Rm) <= 0.0); Rm[clipm] = thr      # McCowan's clip (postfilter.cc:789-826)
+            phi_ss = 2.0 * abs(np.sum((csd[f][iu] - Rm * hs) / (1.0 - Rm))) / (Cn * (Cn - 1))
+            phi_vv = 2.0 * abs(np.sum((hs - csd[f][iu]) / (1.0 - Rc))) / (Cn * (Cn - 1))
+            W = phi_ss / (phi_ss + (phi_vv if f < fb1 else phi_vv / abs(lam[f])))
+            W = min(1.0, max(1e-4, W))
+            assert abs(wp[t, f] - W) <= 1e-9 * max(W, 1e-4), (t, f)
+            exp = Y[t, f] * W if t - 1 >= 1 else Y[t, f]
+            assert abs(out[t, f] - exp) <= 1e-9 * abs(exp)
