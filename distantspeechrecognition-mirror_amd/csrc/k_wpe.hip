@@ -121,6 +121,128 @@ __global__ __launch_bounds__(256) void k_wpe(const float2* __restrict__ Y, const
   if (gnOut) for (int l = tid; l < P; l += nthr) gnOut[((long) u * F + b) * P + l] = g[l];
 }
 
+
+// MultiChannelWPEDereverberation (dereverberation.cc:281-586).  One workgroup owns one (utterance, subband, channel): the subband's series of
+// ALL channels sit in LDS (fp32 as delivered, widened when used), the stacked lag vector is [channel][lag] (_getLags :422-437), theta_n,
+// the (C P) x (C P) weighted correlation matrix, its loading, Cholesky and the prediction filter are this channel's (:439-573).
+// The filters go to memory; k_wpe_multi_out then subtracts the predictions (getOutput :365-395).
+__global__ __launch_bounds__(256) void k_wpe_multi(const float2* __restrict__ Y, const int* __restrict__ nframesArr, double2* __restrict__ gnOut,
+                                                   int* __restrict__ failOut, int U, int C, int Nmax, int F, int M, int lowerN, int P, int iterationsN,
+                                                   double loadFactor, int lowerBW)
+{
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int PT = P * C;
+  double2* R = reinterpret_cast<double2*>(smem);                 // [PT][PT] lower triangle
+  double2* r = R + PT * PT;                                      // [PT]
+  double2* g = r + PT;                                           // [PT]
+  double* rth = reinterpret_cast<double*>(g + PT);               // [N]  1 / theta_n
+  float2* y = reinterpret_cast<float2*>(rth + Nmax);             // [C][N]
+  __shared__ int s_fail;
+  const int tid = threadIdx.x, nthr = blockDim.x;
+  const int b = blockIdx.x, c0 = blockIdx.y, u = blockIdx.z;
+  const int N = nframesArr[u] < Nmax ? nframesArr[u] : Nmax;
+  const bool selected = (b <= lowerBW) || (b >= M - lowerBW);    // dereverberation.cc:552
+  double2* gOut = gnOut + (((long) u * C + c0) * F + b) * PT;
+  if (!selected) { for (int l = tid; l < PT; l += nthr) gOut[l] = make_double2(0.0, 0.0); return; }
+  for (int i = tid; i < C * N; i += nthr) { const int ch = i / N, n = i - ch * N; y[ch * Nmax + n] = Y[(((long) u * C + ch) * Nmax + n) * F + b]; }
+  for (int l = tid; l < PT; l += nthr) g[l] = make_double2(0.0, 0.0);
+  if (tid == 0) s_fail = 0;
+  __syncthreads();
+  auto lagv = [&](int t, int n) -> double2 {                     // lag_t of frame n: channel t / P, delay lowerN + t % P; zero before the start
+    const int ch = t / P, ix = n - lowerN - (t - ch * P);
+    if (ix < 0) return make_double2(0.0, 0.0);
+    const float2 v = y[ch * Nmax + ix]; return make_double2((double) v.x, (double) v.y);
+  };
+  for (int it = 0; it < iterationsN; it++) {
+    for (int n = tid; n < N; n += nthr) {                        // _calculateThetan
+      const float2 v = y[c0 * Nmax + n]; double cr = (double) v.x, ci = (double) v.y;
+      if (n >= lowerN) {
+        double dr = 0.0, di = 0.0;
+        for (int t = 0; t < PT; t++) { const double2 a = lagv(t, n); const double gr = g[t].x, gi = -g[t].y; dr += gr * a.x - gi * a.y; di += gr * a.y + gi * a.x; }
+        cr -= dr; ci -= di;
+      }
+      double th = hypot(cr, ci); if (th < 1.0E-03) th = 1.0E-03;
+      rth[n] = 1.0 / (th * th);
+    }
+    __syncthreads();
+    const int nEnt = PT * (PT + 1) / 2;
+    for (int e = tid; e < nEnt + PT; e += nthr) {                // _calculateRr: lower triangle of R, then r
+      double sr = 0.0, si = 0.0;
+      if (e < nEnt) {
+        int row = (int) ((sqrt(8.0 * e + 1.0) - 1.0) * 0.5); while (row * (row + 1) / 2 > e) row--; while ((row + 1) * (row + 2) / 2 <= e) row++;
+        const int col = e - row * (row + 1) / 2;
+        for (int n = lowerN; n < N; n++) { const double2 a = lagv(row, n), q = lagv(col, n); const double w = rth[n]; sr += (a.x * q.x + a.y * q.y) * w; si += (a.y * q.x - a.x * q.y) * w; }
+        R[row * PT + col] = make_double2(sr, si);
+      } else {
+        const int l = e - nEnt;
+        for (int n = lowerN; n < N; n++) { const float2 v = y[c0 * Nmax + n]; const double2 a = lagv(l, n); const double w = rth[n];
+          sr += ((double) v.x * a.x + (double) v.y * a.y) * w; si += ((double) v.x * a.y - (double) v.y * a.x) * w; }
+        r[l] = make_double2(sr, si);
+      }
+    }
+    __syncthreads();
+    if (tid == 0) {                                              // _loadR, Cholesky (lower), two triangular solves
+      double maxd = 0.0;
+      for (int k = 0; k < PT; k++) { const double d = hypot(R[k * PT + k].x, R[k * PT + k].y); if (d > maxd) maxd = d; }
+      for (int k = 0; k < PT; k++) { const double d = hypot(R[k * PT + k].x, R[k * PT + k].y) + maxd * loadFactor; R[k * PT + k] = make_double2(d, 0.0); }
+      bool ok = true;
+      for (int j = 0; j < PT && ok; j++) {
+        double ajj = R[j * PT + j].x;
+        for (int k = 0; k < j; k++) ajj -= R[j * PT + k].x * R[j * PT + k].x + R[j * PT + k].y * R[j * PT + k].y;
+        if (ajj <= 0.0) { ok = false; break; }
+        ajj = sqrt(ajj); R[j * PT + j] = make_double2(ajj, 0.0);
+        for (int i = j + 1; i < PT; i++) {
+          double sr = R[i * PT + j].x, si = R[i * PT + j].y;
+          for (int k = 0; k < j; k++) { const double2 a = R[i * PT + k], q = R[j * PT + k]; sr -= a.x * q.x + a.y * q.y; si -= a.y * q.x - a.x * q.y; }
+          R[i * PT + j] = make_double2(sr / ajj, si / ajj);
+        }
+      }
+      if (!ok) s_fail = 1;
+      else {
+        for (int i = 0; i < PT; i++) {
+          double sr = r[i].x, si = r[i].y;
+          for (int k = 0; k < i; k++) { const double2 a = R[i * PT + k]; sr -= a.x * g[k].x - a.y * g[k].y; si -= a.x * g[k].y + a.y * g[k].x; }
+          const double d = R[i * PT + i].x; g[i] = make_double2(sr / d, si / d);
+        }
+        for (int i = PT - 1; i >= 0; i--) {
+          double sr = g[i].x, si = g[i].y;
+          for (int k = i + 1; k < PT; k++) { const double ar = R[k * PT + i].x, ai = -R[k * PT + i].y; sr -= ar * g[k].x - ai * g[k].y; si -= ar * g[k].y + ai * g[k].x; }
+          const double d = R[i * PT + i].x; g[i] = make_double2(sr / d, si / d);
+        }
+      }
+    }
+    __syncthreads();
+    if (s_fail) break;
+  }
+  if (s_fail && tid == 0) atomicExch(&failOut[u], 1);
+  for (int l = tid; l < PT; l += nthr) gOut[l] = s_fail ? make_double2(NAN, NAN) : g[l];
+}
+
+// getOutput: one thread per (utterance, channel, frame, bin); filterChan >= 0: every channel through that channel's filter
+__global__ __launch_bounds__(256) void k_wpe_multi_out(const float2* __restrict__ Y, const int* __restrict__ nframesArr, const double2* __restrict__ gn,
+                                                       float2* __restrict__ out, int U, int C, int Nmax, int F, int M, int lowerN, int P, int lowerBW, int filterChan)
+{
+  const long i = (long) blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long) U * C * Nmax * F) return;
+  const int b = (int) (i % F); long q = i / F; const int n = (int) (q % Nmax); q /= Nmax; const int c = (int) (q % C), u = (int) (q / C);
+  const int N = nframesArr[u] < Nmax ? nframesArr[u] : Nmax;
+  if (n >= N) { out[i] = make_float2(0.f, 0.f); return; }
+  const float2 v = Y[i]; double cr = (double) v.x, ci = (double) v.y;
+  if (n >= lowerN && ((b <= lowerBW) || (b >= M - lowerBW))) {
+    const int fc = filterChan >= 0 ? filterChan : c, PT = P * C;
+    const double2* g = gn + (((long) u * C + fc) * F + b) * PT;
+    double dr = 0.0, di = 0.0;
+    for (int ch = 0; ch < C; ch++)
+      for (int l = 0; l < P; l++) {
+        const int ix = n - lowerN - l; if (ix < 0) break;
+        const float2 a = Y[(((long) u * C + ch) * Nmax + ix) * F + b]; const double2 gg = g[ch * P + l];
+        dr += gg.x * (double) a.x + gg.y * (double) a.y; di += gg.x * (double) a.y - gg.y * (double) a.x;      // conj(g) a
+      }
+    cr -= dr; ci -= di;
+  }
+  out[i] = make_float2((float) cr, (float) ci);
+}
+
 }  // namespace dsr
 
 using namespace dsr;
@@ -146,6 +268,38 @@ dsr_status dsr_wpe_single(const float* Y_dev, const int32_t* nframes_dev, int U,
     DSR_HIP(hipFuncSetAttribute((const void*) k_wpe, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
     hipLaunchKernelGGL(k_wpe, dim3(F, U), dim3(256), lds, (hipStream_t) stream, (const float2*) Y_dev, nframes_dev, (float2*) out_dev, (double2*) gn_dev,
                        U, Nmax, F, fftLen, lowerN, P, iterationsN, pow(10.0, loadDb / 10.0), lowerBW);
+    DSR_HIP(hipGetLastError());
+  });
+}
+
+
+// MultiChannelWPEDereverberation (dereverberation.h:89-157, dereverberation.cc:281-586).  Y_dev [U][C][Nmax][M/2+1] complex64 -> out_dev same shape;
+// gn_dev [U][C][M/2+1][C*P] complex128 (required: the filters are handed from the estimation kernel to the output kernel through it).
+// filterChan < 0: every channel is filtered with its own prediction filter; >= 0: all channels with that channel's filter, which is what
+// the reference's getOutput does for the channel whose feature asks for a frame first (:381).  A (subband, channel) whose loaded matrix is
+// not positive definite yields NaNs.
+dsr_status dsr_wpe_multi(const float* Y_dev, const int32_t* nframes_dev, int U, int chanN, int Nmax, int fftLen, int lowerN, int upperN, int iterationsN,
+                         double loadDb, double bandWidth, double sampleRate, int filterChan, float* out_dev, double* gn_dev, void* stream)
+{
+  return guard([&] {
+    if (!Y_dev || !nframes_dev || !out_dev || !gn_dev) throw Error(DSR_E_PARAMETER, "null argument");
+    if (upperN < lowerN || lowerN < 0 || iterationsN < 0 || chanN < 1 || filterChan >= chanN) throw Error(DSR_E_PARAMETER, "bad prediction range [%d, %d] / channels %d / filter channel %d", lowerN, upperN, chanN, filterChan);
+    if (bandWidth > sampleRate / 2.0) throw Error(DSR_E_DIMENSION, "Bandwidth is greater than the Nyquist rate.");          // :335-336
+    if (U <= 0 || Nmax <= 0) return;
+    require_device();
+    const int P = upperN - lowerN + 1, F = fftLen / 2 + 1, PT = P * chanN;
+    const int lowerBW = (bandWidth == 0.0) ? fftLen / 2 : (int) (unsigned) ((bandWidth / (sampleRate / 2.0)) * (fftLen / 2));
+    const size_t lds = (size_t) (PT * PT + 2 * PT) * 16 + (size_t) Nmax * 8 + (size_t) chanN * Nmax * 8;
+    if (lds > 150 * 1024) throw Error(DSR_E_DIMENSION, "WPE: %d channels x %d frames x %d taps do not fit the LDS working set", chanN, Nmax, P);
+    hipStream_t st = (hipStream_t) stream;
+    static thread_local DevBuf<int> fail; fail.reserve(U); DSR_HIP(hipMemsetAsync(fail.p, 0, sizeof(int) * U, st));
+    DSR_HIP(hipFuncSetAttribute((const void*) k_wpe_multi, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
+    hipLaunchKernelGGL(k_wpe_multi, dim3(F, chanN, U), dim3(256), lds, st, (const float2*) Y_dev, nframes_dev, (double2*) gn_dev, fail.p,
+                       U, chanN, Nmax, F, fftLen, lowerN, P, iterationsN, pow(10.0, loadDb / 10.0), lowerBW);
+    DSR_HIP(hipGetLastError());
+    const long tot = (long) U * chanN * Nmax * F;
+    hipLaunchKernelGGL(k_wpe_multi_out, dim3((unsigned) ((tot + 255) / 256)), dim3(256), 0, st, (const float2*) Y_dev, nframes_dev, (const double2*) gn_dev,
+                       (float2*) out_dev, U, chanN, Nmax, F, fftLen, lowerN, P, lowerBW, filterChan);
     DSR_HIP(hipGetLastError());
   });
 }

@@ -200,6 +200,23 @@ struct WpeOp : dsr_stream {          // SingleChannelWPEDereverberationFeature (
     op_expand_bins(O.p, T, F, M, d<double2>(), S0);
   }
 };
+struct WpeMultiOp : dsr_stream {     // MultiChannelWPEDereverberationFeature(source, channelX) (dereverberation.cc:281-602): ups = the source's channels
+  int M = 0, lowerN = 0, upperN = 0, iterationsN = 2, channelX = 0, filterChan = -2; double loadDb = -20.0, bandWidth = 0.0, sampleRate = 16000.0;
+  DevBuf<float2> Y, O; DevBuf<double2> G; DevBuf<int> nf;
+  void compute() override {
+    const int C = (int) ups.size();
+    int T = ups[0]->nFrames; for (int c = 1; c < C; c++) if (ups[c]->nFrames < T) T = ups[c]->nFrames;      // _fillBuffer stops with the shortest channel (:397-412)
+    alloc(T); if (T <= 0) return;
+    const int F = M / 2 + 1, P = upperN - lowerN + 1; Y.reserve((size_t) C * T * F); O.reserve((size_t) C * T * F); G.reserve((size_t) C * F * C * P);
+    for (int c = 0; c < C; c++) op_pack_bins(ups[c]->d<double2>(), T, F, M, Y.p + (size_t) c * T * F, S0);
+    nf.upload(&T, 1);
+    // all channels of a frame go through the filter of the channel that asked first (:381); on its own a feature asks first itself
+    const int fc = filterChan == -2 ? channelX : filterChan;
+    dsr_status s = dsr_wpe_multi((const float*) Y.p, nf.p, 1, C, T, M, lowerN, upperN, iterationsN, loadDb, bandWidth, sampleRate, fc, (float*) O.p, (double*) G.p, S0);
+    if (s) throw Error(s, "%s", dsr_last_error());
+    op_expand_bins(O.p + (size_t) channelX * T * F, T, F, M, d<double2>(), S0);
+  }
+};
 struct ZelinskiOp : dsr_stream {     // ZelinskiPostFilter (postfilter.cc:350-493): ups[0] = beamformer output, ups[1..] = the snapshot array's channels
   dsr_zelinski* plan = nullptr; int M = 0; double alpha = 0.6; int ptype = 2, minFrames = 0; std::vector<std::vector<double>> manifold; int chanSet = 0;
   int kind = 0; float threshold = 0.99f;                   // kind 1: McCowanPostFilter (the plan then also carries the noise coherence matrices)
@@ -354,6 +371,29 @@ dsr_status dsr_wpe_single_stream_create(dsr_stream* samples, int lowerN, int upp
     WpeOp* s = mk<WpeOp>(name, "SingleChannelWPEDereverberationFeature", samples->size_, DSR_T_COMPLEX);
     s->M = samples->size_; s->lowerN = lowerN; s->upperN = upperN; s->iterationsN = iterationsN; s->loadDb = loadDb; s->bandWidth = bandWidth; s->sampleRate = sampleRate;
     s->add_up(samples); *out = s;
+  });
+}
+dsr_status dsr_wpe_multi_feature_create(dsr_stream* const* channels, int channelsN, int channelX, int lowerN, int upperN, int iterationsN, double loadDb,
+                                        double bandWidth, double sampleRate, const char* name, dsr_stream** out)
+{
+  return guard([&] {
+    if (!channels || !out || channelsN < 1) throw Error(DSR_E_PARAMETER, "null argument");
+    if (channelX < 0 || channelX >= channelsN) throw Error(DSR_E_INDEX, "channel %d of %d", channelX, channelsN);
+    for (int c = 0; c < channelsN; c++) { need(channels[c], DSR_T_COMPLEX, "MultiChannelWPEDereverberation"); if (channels[c]->size_ != channels[0]->size_) throw Error(DSR_E_DIMENSION, "channel %d has %d subbands, channel 0 %d", c, channels[c]->size_, channels[0]->size_); }
+    if (upperN < lowerN) throw Error(DSR_E_PARAMETER, "bad prediction range [%d, %d]", lowerN, upperN);
+    if (bandWidth > sampleRate / 2.0) throw Error(DSR_E_DIMENSION, "Bandwidth is greater than the Nyquist rate.");
+    WpeMultiOp* s = mk<WpeMultiOp>(name, "MultiChannelWPEDereverberationFeature", channels[0]->size_, DSR_T_COMPLEX);
+    s->M = channels[0]->size_; s->channelX = channelX; s->lowerN = lowerN; s->upperN = upperN; s->iterationsN = iterationsN; s->loadDb = loadDb; s->bandWidth = bandWidth; s->sampleRate = sampleRate;
+    for (int c = 0; c < channelsN; c++) s->add_up(channels[c]);
+    s->checkOrder = true; *out = s;                      // getOutput: jindex_error on out-of-order requests (:371-372)
+  });
+}
+dsr_status dsr_wpe_multi_feature_set_filter_channel(dsr_stream* feature, int filterChan)
+{
+  return guard([&] {
+    WpeMultiOp* q = dynamic_cast<WpeMultiOp*>(feature); if (!q) throw Error(DSR_E_PARAMETER, "not a MultiChannelWPEDereverberationFeature");
+    if (filterChan >= (int) q->ups.size()) throw Error(DSR_E_INDEX, "filter channel %d of %d", filterChan, (int) q->ups.size());
+    q->filterChan = filterChan < 0 ? -1 : filterChan; q->ready = false;
   });
 }
 dsr_status dsr_zelinski_stream_create(dsr_stream* output, int fftLen, double alpha, int type, int minFrames, const char* name, dsr_stream** out)

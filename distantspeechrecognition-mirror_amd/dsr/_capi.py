@@ -77,6 +77,7 @@ def load():
         "dsr_stft_create": [C.c_int, C.c_int, C.c_int, vp], "dsr_stft_destroy": [vp], "dsr_stft_frames": [vp, C.c_int], "dsr_stft_block_len": [vp],
         "dsr_stft_analysis": [vp, vp, vp, C.c_int, C.c_int, i64, C.c_int, vp, vp],
         "dsr_wpe_single": [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, f64, f64, f64, vp, vp, vp],
+        "dsr_wpe_multi": [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, f64, f64, f64, C.c_int, vp, vp, vp],
         "dsr_zelinski_create": [C.c_int, C.c_int, f64, C.c_int, C.c_int, vp], "dsr_zelinski_destroy": [vp], "dsr_zelinski_set_manifold": [vp, C.c_int, vp],
         "dsr_mccowan_create": [C.c_int, C.c_int, f64, C.c_int, C.c_int, f32, vp], "dsr_lefkimmiatis_create": [C.c_int, C.c_int, f64, C.c_int, f64, C.c_int, C.c_int, f32, vp], "dsr_mccowan_set_noise_matrix": [vp, C.c_int, vp],
         "dsr_mccowan_set_diffuse_noise_model": [vp, vp, f64, f64], "dsr_mccowan_diagonal_loading": [vp, C.c_int, f32], "dsr_mccowan_divide_nondiagonal": [vp, f32],
@@ -328,6 +329,21 @@ def wpe_single(Y, fftLen, lowerN, upperN, iterationsN=2, loadDb=-20.0, bandWidth
     check(_lib.dsr_wpe_single(_dev(Y.contiguous()), _dev(nframes), U, N, fftLen, lowerN, upperN, iterationsN, loadDb, bandWidth, sampleRate, _dev(out),
                               _dev(gn) if want_filters else None, cur_stream()))
     return (out, gn) if want_filters else out
+
+
+def wpe_multi(Y, fftLen, lowerN, upperN, iterationsN=2, loadDb=-20.0, bandWidth=0.0, sampleRate=16000.0, nframes=None, filterChan=-1):
+    """Multi-channel WPE (dereverberation.cc:281-586): Y cuda complex64 [U][C][N][M/2+1] -> (out, filters [U][C][M/2+1][C*P] complex128).
+    filterChan >= 0: all channels through that channel's filter (the reference's getOutput when that channel's feature pulls first)."""
+    import torch
+    load()
+    U, Cn, N, F = Y.shape
+    if nframes is None:
+        nframes = torch.full((U,), N, dtype=torch.int32, device=Y.device)
+    out = torch.zeros((U, Cn, N, F), dtype=torch.complex64, device=Y.device)
+    gn = torch.zeros((U, Cn, F, Cn * (upperN - lowerN + 1)), dtype=torch.complex128, device=Y.device)
+    check(_lib.dsr_wpe_multi(_dev(Y.contiguous()), _dev(nframes), U, Cn, N, fftLen, lowerN, upperN, iterationsN, loadDb, bandWidth, sampleRate, int(filterChan),
+                             _dev(out), _dev(gn), cur_stream()))
+    return out, gn
 
 
 class ZelinskiPostFilter:

@@ -25,6 +25,8 @@ def lib():
                "dsr_normal_fft_bank_create": [vp, ci, ci, ci, C.c_char_p, vp],
                "dsr_pr_analysis_bank_create": [vp, vp, ci, ci, ci, C.c_char_p, vp], "dsr_pr_synthesis_bank_create": [vp, vp, ci, ci, ci, C.c_char_p, vp],
                "dsr_wpe_single_stream_create": [vp, ci, ci, ci, C.c_double, C.c_double, C.c_double, C.c_char_p, vp],
+               "dsr_wpe_multi_feature_create": [vp, ci, ci, ci, ci, ci, C.c_double, C.c_double, C.c_double, C.c_char_p, vp],
+               "dsr_wpe_multi_feature_set_filter_channel": [vp, ci],
                "dsr_zelinski_stream_create": [vp, ci, C.c_double, ci, ci, C.c_char_p, vp], "dsr_zelinski_stream_set_channel": [vp, vp],
                "dsr_zelinski_stream_set_manifold": [vp, ci, vp, ci],
                "dsr_mccowan_stream_create": [vp, ci, C.c_double, ci, ci, C.c_float, C.c_char_p, vp],

@@ -321,6 +321,11 @@ dsr_status dsr_zelinski_apply(dsr_zelinski*, const float* X_dev, const float* Y_
  * filters start from zero for every utterance (nextSpeaker() semantics). */
 dsr_status dsr_wpe_single(const float* Y_dev, const int32_t* nframes_dev, int U, int Nmax, int fftLen, int lowerN, int upperN,
                           int iterationsN, double loadDb, double bandWidth, double sampleRate, float* out_dev, double* gn_dev, void* stream);
+/* MultiChannelWPEDereverberation (dereverberation.h:89-157, dereverberation.cc:281-586): Y_dev [U][chanN][Nmax][fftLen/2+1] complex64 -> out_dev same shape;
+ * gn_dev [U][chanN][fftLen/2+1][chanN*(upperN-lowerN+1)] complex128 (required).  filterChan < 0: own filter per channel; >= 0: all channels through that
+ * channel's filter = the reference's getOutput when that channel's feature asks for the frame first (dereverberation.cc:381) */
+dsr_status dsr_wpe_multi(const float* Y_dev, const int32_t* nframes_dev, int U, int chanN, int Nmax, int fftLen, int lowerN, int upperN, int iterationsN,
+                         double loadDb, double bandWidth, double sampleRate, int filterChan, float* out_dev, double* gn_dev, void* stream);
 
 /* =====================================================================================
  * 6b. LPC / MVDR spectral envelopes  (btk/feature/lpc.cc:44-207, lpc.h:134-195,291-331:
@@ -386,6 +391,13 @@ dsr_status dsr_zelinski_stream_set_manifold(dsr_stream* pf, int fbinX, const dou
 /* SingleChannelWPEDereverberationFeature(samples, lowerN, upperN, iterationsN, loadDb, bandWidth, sampleRate) (dereverberation.i:67-81) */
 dsr_status dsr_wpe_single_stream_create(dsr_stream* samples, int lowerN, int upperN, int iterationsN, double loadDb, double bandWidth,
                                         double sampleRate, const char* name, dsr_stream** out);
+/* MultiChannelWPEDereverberation + MultiChannelWPEDereverberationFeature(source, channelX) (dereverberation.i, dereverberation.h:89-174): one
+ * operator per channel feature over the source's input streams (setInput order).  All channels of a frame go through the prediction filter
+ * of the channel whose feature asks for the frame first (dereverberation.cc:381): by default the feature's own channel; the face that owns
+ * the shared source sets the first asker with ..._set_filter_channel (< 0: every channel its own filter). */
+dsr_status dsr_wpe_multi_feature_create(dsr_stream* const* channels, int channelsN, int channelX, int lowerN, int upperN, int iterationsN, double loadDb,
+                                        double bandWidth, double sampleRate, const char* name, dsr_stream** out);
+dsr_status dsr_wpe_multi_feature_set_filter_channel(dsr_stream* feature, int filterChan);
 /* SubbandDS/GSC/MVDR as a stream: channels are analysis-bank streams (setChannel) */
 dsr_status dsr_subband_bf_create(dsr_bf* weights, const char* name, dsr_stream** out);
 dsr_status dsr_subband_bf_set_channel(dsr_stream* bf, dsr_stream* chan);

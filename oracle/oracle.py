@@ -317,6 +317,19 @@ def wpe_single(Y, lowerN, upperN, iterationsN=2, loadDb=-20.0, bandWidth=0.0, sa
     return out, gn
 
 
+def wpe_multi(Y, lowerN, upperN, iterationsN=2, loadDb=-20.0, bandWidth=0.0, sampleRate=16000.0, filterChan=-1):
+    """MultiChannelWPEDereverberation (dereverberation.cc:281-586): Y [C][N][M] complex -> (out [C][N][M], gn [C][M][C*P]).
+    filterChan >= 0: all channels through that channel's filter (the reference's getOutput when that channel's feature pulls first)."""
+    Y = np.ascontiguousarray(Y, np.complex128); Cn, N, M = Y.shape; P = upperN - lowerN + 1
+    out = np.zeros((Cn, N, M), np.complex128); gn = np.zeros((Cn, M, Cn * P), np.complex128)
+    L = lib(); L.orc_wpe_multi.restype = C.c_int
+    rc = L.orc_wpe_multi(_p(Y), Cn, N, M, lowerN, upperN, iterationsN, C.c_double(loadDb), C.c_double(bandWidth), C.c_double(sampleRate), int(filterChan),
+                         _p(out), _p(gn))
+    if rc != 0:
+        raise ValueError("wpe_multi failed (%d)" % rc)
+    return out, gn
+
+
 def lpc_feature(frames, order, warp=0.0, method=0, kind=0):
     """WarpMVDR/BurgMVDR (kind 0) and WarpLPC/BurgLPC (kind 1) spectral envelopes, lpc.h:134-195,291-331."""
     L = lib(); fr = _f32(frames); T, dim = fr.shape

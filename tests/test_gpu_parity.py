@@ -839,3 +839,63 @@ def test_wpe_single(dsr, oracle, cuda, lowerN, upperN, iters, loadDb, bw):
     rows = np.array([np.array(v) for v in Dv.SingleChannelWPEDereverberationFeaturePtr(src, lowerN, upperN, iters, loadDb, bw, 16000.0)])
     wo, _ = oracle.wpe_single(full, lowerN, upperN, iters, loadDb, bw, 16000.0)
     assert rows.shape == wo.shape and np.abs(rows - wo).max() <= 2e-6 * np.abs(wo).max()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("Cn,lowerN,upperN,iters,loadDb,bw,fc", [(3, 2, 5, 2, -20.0, 0.0, -1), (2, 1, 8, 2, -10.0, 0.0, 1), (4, 3, 4, 1, -30.0, 4000.0, 0)])
+def test_wpe_multi(dsr, oracle, cuda, Cn, lowerN, upperN, iters, loadDb, bw, fc):
+    """dereverberation.cc:281-586: stacked lags [channel][lag], per-channel theta_n / weighted correlation matrix / Cholesky / filter, fp64 on the
+    device (1/theta_n weighting as in the single-channel kernel); getOutput's filter choice (own channel, or the first asker's for all)."""
+    import torch
+    rng = np.random.default_rng(Cn + lowerN + upperN)
+    U, N, M = 2, 120, 32
+    F = M // 2 + 1
+    s = rng.standard_normal((U, 1, N, F)) + 1j * rng.standard_normal((U, 1, N, F))
+    Y = np.zeros((U, Cn, N, F), np.complex128)
+    for c in range(Cn):
+        Y[:, c] = s[:, 0] * np.exp(1j * c) + 0.1 * (rng.standard_normal((U, N, F)) + 1j * rng.standard_normal((U, N, F)))
+        for k in range(1, 10):
+            Y[:, c, k:] += (0.55 + 0.05 * c) ** k * np.roll(s[:, 0], k, axis=1)[:, k:] * np.exp(1j * k * (c + 1))
+    Y = Y.astype(np.complex64)
+    nfr = [N, N - 21]
+    out, gn = dsr.wpe_multi(torch.from_numpy(Y).to(cuda), M, lowerN, upperN, iters, loadDb, bw, 16000.0,
+                            nframes=torch.tensor(nfr, dtype=torch.int32, device=cuda), filterChan=fc)
+    out, gn = out.cpu().numpy(), gn.cpu().numpy()
+
+    def full_of(a):            # [C][n][F] -> [C][n][M] with the mirrored half the reference's streams carry
+        f = np.zeros(a.shape[:2] + (M,), np.complex128); f[:, :, :F] = a; f[:, :, F:] = np.conj(a[:, :, 1:F - 1][:, :, ::-1]); return f
+    for u in range(U):
+        n = nfr[u]
+        wo, wg = oracle.wpe_multi(full_of(Y[u, :, :n]), lowerN, upperN, iters, loadDb, bw, 16000.0, filterChan=fc)
+        np.testing.assert_allclose(gn[u], wg[:, :F], rtol=2e-7, atol=1e-10)
+        assert np.abs(out[u, :, :n] - wo[:, :, :F]).max() <= 2e-6 * np.abs(wo).max()
+        assert not out[u, :, n:].any()
+    # the operators: a shared source, one feature per channel, pulled channel 0 first -> every channel through channel 0's filter
+    from dsr.btk import stream as S, dereverberation as Dv
+
+    class Frames(object):
+        def __init__(self, a):
+            self.a = a
+
+        def size(self):
+            return self.a.shape[1]
+
+        def __iter__(self):
+            return iter(self.a)
+
+    fu = full_of(Y[0])
+    src = Dv.MultiChannelWPEDereverberationPtr(M, Cn, lowerN, upperN, iters, loadDb, bw, 16000.0)
+    for c in range(Cn):
+        src.setInput(S.PyVectorComplexFeatureStreamPtr(Frames(fu[c])))
+    with pytest.raises(dsr.DsrError):
+        src.setInput(S.PyVectorComplexFeatureStreamPtr(Frames(fu[0])))                 # Channel capacity exceeded (dereverberation.cc:359-360)
+    feats = [Dv.MultiChannelWPEDereverberationFeaturePtr(src, c) for c in range(Cn)]
+    rows = [[] for _ in range(Cn)]
+    for t in range(N):
+        for c in range(Cn):
+            rows[c].append(np.array(feats[c].next(t)))
+    with pytest.raises(StopIteration):
+        feats[0].next(N)
+    wo, _ = oracle.wpe_multi(fu, lowerN, upperN, iters, loadDb, bw, 16000.0, filterChan=0)
+    got = np.array(rows)
+    assert got.shape == wo.shape and np.abs(got - wo).max() <= 4e-6 * np.abs(wo).max()

@@ -461,3 +461,40 @@ def test_lefkimmiatis_postfilter_against_numpy(oracle):
             assert abs(wp[t, f] - W) <= 1e-9 * max(W, 1e-4), (t, f)
             exp = Y[t, f] * W if t - 1 >= 1 else Y[t, f]
             assert abs(out[t, f] - exp) <= 1e-9 * abs(exp)
+
+
+def test_wpe_multi_oracle_properties(oracle):
+    """dereverberation.cc:281-586 restated: with one channel it is the single-channel operator; with two, the filters solve the
+    loaded normal equations built from the stacked lags (direct numpy evaluation of one iteration), and filterChan picks the filter."""
+    rng = np.random.default_rng(8)
+    N, M, lowerN, upperN, loadDb = 50, 6, 2, 4, -20.0
+    P = upperN - lowerN + 1
+    Y1 = rng.standard_normal((1, N, M)) + 1j * rng.standard_normal((1, N, M))
+    o1, g1 = oracle.wpe_multi(Y1, lowerN, upperN, 2, loadDb, 0.0, 16000.0)
+    os_, gs = oracle.wpe_single(Y1[0], lowerN, upperN, 2, loadDb, 0.0, 16000.0)
+    assert np.array_equal(o1[0], os_) and np.array_equal(g1[0], gs)
+    Cn = 2
+    Y = rng.standard_normal((Cn, N, M)) + 1j * rng.standard_normal((Cn, N, M))
+    out, gn = oracle.wpe_multi(Y, lowerN, upperN, 1, loadDb, 0.0, 16000.0)
+    b = 1
+    lags = np.zeros((N, Cn * P), complex)
+    for n in range(lowerN, N):
+        for c in range(Cn):
+            for l in range(P):
+                ix = n - lowerN - l
+                lags[n, c * P + l] = Y[c, ix, b] if ix >= 0 else 0.0
+    for c in range(Cn):
+        th = np.maximum(np.abs(Y[c, :, b]), 1e-3) ** 2              # first iteration: filters are zero
+        R = np.zeros((Cn * P, Cn * P), complex); r = np.zeros(Cn * P, complex)
+        for n in range(lowerN, N):
+            R += np.outer(lags[n], np.conj(lags[n])) / th[n]; r += np.conj(Y[c, n, b]) * lags[n] / th[n]
+        d = np.abs(np.diag(R)); R[np.diag_indices(Cn * P)] = d + d.max() * 10 ** (loadDb / 10)
+        g = np.linalg.solve(R, r)
+        assert np.abs(gn[c, b] - g).max() <= 1e-9 * np.abs(g).max()
+        pred = lags @ np.conj(g)
+        exp = Y[c, :, b] - np.where(np.arange(N) >= lowerN, pred, 0.0)
+        assert np.abs(out[c, :, b] - exp).max() <= 1e-9
+    out0, gn0 = oracle.wpe_multi(Y, lowerN, upperN, 1, loadDb, 0.0, 16000.0, filterChan=0)
+    assert np.array_equal(gn0, gn) and np.array_equal(out0[0], out[0]) and not np.array_equal(out0[1], out[1])
+    pred = lags @ np.conj(gn[0, b])
+    assert np.abs(out0[1, :, b] - (Y[1, :, b] - np.where(np.arange(N) >= lowerN, pred, 0.0))).max() <= 1e-9
