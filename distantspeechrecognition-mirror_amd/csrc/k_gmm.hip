@@ -41,6 +41,7 @@ struct GmmModel {
 // ------------------------------------------------------------------------------------------------
 // mode 0: exact nearest-Gaussian.  Block = 256 threads = 256 frames; loop over codebooks, Gaussian
 // parameters of a codebook chunk staged in LDS and read as wave-wide broadcasts.
+static constexpr int kTW = 16;                            // codebooks per score tile of k_gmm_exact
 template <int DP>
 __global__ __launch_bounds__(256) void k_gmm_exact(const float* __restrict__ x, long N, int D, int K, const int* __restrict__ off,
                                                    const float* __restrict__ mean, const float* __restrict__ ivar,
@@ -51,6 +52,9 @@ __global__ __launch_bounds__(256) void k_gmm_exact(const float* __restrict__ x, 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   float* sm = reinterpret_cast<float*>(smem);            // [chunkG][DP] means
   float* sv = sm + (size_t) chunkG * DP;                  // [chunkG][DP] inverse variances
+  // scores of a chunk's codebooks (at most kTW) wait in an LDS tile [256 frames][kTW + 1] and leave as 64-byte row segments: a thread
+  // storing its own frame's scores one by one would write 4 bytes per lane at a stride of K floats, every store a partial line
+  float* tile = sv + (size_t) chunkG * DP;
   const long n = (long) blockIdx.x * blockDim.x + threadIdx.x;
   const bool live = n < N;
   float xr[DP];
@@ -61,7 +65,7 @@ __global__ __launch_bounds__(256) void k_gmm_exact(const float* __restrict__ x, 
   while (k < K) {
     // take as many whole codebooks as fit in the chunk
     const int g0 = off[k]; int k1 = k;
-    while (k1 < K && off[k1 + 1] - g0 <= chunkG) k1++;
+    while (k1 < K && k1 - k < kTW && off[k1 + 1] - g0 <= chunkG) k1++;
     const int ng = off[k1] - g0;
     __syncthreads();
     for (int i = threadIdx.x; i < ng * DP; i += blockDim.x) { sm[i] = mean[(long) g0 * DP + i]; sv[i] = ivar[(long) g0 * DP + i]; }
@@ -82,9 +86,16 @@ __global__ __launch_bounds__(256) void k_gmm_exact(const float* __restrict__ x, 
       if (live) {
         float sc = (float) (0.5 * (double) __fadd_rn(minDist, __fmul_rn(2.0f, val[off[kk] + minIdx])));
         const float s = scale[kk]; if (s != 1.0f) sc = __fmul_rn(sc, s);
-        score[n * K + kk] = sc;
+        tile[threadIdx.x * (kTW + 1) + (kk - k)] = sc;
         if (argmin) argmin[n * K + kk] = (unsigned char) minIdx;
       }
+    }
+    __syncthreads();
+    {
+      const int nk = k1 - k, col = threadIdx.x & (kTW - 1), r0 = threadIdx.x / kTW;
+      const long nb = (long) blockIdx.x * blockDim.x;
+      if (col < nk)
+        for (int r = r0; r < 256; r += 256 / kTW) if (nb + r < N) score[(nb + r) * K + k + col] = tile[r * (kTW + 1) + col];
     }
     k = k1;
   }
@@ -274,8 +285,9 @@ dsr_status dsr_gmm_score(dsr_gmm* m, const float* x, int64_t N, int mode, float*
     if (N <= 0) return;
     hipStream_t st = (hipStream_t) stream;
     if (mode == 0) {
-      int chunkG = 24 * 1024 / (2 * m->Dp * 4); if (chunkG < m->maxRef) chunkG = m->maxRef;
-      const size_t lds = (size_t) chunkG * m->Dp * 2 * sizeof(float);
+      // (20 KB of parameters = 16 codebooks of 4 Gaussians at 40 dims = one score tile; A/B 24 / 20 / 16 KB: 16.4 / 14.9 / 15.7 ms)
+      int chunkG = (getenv("DSR_GMM_CHUNKKB") ? atoi(getenv("DSR_GMM_CHUNKKB")) : 20) * 1024 / (2 * m->Dp * 4); if (chunkG < m->maxRef) chunkG = m->maxRef;
+      const size_t lds = (size_t) chunkG * m->Dp * 2 * sizeof(float) + (size_t) 256 * (kTW + 1) * sizeof(float);
       if (lds > 160 * 1024) throw Error(DSR_E_DIMENSION, "codebook too large for LDS staging");
       dim3 grid(cdiv(N, 256));
 #define LAUNCH(DPV) { DSR_HIP(hipFuncSetAttribute((const void*) k_gmm_exact<DPV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds)); \
