@@ -230,8 +230,8 @@ struct dsr_zelinski : ZelinskiPlan {};
 
 
 // d^H pinv(R) d with the Moore-Penrose pseudo-inverse through a one-sided Jacobi SVD in double precision (columns of A V are
-// orthogonalised by complex plane rotations; singular values = column norms), singular values below minSV dropped as in the
-// reference's pseudoinverse (beamformer.cc:253-300; there: LINPACK csvdc in single precision).
+// orthogonalised by complex plane rotations; singular values = column norms).  The reference's pseudoinverse (beamformer.cc:253-300) runs
+// LINPACK csvdc in single precision and reports failure when a singular value is below minSV.
 static double2 lefkimmiatis_lambda(const double* Rf, const double* df, int C, double minSV)
 {
   typedef std::complex<double> cd;
@@ -260,11 +260,17 @@ static double2 lefkimmiatis_lambda(const double* Rf, const double* df, int C, do
     if (off == 0.0) break;
   }
   // pinv = V diag(1/s) U^H with U_k = A_k / s_k  =>  pinv = sum_k V_k A_k^H / s_k^2 ;  Lambda = (pinv^H d)^H d = d^H pinv d
+  // a matrix that loses a singular value to the floor is replaced by the identity (calcInverseNoiseSpatialSpectralMatrix, postfilter.cc:989-991:
+  // pseudoinverse() returns false then): Lambda = d^H d
+  for (int k = 0; k < C; k++) {
+    double s2 = 0.0; for (int i = 0; i < C; i++) s2 += std::norm(A[i + (size_t) k * C]);
+    if (std::sqrt(s2) < minSV) { double n2 = 0.0; for (int i = 0; i < C; i++) n2 += df[2 * i] * df[2 * i] + df[2 * i + 1] * df[2 * i + 1]; return make_double2(n2, 0.0); }
+  }
   cd lam(0.0, 0.0);
   for (int k = 0; k < C; k++) {
     double s2 = 0.0; for (int i = 0; i < C; i++) s2 += std::norm(A[i + (size_t) k * C]);
     const double sv = std::sqrt(s2);
-    if (sv < minSV || sv == 0.0) continue;
+    if (sv == 0.0) continue;
     cd dv(0.0, 0.0), ad(0.0, 0.0);                                             // d^H V_k  and  A_k^H d
     for (int i = 0; i < C; i++) { const cd d(df[2 * i], df[2 * i + 1]); dv += std::conj(d) * V[i + (size_t) k * C]; ad += std::conj(A[i + (size_t) k * C]) * d; }
     lam += dv * ad / s2;

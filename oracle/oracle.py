@@ -277,17 +277,17 @@ def mccowan_postfilter(X, Y, wq, R, alpha=0.6, type=2, minFrames=0, threshold=0.
 
 
 def lefkimmiatis_lambda(R, d, minSV=1e-8):
-    """d^H pinv(R_f) d per bin (LefkimmiatisPostFilter::calcInverseNoiseSpatialSpectralMatrix + calcLambda, postfilter.cc:981-1009).
-    The reference's pseudoinverse (beamformer.cc:253-300) runs LINPACK csvdc in SINGLE precision and drops singular values below
-    minSV (absolute); this restatement uses numpy's SVD in double precision with the same rule, so for well-conditioned R the two agree
-    to single precision, and for rank-deficient R (where the reference's result is governed by float round-off in the singular values
-    that should be zero) parity is unpinned.  R [F][C][C], d [F][C] -> [F] complex128."""
+    """d^H pinv(R_f) d per bin (LefkimmiatisPostFilter::calcInverseNoiseSpatialSpectralMatrix + calcLambda, postfilter.cc:981-1009) with
+    the reference's pseudo-inverse as restated in orc_pseudoinverse (beamformer.cc:253-300: LINPACK csvdc on complex<float>, singular
+    values below minSV dropped, pinned against the reference's own csvdc in test_oracle_cpu.py).  A bin whose SVD drops a value keeps
+    its pseudo-inverse here; the reference replaces such a matrix by the identity (postfilter.cc:989-991), restated too.
+    R [F][C][C], d [F][C] -> [F] complex128."""
     R = np.asarray(R, np.complex128); d = np.asarray(d, np.complex128)
     lam = np.zeros(R.shape[0], np.complex128)
     for f in range(R.shape[0]):
-        U, sv, Vh = np.linalg.svd(R[f])
-        inv = np.where(sv < minSV, 0.0, 1.0 / np.where(sv == 0, 1.0, sv))
-        pinv = (Vh.conj().T * inv) @ U.conj().T
+        pinv, ok = pseudoinverse(R[f], minSV)
+        if not ok:
+            pinv = np.eye(R.shape[1], dtype=np.complex128)         # "if( false == ret ) gsl_matrix_complex_set_identity( _invR[fbinX] )"
         lam[f] = np.vdot(pinv.conj().T @ d[f], d[f])           # tmpH = invR^H d; Lambda = tmpH^H d
     return lam
 

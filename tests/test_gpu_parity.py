@@ -762,7 +762,8 @@ def test_mccowan_postfilter(dsr, oracle, cuda, Cn, ptype, alpha, minFrames, myu)
 def test_lefkimmiatis_postfilter(dsr, oracle, cuda, Cn, ptype, alpha, minFrames, fbinX1, load):
     """postfilter.cc:948-1210 on McCowan's recursions: noise estimate sum (0.5(phi_ii+phi_jj) - phi_ij)/(1 - R_ij), divided by d^H pinv(R) d
     from bin fbinX1 on.  The pseudo-inverse (reference: single-precision LINPACK SVD) is a double-precision Jacobi SVD on the product
-    side and numpy's SVD in the oracle: with the diagonally loaded (full rank) coherence matrices used here the two agree to 1e-9."""
+    side; the oracle uses the reference's single-precision csvdc pseudo-inverse (restated, pinned against the reference's own csvdc):
+    with the diagonally loaded (full rank) coherence matrices used here the weights agree to 2e-4."""
     import torch
     rng = np.random.default_rng(70 + Cn)
     U, T, M = 2, 25, 64
@@ -782,14 +783,16 @@ def test_lefkimmiatis_postfilter(dsr, oracle, cuda, Cn, ptype, alpha, minFrames,
     got, w = got.cpu().numpy(), w.cpu().numpy()
     for u in range(U):
         wo, ww = oracle.lefkimmiatis_postfilter(X[u].astype(np.complex128), Y[u].astype(np.complex128), wq, R, lam, alpha, ptype, minFrames, 0.99, fbinX1)
-        np.testing.assert_allclose(w[u], ww, rtol=2e-6)
-        assert np.abs(got[u] - wo).max() <= 2e-6 * np.abs(wo).max()
+        np.testing.assert_allclose(w[u], ww, rtol=2e-4)               # the oracle's pseudo-inverse is the reference's single-precision one
+        assert np.abs(got[u] - wo).max() <= 2e-4 * np.abs(wo).max()
     assert 0.0001 < w.min() < 0.9 or w.max() > 0.0001
-    # a rank-deficient matrix: the singular values below minSV are dropped, not inverted (bin 0 of the unloaded diffuse model is all ones)
-    pf2 = dsr.LefkimmiatisPostFilter(M, Cn, wq, minSV=1e-6, fbinX1=0, alpha=alpha, type=ptype)
+    # a rank-deficient matrix (bin 0 of the unloaded diffuse model is all ones): a singular value under the floor makes the reference fall
+    # back to the identity for that bin (postfilter.cc:989-991), Lambda = d^H d; the floor is chosen above single-precision round-off
+    pf2 = dsr.LefkimmiatisPostFilter(M, Cn, wq, minSV=1e-4, fbinX1=0, alpha=alpha, type=ptype)
     pf2.setDiffuseNoiseModel(mp, 16000.0)
     R2 = oracle.pf_diffuse_noise_model(mp, M, 16000.0)
-    lam2 = oracle.lefkimmiatis_lambda(R2, wq, 1e-6)
+    lam2 = oracle.lefkimmiatis_lambda(R2, wq, 1e-4)
+    assert abs(lam2[0] - np.vdot(wq[0], wq[0])) < 1e-12
     _, w2 = pf2.apply(torch.from_numpy(X).to(cuda), torch.from_numpy(Y).to(cuda), want_weights=True)
     _, ww2 = oracle.lefkimmiatis_postfilter(X[0].astype(np.complex128), Y[0].astype(np.complex128), wq, R2, lam2, alpha, ptype, 0, 0.99, 0)
     np.testing.assert_allclose(w2.cpu().numpy()[0][:, 0], ww2[:, 0], rtol=1e-5)
