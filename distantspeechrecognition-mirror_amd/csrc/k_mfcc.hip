@@ -231,39 +231,56 @@ __global__ void k_cmn(const float* __restrict__ cep, const int* __restrict__ Tar
 }
 
 // out[u][t][i] = sum_j A[i][j] * splice(t)[j], splice slot s = frame clamp(t+s-delta, 0, T-1)
+// A workgroup owns FB consecutive frames of one utterance.  LDS holds the transform as [outDim][2 delta + 1][Np] (rows of N coefficients padded
+// to Np = multiple of 4) and the FB + 2 delta (clamped) input rows, padded the same way: every LDS read is an aligned 16-byte read, the
+// accumulation order (slot by slot, coefficient by coefficient, fp32, no FMA: gsl_blas_sgemv's reference loop) is unchanged.
 __global__ __launch_bounds__(256) void k_splice_lda(const float* __restrict__ in, const int* __restrict__ Tarr, int Tmax, int N,
-                                                    int delta, int outDim, const float* __restrict__ A, float* __restrict__ out)
+                                                    int delta, int outDim, const float* __restrict__ A, float* __restrict__ out, int FB)
 {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  float* a = reinterpret_cast<float*>(smem);
-  const int W = (2 * delta + 1) * N;
-  const int u = blockIdx.y;
-  if (A) for (int i = threadIdx.x; i < outDim * W; i += blockDim.x) a[i] = A[i];
-  __syncthreads();
+  const int S = 2 * delta + 1, W = S * N, Np = (N + 3) & ~3;
+  const int u = blockIdx.y, t0 = blockIdx.x * FB;
   int T = Tarr[u] < Tmax ? Tarr[u] : Tmax;
   if (delta > 0 && T < delta) T = 0;                 // AdjacentFeature cannot be primed (feature.cc:2861-2866)
   const float* x = in + (long) u * Tmax * N;
   const int od = A ? outDim : W;
   float* o = out + (long) u * Tmax * od;
-  for (long idx = (long) blockIdx.x * blockDim.x + threadIdx.x; idx < (long) Tmax * od; idx += (long) gridDim.x * blockDim.x) {
-    const int t = (int) (idx / od), i = (int) (idx - (long) t * od);
+  int t1 = t0 + FB; if (t1 > Tmax) t1 = Tmax;
+  if (!A) {                                          // splice only
+    for (int idx = threadIdx.x; idx < (t1 - t0) * od; idx += blockDim.x) {
+      const int t = t0 + idx / od, i = idx - (t - t0) * od; float r = 0.0f;
+      if (t < T) { const int s = i / N, k = i - s * N; int src = t + s - delta; if (src < 0) src = 0; if (src > T - 1) src = T - 1; r = x[(long) src * N + k]; }
+      o[(long) t * od + i] = r;
+    }
+    return;
+  }
+  float* a = reinterpret_cast<float*>(smem);                         // [outDim][S][Np]
+  float* xs = a + (size_t) outDim * S * Np;                          // [FB + 2 delta][Np]
+  for (int i = threadIdx.x; i < outDim * S * Np; i += blockDim.x) { const int k = i % Np, q = i / Np; a[i] = (k < N) ? A[(long) (q / S) * W + (q % S) * N + k] : 0.0f; }
+  if (T > 0)
+    for (int i = threadIdx.x; i < (FB + 2 * delta) * Np; i += blockDim.x) {
+      const int k = i % Np, rr = i / Np; int src = t0 - delta + rr; if (src < 0) src = 0; if (src > T - 1) src = T - 1;
+      xs[i] = (k < N) ? x[(long) src * N + k] : 0.0f;
+    }
+  __syncthreads();
+  for (int idx = threadIdx.x; idx < (t1 - t0) * od; idx += blockDim.x) {
+    const int tl = idx / od, i = idx - tl * od, t = t0 + tl;
     float r = 0.0f;
     if (t < T) {
-      if (A) {
-        float temp = 0.0f;
-        for (int s = 0; s <= 2 * delta; s++) {
-          int src = t + s - delta; if (src < 0) src = 0; if (src > T - 1) src = T - 1;
-          const float* xr = x + (long) src * N;
-          for (int k = 0; k < N; k++) temp = __fadd_rn(temp, __fmul_rn(xr[k], a[i * W + s * N + k]));
+      float temp = 0.0f;
+      for (int s = 0; s < S; s++) {
+        const float* ar = a + ((size_t) i * S + s) * Np; const float* xr = xs + (size_t) (tl + s) * Np;
+        for (int k4 = 0; k4 < Np; k4 += 4) {
+          const float4 av = *reinterpret_cast<const float4*>(ar + k4), xv = *reinterpret_cast<const float4*>(xr + k4);
+          temp = __fadd_rn(temp, __fmul_rn(xv.x, av.x));
+          if (k4 + 1 < N) temp = __fadd_rn(temp, __fmul_rn(xv.y, av.y));
+          if (k4 + 2 < N) temp = __fadd_rn(temp, __fmul_rn(xv.z, av.z));
+          if (k4 + 3 < N) temp = __fadd_rn(temp, __fmul_rn(xv.w, av.w));
         }
-        r = __fadd_rn(0.0f, temp);
-      } else {
-        const int s = i / N, k = i - s * N;
-        int src = t + s - delta; if (src < 0) src = 0; if (src > T - 1) src = T - 1;
-        r = x[(long) src * N + k];
       }
+      r = __fadd_rn(0.0f, temp);
     }
-    o[idx] = r;
+    o[(long) t * od + i] = r;
   }
 }
 
@@ -498,14 +515,13 @@ dsr_status dsr_mfcc_run(dsr_mfcc* p, const float* y, const int32_t* nsamp, int U
       DSR_HIP(hipGetLastError());
     } else if (stage == 2) { DSR_HIP(hipMemcpyAsync(feat, cepOut, nT * c.ncep * sizeof(float), hipMemcpyDeviceToDevice, st)); }
     if (stage == 2) return;
-    const int W = (2 * c.delta + 1) * c.ncep;
-    const size_t lds2 = c.outDim > 0 ? sizeof(float) * (size_t) c.outDim * W : 16;
+    const int Np = (c.ncep + 3) & ~3, S2 = 2 * c.delta + 1;
+    const int FB = getenv("DSR_LDA_FB") ? atoi(getenv("DSR_LDA_FB")) : 64;           // frames per workgroup (the transform is staged once per workgroup)
+    const size_t lds2 = c.outDim > 0 ? sizeof(float) * ((size_t) c.outDim * S2 * Np + (size_t) (FB + 2 * c.delta) * Np) : 16;
     if (lds2 > 160 * 1024) throw Error(DSR_E_DIMENSION, "linear transform needs %zu bytes of LDS", lds2);
     DSR_HIP(hipFuncSetAttribute((const void*) k_splice_lda, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds2));
-    const int od = c.outDim > 0 ? c.outDim : W;
-    int gx = cdiv((long) Tmax * od, 256); if (gx > 256) gx = 256;
-    hipLaunchKernelGGL(k_splice_lda, dim3(gx, U), dim3(256), lds2, st, cmnOut, p->d_T.p, Tmax, c.ncep, c.delta, c.outDim,
-                       c.outDim > 0 ? p->d_lda.p : nullptr, feat);
+    hipLaunchKernelGGL(k_splice_lda, dim3(cdiv(Tmax, FB), U), dim3(256), lds2, st, cmnOut, p->d_T.p, Tmax, c.ncep, c.delta, c.outDim,
+                       c.outDim > 0 ? p->d_lda.p : nullptr, feat, FB);
     DSR_HIP(hipGetLastError());
   });
 }
