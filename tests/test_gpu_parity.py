@@ -902,3 +902,64 @@ def test_wpe_multi(dsr, oracle, cuda, Cn, lowerN, upperN, iters, loadDb, bw, fc)
     wo, _ = oracle.wpe_multi(fu, lowerN, upperN, iters, loadDb, bw, 16000.0, filterChan=0)
     got = np.array(rows)
     assert got.shape == wo.shape and np.abs(got - wo).max() <= 4e-6 * np.abs(wo).max()
+
+
+# ------------------------------------------------------------------------------------------- BASELINE sizes
+@pytest.mark.gpu
+def test_gmm_full_size(dsr, oracle, cuda):
+    """BASELINE config 3 at size (39-dim x 4096 Gaussians as 1024 codebooks of 4, 200 000 frames): a sample of frames bit-exact against the
+    oracle, every frame independent of its place in the batch (a permutation of the frames permutes the rows), scores finite."""
+    import torch
+    K, R, D, N = 1024, 4, 39, 200000
+    m = synth.gmm_model(K, R, D, seed=12)
+    gm = dsr.Gmm(**m)
+    g = torch.Generator(device=cuda); g.manual_seed(3)
+    x = torch.randn((N, D), generator=g, device=cuda) * 1.5
+    sc, am = gm.score(x, mode=0)
+    assert bool(torch.isfinite(sc).all())
+    perm = torch.randperm(N, generator=g, device=cuda)
+    sc2, am2 = gm.score(x[perm].contiguous(), mode=0)
+    assert torch.equal(sc2, sc[perm]) and torch.equal(am2, am[perm])
+    pick = np.concatenate([np.arange(0, 300), np.arange(N - 300, N), np.random.default_rng(1).integers(0, N, 400)])
+    cb = oracle.Codebooks(m["refN"], m["mean"], m["ivar"], m["det"])
+    ref, arg = oracle.gmm_score_opt(cb, m["val"], x[torch.from_numpy(pick).to(cuda)].cpu().numpy())
+    assert np.array_equal(sc.cpu().numpy()[pick].view(np.uint32), ref.view(np.uint32))
+    assert np.array_equal(am.cpu().numpy()[pick].astype(np.int32), arg)
+    sc3, am3 = gm.score(x[:50000].contiguous(), mode=2)                  # the MFMA path returns the same bits
+    assert torch.equal(am3, am[:50000]) and float((sc3 - sc[:50000]).abs().max() / sc[:50000].abs().max()) < 2e-6
+
+
+@pytest.mark.gpu
+def test_viterbi_full_size(dsr, oracle, cuda, monkeypatch):
+    """BASELINE config 4 at size (50 000 states / ~200 000 arcs, 1024 distributions, beam tuned to thousands of active tokens): 300 frames
+    bit-exact against the oracle; register path, memory path and every position in a batch larger than the slot count give identical results."""
+    import torch
+    arcs, fin = synth.random_wfst(50000, 1024, seed=21, outdeg=4, eps_frac=0.1, out_frac=0.05, nWords=5000, nFinal=50)
+    go, gd = _graphs(dsr, oracle, arcs, fin)
+    gm = dsr.Gmm(**synth.gmm_model(1024, 4, 39, seed=12))
+    T, U = 300, 4
+    g = torch.Generator(device=cuda); g.manual_seed(5)
+    f = torch.randn((U, T + 16, 39), generator=g, device=cuda)
+    f = torch.nn.functional.avg_pool1d(f.transpose(1, 2), 9, 1).transpose(1, 2)[:, :T].contiguous() * 3.0
+    sc = gm.score(f.reshape(-1, 39), mode=0, want_argmin=False)[0].reshape(U, T, 1024)
+    beam = 50.0
+    dec = dsr.Decoder(beam=beam, lmScale=12.0, maxActive=65536); dec.set(gd)
+    out = dec.decode_batch(sc, maxPath=1024)
+    assert np.mean([o["activeHypos"] / T for o in out]) > 1500, "the case is meant to keep thousands of tokens alive"
+    assert all(o["registerFrames"] > 0.9 * T for o in out)
+    sch = sc.cpu().numpy()
+    for u in range(2):
+        ro = go.decode(sch[u], beam=beam, lmScale=12.0)
+        assert ro["rc"] == 0
+        _check_decode(ro, out[u])
+    monkeypatch.setenv("DSR_VITERBI_NOFAST", "1")
+    dec2 = dsr.Decoder(beam=beam, lmScale=12.0, maxActive=65536); dec2.set(gd)
+    monkeypatch.delenv("DSR_VITERBI_NOFAST")
+    out2 = dec2.decode_batch(sc, maxPath=1024)
+    big = sc.repeat(80, 1, 1)                                              # 320 utterances: more than the 256 decoder slots
+    out3 = dec.decode_batch(big, maxPath=1024)
+    keys = ["score", "ac", "lm", "status", "activeHypos", "placements", "maxActive", "reachedFinal", "frames"]
+    for u in range(U):
+        assert all(out[u][k] == out2[u][k] for k in keys) and np.array_equal(out[u]["arcs"], out2[u]["arcs"]) and out2[u]["registerFrames"] == 0
+    for v in range(320):
+        assert all(out[v % U][k] == out3[v][k] for k in keys) and np.array_equal(out[v % U]["words"], out3[v]["words"])
