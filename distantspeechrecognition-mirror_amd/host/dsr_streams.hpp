@@ -173,6 +173,69 @@ class ZelinskiPostFilter : public VectorComplexFeatureStream {
  private: VectorComplexFeatureStreamPtr _s; std::vector<VectorComplexFeatureStreamPtr> _chans;
 };
 
+// ---- btk/postfilter/postfilter.h:128-204.  The noise coherence setters fix the array size at their first call (chanN).
+class McCowanPostFilter : public VectorComplexFeatureStream {
+ public:
+  McCowanPostFilter(VectorComplexFeatureStreamPtr& output, unsigned fftLen, double alpha = 0.6, int type = 2, int minFrames = 0, float threshold = 0.99f,
+                    const String& nm = "McCowanPostFilterPtr")
+  : _s(output) { DSR_OP(McCowanPostFilter, cplx, dsr_mccowan_stream_create(output->handle(), (int) fftLen, alpha, type, minFrames, threshold, nm.c_str(), &h)) }
+  void setSnapShotChannel(VectorComplexFeatureStreamPtr& chan) { dsr_throw(dsr_zelinski_stream_set_channel(_h, chan->handle())); _chans.push_back(chan); }
+  void setArrayManifoldVector(unsigned fbinX, const double* vec, unsigned chanN, bool halfBandShift = false, unsigned NC = 1)
+  { (void) halfBandShift; (void) NC; dsr_throw(dsr_zelinski_stream_set_manifold(_h, (int) fbinX, vec, (int) chanN)); }
+  void setDiffuseNoiseModel(const double* micPositions /* [chanN][3] */, unsigned chanN, double sampleRate, double sspeed = 343740.0)
+  { _C = chanN; dsr_throw(dsr_mccowan_stream_set_noise(_h, 1, 0, micPositions, (int) chanN, sampleRate, sspeed)); }
+  void setNoiseSpatialSpectralMatrix(unsigned fbinX, const double* Rnn /* [chanN][chanN] complex */, unsigned chanN)
+  { _C = chanN; dsr_throw(dsr_mccowan_stream_set_noise(_h, 0, (int) fbinX, Rnn, (int) chanN, 0.0, 0.0)); }
+  void setAllLevelsOfDiagonalLoading(float diagonalWeight) { dsr_throw(dsr_mccowan_stream_set_noise(_h, 2, -1, 0, (int) _C, diagonalWeight, 0.0)); }
+  void setLevelOfDiagonalLoading(unsigned fbinX, float diagonalWeight) { dsr_throw(dsr_mccowan_stream_set_noise(_h, 2, (int) fbinX, 0, (int) _C, diagonalWeight, 0.0)); }
+  void divideAllNonDiagonalElements(float myu) { dsr_throw(dsr_mccowan_stream_set_noise(_h, 3, 0, 0, (int) _C, myu, 0.0)); }
+ protected:
+  McCowanPostFilter(VectorComplexFeatureStreamPtr& output) : _s(output), _C(0) {}
+  VectorComplexFeatureStreamPtr _s; std::vector<VectorComplexFeatureStreamPtr> _chans; unsigned _C = 0;
+};
+class LefkimmiatisPostFilter : public McCowanPostFilter {
+ public:
+  LefkimmiatisPostFilter(VectorComplexFeatureStreamPtr& output, unsigned fftLen, double minSV = 1.0E-8, unsigned fbinX1 = 0, double alpha = 0.6, int type = 2,
+                         int minFrames = 0, float threshold = 0.99f, const String& nm = "LefkimmiatisPostFilte")
+  : McCowanPostFilter(output) { DSR_OP(LefkimmiatisPostFilter, cplx, dsr_lefkimmiatis_stream_create(output->handle(), (int) fftLen, minSV, (int) fbinX1, alpha, type, minFrames, threshold, nm.c_str(), &h)) }
+  void calcInverseNoiseSpatialSpectralMatrix() {}          // implied: refreshed whenever the coherence matrices or the manifold change
+};
+
+// ---- btk/dereverberation/dereverberation.h:89-174
+class MultiChannelWPEDereverberation {
+ public:
+  MultiChannelWPEDereverberation(unsigned subbandsN, unsigned channelsN, unsigned lowerN, unsigned upperN, unsigned iterationsN = 2, double loadDb = -20.0,
+                                 double bandWidth = 0.0, double sampleRate = 16000.0)
+  : _subbandsN(subbandsN), _channelsN(channelsN), _lowerN(lowerN), _upperN(upperN), _iterationsN(iterationsN), _loadDb(loadDb), _bandWidth(bandWidth),
+    _sampleRate(sampleRate), _first(-1)
+  { if (bandWidth > sampleRate / 2.0) throw jdimension_error("Bandwidth is greater than the Nyquist rate.\n"); }
+  unsigned size() const { return _subbandsN; }
+  void setInput(VectorComplexFeatureStreamPtr& samples) { if (_sources.size() == _channelsN) throw jallocation_error("Channel capacity exceeded."); _sources.push_back(samples); }
+  void reset() { _first = -1; for (size_t i = 0; i < _features.size(); i++) dsr_throw(dsr_stream_reset(_features[i])); }
+  void nextSpeaker() { reset(); }
+ private:
+  friend class MultiChannelWPEDereverberationFeature;
+  // the channel whose feature asks for a frame first decides the filter all channels go through (dereverberation.cc:381)
+  void asked(int channelX) { if (_first < 0) { _first = channelX; for (size_t i = 0; i < _features.size(); i++) dsr_throw(dsr_wpe_multi_feature_set_filter_channel(_features[i], channelX)); } }
+  unsigned _subbandsN, _channelsN, _lowerN, _upperN, _iterationsN; double _loadDb, _bandWidth, _sampleRate; int _first;
+  std::vector<VectorComplexFeatureStreamPtr> _sources; std::vector<dsr_stream*> _features;
+};
+typedef std::shared_ptr<MultiChannelWPEDereverberation> MultiChannelWPEDereverberationPtr;
+class MultiChannelWPEDereverberationFeature : public VectorComplexFeatureStream {
+ public:
+  MultiChannelWPEDereverberationFeature(MultiChannelWPEDereverberationPtr& source, unsigned channelX, const String& nm = "MultiChannelWPEDereverberationFeature")
+  : _source(source), _channelX((int) channelX) {
+    std::vector<dsr_stream*> in; for (size_t i = 0; i < source->_sources.size(); i++) in.push_back(source->_sources[i]->handle());
+    DSR_OP(MultiChannelWPEDereverberationFeature, cplx, dsr_wpe_multi_feature_create(in.data(), (int) in.size(), (int) channelX, (int) source->_lowerN, (int) source->_upperN,
+           (int) source->_iterationsN, source->_loadDb, source->_bandWidth, source->_sampleRate, nm.c_str(), &h))
+    source->_features.push_back(_h);
+    if (source->_first >= 0) dsr_throw(dsr_wpe_multi_feature_set_filter_channel(_h, source->_first));
+  }
+  const std::complex<double>* next(int frameX = -5) { _source->asked(_channelX); return VectorComplexFeatureStream::next(frameX); }
+  void reset() { _source->reset(); }
+ private: MultiChannelWPEDereverberationPtr _source; int _channelX;
+};
+
 // ---- btk/modulated/modulated.h
 class NormalFFTAnalysisBank : public VectorComplexFeatureStream {
  public:
