@@ -55,6 +55,7 @@ __global__ __launch_bounds__(256) void k_gmm_exact(const float* __restrict__ x, 
   // scores of a chunk's codebooks (at most kTW) wait in an LDS tile [256 frames][kTW + 1] and leave as 64-byte row segments: a thread
   // storing its own frame's scores one by one would write 4 bytes per lane at a stride of K floats, every store a partial line
   float* tile = sv + (size_t) chunkG * DP;
+  unsigned char* tileI = reinterpret_cast<unsigned char*>(tile + 256 * (kTW + 1));     // [256][kTW + 4] nearest-Gaussian indices, same way
   const long n = (long) blockIdx.x * blockDim.x + threadIdx.x;
   const bool live = n < N;
   float xr[DP];
@@ -87,7 +88,7 @@ __global__ __launch_bounds__(256) void k_gmm_exact(const float* __restrict__ x, 
         float sc = (float) (0.5 * (double) __fadd_rn(minDist, __fmul_rn(2.0f, val[off[kk] + minIdx])));
         const float s = scale[kk]; if (s != 1.0f) sc = __fmul_rn(sc, s);
         tile[threadIdx.x * (kTW + 1) + (kk - k)] = sc;
-        if (argmin) argmin[n * K + kk] = (unsigned char) minIdx;
+        if (argmin) tileI[threadIdx.x * (kTW + 4) + (kk - k)] = (unsigned char) minIdx;
       }
     }
     __syncthreads();
@@ -95,7 +96,10 @@ __global__ __launch_bounds__(256) void k_gmm_exact(const float* __restrict__ x, 
       const int nk = k1 - k, col = threadIdx.x & (kTW - 1), r0 = threadIdx.x / kTW;
       const long nb = (long) blockIdx.x * blockDim.x;
       if (col < nk)
-        for (int r = r0; r < 256; r += 256 / kTW) if (nb + r < N) score[(nb + r) * K + k + col] = tile[r * (kTW + 1) + col];
+        for (int r = r0; r < 256; r += 256 / kTW) if (nb + r < N) {
+          score[(nb + r) * K + k + col] = tile[r * (kTW + 1) + col];
+          if (argmin) argmin[(nb + r) * K + k + col] = tileI[r * (kTW + 4) + col];
+        }
     }
     k = k1;
   }
@@ -287,7 +291,7 @@ dsr_status dsr_gmm_score(dsr_gmm* m, const float* x, int64_t N, int mode, float*
     if (mode == 0) {
       // (20 KB of parameters = 16 codebooks of 4 Gaussians at 40 dims = one score tile; A/B 24 / 20 / 16 KB: 16.4 / 14.9 / 15.7 ms)
       int chunkG = (getenv("DSR_GMM_CHUNKKB") ? atoi(getenv("DSR_GMM_CHUNKKB")) : 20) * 1024 / (2 * m->Dp * 4); if (chunkG < m->maxRef) chunkG = m->maxRef;
-      const size_t lds = (size_t) chunkG * m->Dp * 2 * sizeof(float) + (size_t) 256 * (kTW + 1) * sizeof(float);
+      const size_t lds = (size_t) chunkG * m->Dp * 2 * sizeof(float) + (size_t) 256 * (kTW + 1) * sizeof(float) + (argmin ? (size_t) 256 * (kTW + 4) : 0);     // (the index tile only when indices are asked for: it costs a workgroup per CU)
       if (lds > 160 * 1024) throw Error(DSR_E_DIMENSION, "codebook too large for LDS staging");
       dim3 grid(cdiv(N, 256));
 #define LAUNCH(DPV) { DSR_HIP(hipFuncSetAttribute((const void*) k_gmm_exact<DPV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds)); \
