@@ -29,6 +29,11 @@ struct BfState {
   std::vector<zc> eff;     // [M/2+1][C] weights in use
   DevBuf<float2> d_w;      // [M/2+1][C]
   bool dirty = true;
+  // SubbandGSCRLS (beamformer.h:213-262): recursive-least-squares adaptation of the active weights
+  bool rlsOn = false, rlsAdapt = true, haveP0 = false; double rlsMyu = 0.9, rlsAlpha = -1.0; int rlsQc = 0;
+  std::vector<double> rlsDiag;   // [M/2+1] _diagonalWeights (the constructor's sigma2)
+  std::vector<zc> rlsP0;         // [M/2+1][C-1][C-1] precision matrices every utterance starts from
+  DevBuf<double2> d_wq, d_B, d_P0, d_state; DevBuf<double> d_diag; bool rlsDirty = true;
 };
 
 // Hestenes one-sided Jacobi SVD, complex<float>, square n x n, column-major a(i,j)=a[i+j*n].
@@ -192,7 +197,113 @@ __global__ __launch_bounds__(256) void k_bf_apply(const float2* __restrict__ X, 
 }  // namespace dsr
 
 using namespace dsr;
+
+// SubbandGSCRLS::next + _updateActiveWeightVector2 (beamformer.cc:1554-1698).  One thread owns one (utterance, bin) and walks the frames: the
+// frame's output with the weights as they stand, then Z = B^H X, the gain vector, the precision matrix and the active weights (quadratic
+// constraint optional), all fp64 in the reference's order of operations; precision matrix and active weights live in a state array
+// [entry][utterance x bin] (coalesced across the threads of a wave).  Every utterance starts from P0 and wa = 0.
+__device__ __forceinline__ double2 cdiv_gsl2(double ar, double ai, double br, double bi)
+{ const double s = 1.0 / hypot(br, bi); const double sbr = s * br, sbi = s * bi; return make_double2((ar * sbr + ai * sbi) * s, (ai * sbr - ar * sbi) * s); }
+__device__ __forceinline__ double2 cmul2(double2 a, double2 b) { return make_double2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
+__device__ __forceinline__ double2 cmulc2(double2 a, double2 b) { return make_double2(a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y); }     // a conj(b)
+
+// (CT: compile-time channel count -- the small vectors then live in registers and the loops unroll; 0: run-time count, arrays in scratch)
+template <int CT>
+__global__ __launch_bounds__(64) void k_gsc_rls(const float2* __restrict__ X, const double2* __restrict__ wq, const double2* __restrict__ B,
+                                                const double2* __restrict__ P0, const double* __restrict__ diagW, double2* __restrict__ state,
+                                                float2* __restrict__ Y, double2* __restrict__ waOut, int U, int Crt, int Tmax, int F, double rmu,
+                                                double alpha, int qctype, int adapt, int normalize, int ldsState)
+{
+  const int C = CT ? CT : Crt;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const long tix = (long) blockIdx.x * blockDim.x + threadIdx.x;
+  if (tix >= (long) U * F) return;
+  const int u = (int) (tix / F), f = (int) (tix - (long) u * F), n = C - 1;
+  // the adaptation state of a thread, entry e at P[e * S]: in LDS ([entry][lane], conflict free) when (n^2 + n) x 16 B x 64 lanes fit, else in memory
+  const long S = ldsState ? 64 : (long) U * F;
+  const float2* Xu = X + (long) u * C * Tmax * F; float2* Yu = Y + (long) u * Tmax * F;
+  const double2* wqf = wq + (long) f * C; const double2* Bf = B + (long) f * C * n;
+  double2* P = ldsState ? reinterpret_cast<double2*>(smem) + threadIdx.x : state + tix; double2* wa = P + (long) n * n * S;
+  constexpr int CA = CT ? CT : 16;
+  double2 x[CA], w[CA], Z[CA], PH[CA], g[CA], wn[CA];
+  if (f > 0) { for (int e = 0; e < n * n; e++) P[(long) e * S] = P0[(long) f * n * n + e]; for (int j = 0; j < n; j++) wa[(long) j * S] = make_double2(0.0, 0.0); }
+  const double dw = diagW[f];
+  for (int t = 0; t < Tmax; t++) {
+    for (int c = 0; c < C; c++) { const float2 v = Xu[((long) c * Tmax + t) * F + f]; x[c] = make_double2((double) v.x, (double) v.y); }
+    double2 y = make_double2(0.0, 0.0);
+    if (f == 0) { for (int c = 0; c < C; c++) { const double2 q = cmulc2(x[c], wqf[c]); y.x += q.x; y.y += q.y; } }
+    else {
+      double nrm = 0.0;
+      for (int i = 0; i < C; i++) {
+        double2 wl = make_double2(0.0, 0.0);
+        for (int j = 0; j < n; j++) { const double2 q = cmul2(Bf[i * n + j], wa[(long) j * S]); wl.x += q.x; wl.y += q.y; }
+        w[i] = make_double2(wqf[i].x - wl.x, wqf[i].y - wl.y); nrm += w[i].x * w[i].x + w[i].y * w[i].y;
+      }
+      if (normalize) { nrm = sqrt(nrm) * (double) C; for (int i = 0; i < C; i++) { w[i].x /= nrm; w[i].y /= nrm; } }
+      for (int c = 0; c < C; c++) { const double2 q = cmulc2(x[c], w[c]); y.x += q.x; y.y += q.y; }
+    }
+    Yu[(long) t * F + f] = make_float2((float) y.x, (float) y.y);
+    if (f == 0 || !adapt) continue;
+    for (int j = 0; j < n; j++) { double2 a = make_double2(0.0, 0.0); for (int c = 0; c < C; c++) { const double2 q = cmulc2(x[c], Bf[c * n + j]); a.x += q.x; a.y += q.y; } Z[j] = a; }
+    for (int j = 0; j < n; j++) { double2 a = make_double2(0.0, 0.0); for (int i = 0; i < n; i++) { const double2 q = cmulc2(Z[i], P[(long) (i * n + j) * S]); a.x += q.x; a.y += q.y; } PH[j] = a; }
+    for (int i = 0; i < n; i++) { double2 a = make_double2(0.0, 0.0); for (int j = 0; j < n; j++) { const double2 q = cmul2(P[(long) (i * n + j) * S], Z[j]); a.x += q.x; a.y += q.y; } g[i] = make_double2(a.x * rmu, a.y * rmu); }
+    double2 de = make_double2(0.0, 0.0);
+    for (int j = 0; j < n; j++) { const double2 q = cmulc2(Z[j], PH[j]); de.x += q.x; de.y += q.y; }
+    de = make_double2(de.x * rmu + 1.0, de.y * rmu);
+    for (int i = 0; i < n; i++) g[i] = cdiv_gsl2(g[i].x, g[i].y, de.x, de.y);
+    for (int i = 0; i < n; i++)
+      for (int j = 0; j < n; j++) {
+        const double2 o = P[(long) (i * n + j) * S], q = cmulc2(g[i], PH[j]);
+        P[(long) (i * n + j) * S] = make_double2((o.x - q.x) * rmu, (o.y - q.y) * rmu);
+      }
+    const double2 epA = make_double2(y.x, -y.y);
+    for (int i = 0; i < n; i++) {
+      double2 a = make_double2(0.0, 0.0);
+      for (int j = 0; j < n; j++) {
+        const double2 p = P[(long) (i * n + j) * S]; double2 m1 = make_double2(p.x * (-dw), p.y * (-dw)); if (i == j) m1.x += 1.0;
+        const double2 q = cmul2(m1, wa[(long) j * S]); a.x += q.x; a.y += q.y;
+      }
+      const double2 q = cmul2(g[i], epA); wn[i] = make_double2(a.x + q.x, a.y + q.y);
+    }
+    if (qctype == 1 || qctype == 2) {
+      double nr = 0.0; for (int i = 0; i < n; i++) nr += wn[i].x * wn[i].x + wn[i].y * wn[i].y;
+      nr = sqrt(nr);
+      if (qctype == 1 || nr * nr >= alpha) { const double sc = alpha / nr; for (int i = 0; i < n; i++) { wn[i].x *= sc; wn[i].y *= sc; } }
+    }
+    for (int i = 0; i < n; i++) wa[(long) i * S] = wn[i];
+  }
+  if (waOut && f > 0) for (int j = 0; j < n; j++) waOut[((long) u * F + f) * n + j] = wa[(long) j * S];
+  if (waOut && f == 0) for (int j = 0; j < n; j++) waOut[((long) u * F) * n + j] = make_double2(0.0, 0.0);
+}
+
 struct dsr_bf : BfState {};
+
+
+static void gsc_rls_apply(BfState& s, const float* X, int U, int Tmax, float* Y, double* waOut, hipStream_t st)
+{
+  if (!s.haveB) throw Error(DSR_E_ERROR, "call calcGSCWeightsX() once");                                                    // beamformer.cc:1562-1565
+  if (!s.haveP0) throw Error(DSR_E_ERROR, "set the precision matrix with initPrecisionMatrix() or setPrecisionMatrix()");   // :1566-1569
+  if (s.halfBandShift) throw Error(DSR_E_ERROR, "not yet implemented");                                                     // :1580-1583
+  if (s.C > 16) throw Error(DSR_E_DIMENSION, "SubbandGSCRLS: at most 16 channels (%d)", s.C);
+  if (U <= 0 || Tmax <= 0) return;
+  const int C = s.C, n = C - 1, F = s.M / 2 + 1;
+  if (s.rlsDirty || s.dirty) {
+    std::vector<double2> a((size_t) F * C), b((size_t) F * C * n), p((size_t) F * n * n);
+    for (size_t i = 0; i < a.size(); i++) a[i] = make_double2(s.wq[i].real(), s.wq[i].imag());
+    for (size_t i = 0; i < b.size(); i++) b[i] = make_double2(s.B[i].real(), s.B[i].imag());
+    for (size_t i = 0; i < p.size(); i++) p[i] = make_double2(s.rlsP0[i].real(), s.rlsP0[i].imag());
+    s.d_wq.upload(a); s.d_B.upload(b); s.d_P0.upload(p); s.d_diag.upload(s.rlsDiag); s.rlsDirty = false;
+  }
+  const long S = (long) U * F;
+  const size_t ldsB = (size_t) (n * n + n) * 16 * 64; const int ldsState = (ldsB <= 150 * 1024 && !getenv("DSR_RLS_MEMSTATE")) ? 1 : 0;
+  s.d_state.reserve(ldsState ? 16 : (size_t) S * (n * n + n));
+#define RLS_LAUNCH(CTV) { if (ldsState) DSR_HIP(hipFuncSetAttribute((const void*) k_gsc_rls<CTV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) ldsB)); \
+  hipLaunchKernelGGL(k_gsc_rls<CTV>, dim3((unsigned) ((S + 63) / 64)), dim3(64), ldsState ? ldsB : 0, st, (const float2*) X, s.d_wq.p, s.d_B.p, s.d_P0.p, s.d_diag.p, s.d_state.p, \
+                     (float2*) Y, (double2*) waOut, U, C, Tmax, F, 1.0 / s.rlsMyu, s.rlsAlpha, s.rlsQc, s.rlsAdapt ? 1 : 0, s.mode == 3 ? 1 : 0, ldsState); }
+  if (C == 8) RLS_LAUNCH(8) else if (C == 4) RLS_LAUNCH(4) else if (C == 6) RLS_LAUNCH(6) else RLS_LAUNCH(0)
+#undef RLS_LAUNCH
+  DSR_HIP(hipGetLastError());
+}
 
 extern "C" {
 
@@ -349,6 +460,7 @@ dsr_status dsr_bf_apply(dsr_bf* s, const float* X, int U, int Tmax, float* Y, vo
   return guard([&] {
     if (!s || !X || !Y) throw Error(DSR_E_PARAMETER, "null argument");
     require_device();
+    if (s->rlsOn) { gsc_rls_apply(*s, X, U, Tmax, Y, nullptr, (hipStream_t) stream); return; }
     if (s->dirty) refresh_effective(*s);
     if (U <= 0 || Tmax <= 0) return;
     const int F = s->M / 2 + 1; const long perUtt = (long) Tmax * F;
@@ -359,6 +471,58 @@ dsr_status dsr_bf_apply(dsr_bf* s, const float* X, int U, int Tmax, float* Y, vo
     hipLaunchKernelGGL(k_bf_apply, dim3(gx, U), dim3(256), lds, (hipStream_t) stream, (const float2*) X, s->d_w.p, (float2*) Y,
                        s->C, Tmax, F, perUtt);
     DSR_HIP(hipGetLastError());
+  });
+}
+
+
+// SubbandGSCRLS(fftLen, halfBandShift, myu, sigma2) (beamformer.h:230-262).  rls_config switches dsr_bf_apply to the recursive-least-squares
+// GSC (the object must hold GSC weights: calcGSCWeights); sigma2 is the constructor's diagonal weight of the active-weight update.
+dsr_status dsr_bf_rls_config(dsr_bf* s, float myu, float sigma2)
+{
+  return guard([&] {
+    if (!s) throw Error(DSR_E_PARAMETER, "null argument");
+    if (!(myu > 0.0f)) throw Error(DSR_E_PARAMETER, "the forgetting factor must be positive (%g)", (double) myu);
+    s->rlsOn = true; s->rlsMyu = (double) myu; s->rlsDiag.assign((size_t) s->M / 2 + 1, (double) sigma2); s->rlsDirty = true;
+    if (s->mode < 2) s->mode = 2;
+  });
+}
+// initPrecisionMatrix(sigma2): P = I / sigma2 for every bin, active weights zeroed (beamformer.cc:1526-1538)
+dsr_status dsr_bf_rls_init_precision(dsr_bf* s, float sigma2)
+{
+  return guard([&] {
+    if (!s) throw Error(DSR_E_PARAMETER, "null argument");
+    if (!s->haveB) throw Error(DSR_E_ERROR, "call calcGSCWeightsX() once");
+    const int n = s->C - 1, F = s->M / 2 + 1;
+    s->rlsP0.assign((size_t) F * n * n, zc(0, 0));
+    for (int f = 0; f < F; f++) for (int i = 0; i < n; i++) s->rlsP0[((size_t) f * n + i) * n + i] = zc((double) (1 / sigma2), 0.0);
+    std::fill(s->wa.begin(), s->wa.end(), zc(0, 0));
+    s->haveP0 = true; s->rlsDirty = true; s->dirty = true;
+  });
+}
+// setPrecisionMatrix(fbinX, Pz) (:1540-1552); Pz [C-1][C-1] complex128
+dsr_status dsr_bf_rls_set_precision(dsr_bf* s, int fbinX, const double* Pz)
+{
+  return guard([&] {
+    if (!s || !Pz) throw Error(DSR_E_PARAMETER, "null argument");
+    if (!s->haveB) throw Error(DSR_E_ERROR, "call calcGSCWeightsX() once");
+    const int n = s->C - 1, F = s->M / 2 + 1;
+    if (fbinX < 0 || fbinX >= F) throw Error(DSR_E_DIMENSION, "Must be a frequency bin %d <= %d", fbinX, F - 1);
+    if (s->rlsP0.size() != (size_t) F * n * n) s->rlsP0.assign((size_t) F * n * n, zc(0, 0));
+    for (int e = 0; e < n * n; e++) s->rlsP0[(size_t) fbinX * n * n + e] = zc(Pz[2 * e], Pz[2 * e + 1]);
+    s->haveP0 = true; s->rlsDirty = true;
+  });
+}
+dsr_status dsr_bf_rls_quadratic_constraint(dsr_bf* s, float alpha, int qctype)
+{ return guard([&] { if (!s || qctype < 0 || qctype > 2) throw Error(DSR_E_PARAMETER, "bad quadratic constraint type"); s->rlsAlpha = (double) alpha; s->rlsQc = qctype; }); }
+dsr_status dsr_bf_rls_adapt(dsr_bf* s, int flag) { return guard([&] { if (!s) throw Error(DSR_E_PARAMETER, "null argument"); s->rlsAdapt = flag != 0; }); }
+// batch entry with the final active weights: wa_out_dev (optional) [U][M/2+1][C-1] complex128
+dsr_status dsr_bf_gsc_rls(dsr_bf* s, const float* X, int U, int Tmax, float* Y, double* wa_out_dev, void* stream)
+{
+  return guard([&] {
+    if (!s || !X || !Y) throw Error(DSR_E_PARAMETER, "null argument");
+    if (!s->rlsOn) throw Error(DSR_E_ERROR, "not a SubbandGSCRLS object: call dsr_bf_rls_config first");
+    require_device();
+    gsc_rls_apply(*s, X, U, Tmax, Y, wa_out_dev, (hipStream_t) stream);
   });
 }
 

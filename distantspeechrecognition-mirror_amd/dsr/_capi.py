@@ -69,6 +69,8 @@ def load():
         "dsr_bf_set_diffuse_noise_model": [vp, vp, f64, f64], "dsr_bf_divide_nondiagonal": [vp, f32],
         "dsr_bf_diagonal_loading": [vp, f32], "dsr_bf_set_noise_matrix": [vp, C.c_int, vp],
         "dsr_bf_calc_mvdr_weights": [vp, f64, f64], "dsr_bf_calc_gsc_weights": [vp, f64, vp],
+        "dsr_bf_rls_config": [vp, f32, f32], "dsr_bf_rls_init_precision": [vp, f32], "dsr_bf_rls_set_precision": [vp, C.c_int, vp],
+        "dsr_bf_rls_quadratic_constraint": [vp, f32, C.c_int], "dsr_bf_rls_adapt": [vp, C.c_int], "dsr_bf_gsc_rls": [vp, vp, C.c_int, C.c_int, vp, vp, vp],
         "dsr_bf_set_active_weights": [vp, C.c_int, vp], "dsr_bf_zero_active_weights": [vp], "dsr_bf_select": [vp, C.c_int],
         "dsr_bf_get": [vp, C.c_int, vp, C.c_size_t], "dsr_bf_apply": [vp, vp, C.c_int, C.c_int, vp, vp],
         "dsr_prfb_create": [vp, C.c_int, C.c_int, C.c_int, vp], "dsr_prfb_destroy": [vp], "dsr_prfb_fft_len": [vp], "dsr_prfb_block_len": [vp],
@@ -236,6 +238,34 @@ class Beamformer:
         out = np.zeros(shape, np.complex128)
         check(_lib.dsr_bf_get(self.h, kind, _ptr(out), out.size * 2))
         return out
+
+    # SubbandGSCRLS (beamformer.h:213-262): recursive-least-squares adaptation of the active weights
+    def rlsConfig(self, myu=0.9, sigma2=0.0):
+        check(_lib.dsr_bf_rls_config(self.h, myu, sigma2))
+
+    def initPrecisionMatrix(self, sigma2=0.01):
+        check(_lib.dsr_bf_rls_init_precision(self.h, sigma2))
+
+    def setPrecisionMatrix(self, fbinX, Pz):
+        p = np.ascontiguousarray(Pz, np.complex128)
+        if p.shape != (self.C - 1, self.C - 1):
+            raise DsrError(5, "the precision matrix must be %d x %d" % (self.C - 1, self.C - 1))
+        check(_lib.dsr_bf_rls_set_precision(self.h, fbinX, _ptr(p)))
+
+    def setQuadraticConstraint(self, alpha, qctype=1):
+        check(_lib.dsr_bf_rls_quadratic_constraint(self.h, alpha, qctype))
+
+    def updateActiveWeightVecotrs(self, flag):
+        check(_lib.dsr_bf_rls_adapt(self.h, int(bool(flag))))
+
+    def gsc_rls(self, X):
+        """X: cuda complex64 [U][C][T][F] -> (Y [U][T][F], final active weights [U][F][C-1] complex128)"""
+        import torch
+        U, Cn, T, F = X.shape
+        Y = torch.empty((U, T, F, 2), dtype=torch.float32, device=X.device)
+        wa = torch.zeros((U, F, Cn - 1), dtype=torch.complex128, device=X.device)
+        check(_lib.dsr_bf_gsc_rls(self.h, _dev(torch.view_as_real(X.contiguous())), U, T, _dev(Y), _dev(wa), cur_stream()))
+        return torch.view_as_complex(Y), wa
 
     def apply(self, X):
         """X: cuda complex64 [U][C][T][F] -> [U][T][F]"""

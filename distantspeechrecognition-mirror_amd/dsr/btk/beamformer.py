@@ -1,4 +1,4 @@
-"""btk.beamformer: SubbandDSPtr / SubbandGSCPtr / SubbandMVDRPtr (beamformer.i:298-323) as streams."""
+"""btk.beamformer: SubbandDSPtr / SubbandGSCPtr / SubbandGSCRLSPtr / SubbandMVDRPtr (beamformer.i:227-323) as streams."""
 import numpy as np
 
 from .. import _capi as K
@@ -54,6 +54,30 @@ class SubbandGSCPtr(_Subband):
 
     def zeroActiveWeights(self):
         self._weights().zeroActiveWeights()
+
+
+class SubbandGSCRLSPtr(SubbandGSCPtr):
+    """beamformer.i:227-253 (SubbandGSCRLS, beamformer.cc:1497-1698).  Every reset() starts again from the precision matrices set
+    with initPrecisionMatrix()/setPrecisionMatrix() and zero active weights; the reference keeps adapting across reset()."""
+
+    def __init__(self, fftLen=512, halfBandShift=False, myu=0.9, sigma2=0.01, nm="SubbandGSCRLS"):
+        SubbandGSCPtr.__init__(self, fftLen, halfBandShift, nm); self._myu, self._sigma2 = myu, sigma2
+
+    def calcGSCWeights(self, sampleRate, delaysT):
+        SubbandGSCPtr.calcGSCWeights(self, sampleRate, delaysT)
+        self._weights().rlsConfig(self._myu, self._sigma2)
+
+    def initPrecisionMatrix(self, sigma2=0.01):
+        self._weights().initPrecisionMatrix(sigma2)
+
+    def setPrecisionMatrix(self, fbinX, Pz):
+        self._weights().setPrecisionMatrix(fbinX, Pz)
+
+    def setQuadraticConstraint(self, alpha, qctype=1):
+        self._weights().setQuadraticConstraint(alpha, qctype)
+
+    def updateActiveWeightVecotrs(self, flag):
+        self._weights().updateActiveWeightVecotrs(flag)
 
 
 class SubbandMVDRPtr(_Subband):

@@ -243,6 +243,22 @@ def gsc_apply(X, wq, B, wa, normalize=False):
     return Y
 
 
+def gsc_rls(X, wq, B, myu=0.9, sigma2=0.0, sigma2init=0.01, alpha=-1.0, qctype=0, adapt=True, normalize=False, P0=None):
+    """SubbandGSCRLS (beamformer.cc:1497-1698): X [C][T][M], wq [M][C], B [M/2+1][C][C-1] -> (Y [T][M], final wa [M/2+1][C-1]).
+    sigma2 = the constructor's diagonal weight, sigma2init = initPrecisionMatrix's argument (P0 overrides: [M/2+1][n][n])."""
+    X = np.ascontiguousarray(X, dtype=np.complex128); Cn, T, M = X.shape; n = Cn - 1; F = M // 2 + 1
+    wq = np.ascontiguousarray(wq, dtype=np.complex128); B = np.ascontiguousarray(B, dtype=np.complex128)
+    if P0 is None:
+        P0 = np.broadcast_to(np.eye(n, dtype=np.complex128) * float(np.float32(1.0) / np.float32(sigma2init)), (F, n, n))   # 1/sigma2 is a float division (:1534)
+    P0 = np.ascontiguousarray(P0, dtype=np.complex128)
+    dw = np.full(F, np.float32(sigma2), np.float64)
+    Y = np.zeros((T, M), np.complex128); wa = np.zeros((F, n), np.complex128)
+    L = lib(); L.orc_gsc_rls.restype = None
+    L.orc_gsc_rls(_p(X), _p(wq), _p(B), _p(P0), _p(dw), Cn, T, M, C.c_double(float(np.float32(myu))), C.c_double(float(np.float32(alpha))), int(qctype), int(bool(adapt)),
+                  int(bool(normalize)), _p(Y), _p(wa))
+    return Y, wa
+
+
 # ------------------------------------------------------------------ MFCC chain
 def zelinski_postfilter(X, Y, wq, alpha=0.6, type=2, minFrames=0):
     """X [C][T][F], Y [T][F], wq [F][C] complex -> (out [T][F] complex128, wp1 [T][F]) (postfilter.cc:56-221,428-493)."""

@@ -85,6 +85,9 @@ void orc_beamform_apply(const double* X, const double* W, int C, int T, int M, d
 int  orc_blocking_matrix(const double* d /*[C][2]*/, int C, double* B /*[C][C-1][2]*/);
 void orc_gsc_apply(const double* X, const double* wq, const double* B, const double* wa,
                    int C, int T, int M, int normalize, double* Y);
+/* SubbandGSCRLS (beamformer.cc:1497-1698) */
+void orc_gsc_rls(const double* X, const double* wq, const double* B, const double* P0, const double* diagW, int C, int T, int M, double myu,
+                 double alpha, int qctype, int adapt, int normalize, double* Y, double* waOut);
 
 /* ---------------- MFCC chain (btk/feature/feature.cc) ---------------- */
 int  orc_sample_num_blocks(int nsamp, int blockLen, int shiftLen, int padZeros);

@@ -272,3 +272,70 @@ void orc_gsc_apply(const double* X, const double* wq, const double* B, const dou
   orc_beamform_apply(X, W, C, T, M, Y);
   free(W);
 }
+
+static void cdiv_gsl_b(double ar, double ai, double br, double bi, double* zr, double* zi)
+{ /* gsl_complex_div: s = 1/|b|, scaled operands (gsl complex/math.c) */
+  const double s = 1.0 / hypot(br, bi);
+  const double sbr = s * br, sbi = s * bi;
+  *zr = (ar * sbr + ai * sbi) * s; *zi = (ai * sbr - ar * sbi) * s;
+}
+
+/* SubbandGSCRLS (beamformer.h:213-262; beamformer.cc:1497-1698): the GSC whose active weight vectors follow a recursive-least-squares update
+ * after every frame (_updateActiveWeightVector2 :1627-1698, notation of Van Trees pp. 766-767):
+ *   Z = B^H X;  g = (P Z / mu) / (1 + Z^H P Z / mu)  [written as zdotc(P^H Z, Z)];  P <- (P - g (P^H Z)^H) / mu;
+ *   wa <- (I - sigma2 P) wa + g conj(Y);  quadratic constraint (CONSTANT_NORM 1: wa <- wa alpha/||wa||; THRESHOLD_LIMITATION 2: the same when
+ *   ||wa||^2 >= alpha);  wl = B wa.
+ * The frame's output uses the weights BEFORE the update; bin 0 is wq^H X and is never adapted (:1590-1611).  Every utterance starts from
+ * P = P0 (initPrecisionMatrix: I / sigma2init, or setPrecisionMatrix) and wa = 0 -- the reference keeps adapting across reset().
+ * X: [C][T][M] complex, wq: [M][C] (rows 0..M/2 used), B: [M/2+1][C][C-1], P0: [M/2+1][n][n] (n = C-1), diagW: [M/2+1] -> Y [T][M] (bins above
+ * M/2 mirrored), waOut (optional) [M/2+1][n] final active weights. */
+void orc_gsc_rls(const double* X, const double* wq, const double* B, const double* P0, const double* diagW, int C, int T, int M, double myu,
+                 double alpha, int qctype, int adapt, int normalize, double* Y, double* waOut)
+{
+  const int n = C - 1, F = M / 2 + 1;
+  zc* P = (zc*) malloc(sizeof(zc) * (size_t) F * n * n); zc* wa = (zc*) calloc((size_t) F * n, sizeof(zc));
+  zc* Z = (zc*) malloc(sizeof(zc) * n); zc* PH = (zc*) malloc(sizeof(zc) * n); zc* g = (zc*) malloc(sizeof(zc) * n); zc* wn = (zc*) malloc(sizeof(zc) * n);
+  zc* w = (zc*) malloc(sizeof(zc) * C);
+  for (size_t i = 0; i < (size_t) F * n * n; i++) P[i] = ZGET(P0, i);
+  const double rmu = 1.0 / myu;
+  for (int t = 0; t < T; t++) {
+    for (int f = 0; f < F; f++) {
+      const double* Bf = B + (size_t) f * C * n * 2; zc* Pf = P + (size_t) f * n * n; zc* waf = wa + (size_t) f * n;
+      zc y = 0.0;
+      if (f == 0) { for (int c = 0; c < C; c++) y += conj(ZGET(wq, c)) * ZGET(X, ((size_t) c * T + t) * M); }
+      else {
+        double nrm = 0.0;
+        for (int i = 0; i < C; i++) {
+          zc wl = 0.0; for (int j = 0; j < n; j++) wl += ZGET(Bf, (size_t) i * n + j) * waf[j];
+          w[i] = ZGET(wq, (size_t) f * C + i) - wl; nrm += creal(w[i] * conj(w[i]));
+        }
+        if (normalize) { nrm = sqrt(nrm); for (int i = 0; i < C; i++) w[i] = w[i] / (nrm * C); }
+        for (int c = 0; c < C; c++) y += conj(w[c]) * ZGET(X, ((size_t) c * T + t) * M + f);
+      }
+      ZSET(Y, (size_t) t * M + f, y);
+      if (f > 0 && f < M / 2) ZSET(Y, (size_t) t * M + (M - f), conj(y));
+      if (f == 0 || !adapt) continue;
+      for (int j = 0; j < n; j++) { zc a = 0.0; for (int c = 0; c < C; c++) a += conj(ZGET(Bf, (size_t) c * n + j)) * ZGET(X, ((size_t) c * T + t) * M + f); Z[j] = a; }
+      for (int j = 0; j < n; j++) { zc a = 0.0; for (int i = 0; i < n; i++) a += conj(Pf[i * n + j]) * Z[i]; PH[j] = a; }
+      for (int i = 0; i < n; i++) { zc a = 0.0; for (int j = 0; j < n; j++) a += Pf[i * n + j] * Z[j]; g[i] = a * rmu; }
+      zc de = 0.0; for (int j = 0; j < n; j++) de += conj(PH[j]) * Z[j];
+      de = de * rmu + 1.0;
+      for (int i = 0; i < n; i++) { double qr, qi; cdiv_gsl_b(creal(g[i]), cimag(g[i]), creal(de), cimag(de), &qr, &qi); g[i] = qr + qi * I; }
+      for (int i = 0; i < n; i++) for (int j = 0; j < n; j++) Pf[i * n + j] = (Pf[i * n + j] - g[i] * conj(PH[j])) * rmu;
+      const zc epA = conj(y);
+      for (int i = 0; i < n; i++) {
+        zc a = 0.0;
+        for (int j = 0; j < n; j++) { zc m1 = Pf[i * n + j] * (-diagW[f]); if (i == j) m1 += 1.0; a += m1 * waf[j]; }
+        wn[i] = a + g[i] * epA;
+      }
+      if (qctype == 1 || qctype == 2) {
+        double nr = 0.0; for (int i = 0; i < n; i++) nr += creal(wn[i] * conj(wn[i]));
+        nr = sqrt(nr);
+        if (qctype == 1 || nr * nr >= alpha) for (int i = 0; i < n; i++) wn[i] = wn[i] * (alpha / nr);
+      }
+      for (int i = 0; i < n; i++) waf[i] = wn[i];
+    }
+  }
+  if (waOut) for (size_t i = 0; i < (size_t) F * n; i++) ZSET(waOut, i, wa[i]);
+  free(P); free(wa); free(Z); free(PH); free(g); free(wn); free(w);
+}

@@ -904,6 +904,84 @@ def test_wpe_multi(dsr, oracle, cuda, Cn, lowerN, upperN, iters, loadDb, bw, fc)
     assert got.shape == wo.shape and np.abs(got - wo).max() <= 4e-6 * np.abs(wo).max()
 
 
+# ------------------------------------------------------------------------------------------- adaptive beamformers
+@pytest.mark.gpu
+@pytest.mark.parametrize("Cn,myu,sigma2,qc,alpha,mode", [(4, 0.9, 0.0, 0, -1.0, "gsc"), (8, 0.95, 0.01, 2, 0.05, "gsc"), (5, 0.8, 0.001, 1, 0.3, "gsc_norm")])
+def test_gsc_rls(dsr, oracle, cuda, Cn, myu, sigma2, qc, alpha, mode):
+    """beamformer.cc:1497-1698: GSC output with the weights as they stand, then the recursive-least-squares update of the precision matrix and
+    the active weights per (utterance, bin), fp64 on the device; summation order of the small matrix-vector products differs from CBLAS:
+    1e-9 relative on the final active weights, 1e-6 of the magnitude on the fp32 output."""
+    import torch
+    rng = np.random.default_rng(90 + Cn)
+    U, T, M = 2, 60, 32
+    F = M // 2 + 1
+    mp = synth.linear_array(Cn)
+    delays = dsr.calcDelaysPolar2(np.float32(0.4), np.float32(np.pi / 2), mp)
+    bf = dsr.Beamformer(M, Cn); bf.calcGSCWeights(16000.0, delays); bf.select(mode); bf.rlsConfig(myu, sigma2)
+    s = rng.standard_normal((U, T, F)) + 1j * rng.standard_normal((U, T, F))
+    wq = bf.get(0); B = bf.get(3)[:F]
+    X = np.stack([s * np.conj(wq[:F, c]) * Cn + 0.7 * (rng.standard_normal((U, T, F)) + 1j * rng.standard_normal((U, T, F))) for c in range(Cn)], axis=1).astype(np.complex64)
+    with pytest.raises(dsr.DsrError):
+        bf.gsc_rls(torch.from_numpy(X).to(cuda))                           # no precision matrix yet (beamformer.cc:1566-1569)
+    bf.initPrecisionMatrix(0.01)
+    if qc:
+        bf.setQuadraticConstraint(alpha, qc)
+    Y, wa = bf.gsc_rls(torch.from_numpy(X).to(cuda))
+    Y, wa = Y.cpu().numpy(), wa.cpu().numpy()
+
+    def full_of(a):            # [C][T][F] -> [C][T][M]
+        f = np.zeros(a.shape[:2] + (M,), np.complex128); f[:, :, :F] = a; f[:, :, F:] = np.conj(a[:, :, 1:F - 1][:, :, ::-1]); return f
+    for u in range(U):
+        Yo, wao = oracle.gsc_rls(full_of(X[u]), wq, B, myu, sigma2, 0.01, alpha, qc, True, mode == "gsc_norm")
+        np.testing.assert_allclose(wa[u][1:], wao[1:], rtol=1e-8, atol=1e-12)
+        assert np.abs(Y[u] - Yo[:, :F]).max() <= 2e-6 * np.abs(Yo).max()
+    fixed = dsr.Beamformer(M, Cn); fixed.calcGSCWeights(16000.0, delays); fixed.select(mode)
+    Y0 = fixed.apply(torch.from_numpy(X).to(cuda)).cpu().numpy()
+    assert np.abs(Y[:, 0] - Y0[:, 0]).max() <= 2e-6 * np.abs(Y0).max()   # the first frame still has zero active weights
+    if qc != 1:                                                            # (a forced norm of the active weights need not help)
+        assert np.abs(Y[:, -20:]).mean() < np.abs(Y0[:, -20:]).mean()    # the adaptation takes noise out
+    bf.updateActiveWeightVecotrs(False)                                   # adaptation off: the fixed GSC
+    Y1, _ = bf.gsc_rls(torch.from_numpy(X).to(cuda))
+    assert np.abs(Y1.cpu().numpy() - Y0).max() <= 2e-6 * np.abs(Y0).max()
+
+
+@pytest.mark.gpu
+def test_gsc_rls_stream(dsr, oracle, cuda):
+    """SubbandGSCRLSPtr (beamformer.i:227-253) behind the stream protocol: setChannel / calcGSCWeights / initPrecisionMatrix / iteration."""
+    from dsr.btk import stream as S, beamformer as Bm
+    rng = np.random.default_rng(17)
+    Cn, T, M = 4, 40, 32
+    F = M // 2 + 1
+    mp = synth.linear_array(Cn)
+    delays = dsr.calcDelaysPolar2(np.float32(0.3), np.float32(np.pi / 2), mp)
+
+    class Frames(object):
+        def __init__(self, a):
+            self.a = a
+
+        def size(self):
+            return self.a.shape[1]
+
+        def __iter__(self):
+            return iter(self.a)
+
+    half = (rng.standard_normal((Cn, T, F)) + 1j * rng.standard_normal((Cn, T, F))).astype(np.complex64)
+    full = np.zeros((Cn, T, M), np.complex128); full[:, :, :F] = half; full[:, :, F:] = np.conj(half[:, :, 1:F - 1][:, :, ::-1])
+    bf = Bm.SubbandGSCRLSPtr(fftLen=M, halfBandShift=False, myu=0.9, sigma2=0.001)
+    for c in range(Cn):
+        bf.setChannel(S.PyVectorComplexFeatureStreamPtr(Frames(full[c])))
+    bf.calcGSCWeights(16000.0, delays)
+    with pytest.raises(dsr.DsrError):
+        bf.next()                                                           # no precision matrix yet
+    bf.reset()
+    bf.initPrecisionMatrix(0.02)
+    bf.setQuadraticConstraint(0.5, 2)
+    rows = np.array([np.array(v) for v in bf])
+    w = bf._weights(); wq = w.get(0); B = w.get(3)[:F]
+    Yo, _ = oracle.gsc_rls(full, wq, B, 0.9, 0.001, 0.02, 0.5, 2, True, False)
+    assert rows.shape == Yo.shape and np.abs(rows - Yo).max() <= 4e-6 * np.abs(Yo).max()
+
+
 # ------------------------------------------------------------------------------------------- BASELINE sizes
 @pytest.mark.gpu
 def test_gmm_full_size(dsr, oracle, cuda):

@@ -501,3 +501,35 @@ def test_wpe_multi_oracle_properties(oracle):
     assert np.array_equal(gn0, gn) and np.array_equal(out0[0], out[0]) and not np.array_equal(out0[1], out[1])
     pred = lags @ np.conj(gn[0, b])
     assert np.abs(out0[1, :, b] - (Y[1, :, b] - np.where(np.arange(N) >= lowerN, pred, 0.0))).max() <= 1e-9
+
+
+def test_gsc_rls_against_numpy(oracle):
+    """beamformer.cc:1627-1698 restated vs numpy matrix algebra: Z = B^H X, g = P Z / (mu + Z^H P Z), P <- (P - g Z^H P) / mu,
+    wa <- (I - sigma2 P) wa + g conj(Y), threshold constraint; the frame's output uses the weights before the update."""
+    rng = np.random.default_rng(6)
+    Cn, T, M, mu, s2, s2i, alpha = 4, 25, 8, 0.9, 0.01, 0.05, 0.2
+    F, n = M // 2 + 1, Cn - 1
+    d = oracle.calc_delays_polar2(np.float32(0.7), np.float32(1.2), synth.linear_array(Cn)); wq = oracle.calc_mainlobe(16000.0, d, M)
+    B = np.array([oracle.blocking_matrix(wq[f])[0] for f in range(F)])
+    X = rng.standard_normal((Cn, T, M)) + 1j * rng.standard_normal((Cn, T, M))
+    Y, waF = oracle.gsc_rls(X, wq, B, mu, s2, s2i, alpha, 2, True, False)
+    muf, s2f, s2if, af = float(np.float32(mu)), float(np.float32(s2)), float(np.float32(s2i)), float(np.float32(alpha))
+    P = [np.eye(n, dtype=complex) * float(np.float32(1.0) / np.float32(s2i)) for _ in range(F)]; wa = np.zeros((F, n), complex)
+    for t in range(T):
+        assert abs(Y[t, 0] - np.vdot(wq[0], X[:, t, 0])) < 1e-12
+        for f in range(1, F):
+            x = X[:, t, f]
+            y = np.vdot(wq[f] - B[f] @ wa[f], x)
+            assert abs(Y[t, f] - y) <= 1e-9 * max(1.0, abs(y)), (t, f)
+            Z = B[f].conj().T @ x
+            PZ = P[f] @ Z; PH = P[f].conj().T @ Z
+            g = (PZ / muf) / (np.vdot(PH, Z) / muf + 1.0)
+            P[f] = (P[f] - np.outer(g, PH.conj())) / muf
+            w2 = (np.eye(n) - s2f * P[f]) @ wa[f] + g * np.conj(y)
+            nr = np.linalg.norm(w2)
+            if nr * nr >= af:
+                w2 = w2 * (af / nr)
+            wa[f] = w2
+    assert np.abs(waF[1:] - wa[1:]).max() <= 1e-9 * max(1.0, np.abs(wa).max())
+    Yoff, _ = oracle.gsc_rls(X, wq, B, mu, s2, s2i, alpha, 2, False, False)
+    assert np.abs(Yoff - oracle.gsc_apply(X, wq, B, np.zeros((F, n), complex))).max() < 1e-12
