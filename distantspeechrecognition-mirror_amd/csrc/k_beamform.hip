@@ -26,6 +26,7 @@ struct BfState {
   std::vector<zc> mvdr;    // [M/2+1][C]
   std::vector<zc> B;       // [M][C][C-1]
   std::vector<zc> wa;      // [M][C-1]
+  std::vector<zc> wl;      // [M][C]  B wa as of the last setActiveWeights_f / zeroActiveWeights (SubbandMVDRGSC reads this cached product)
   std::vector<zc> eff;     // [M/2+1][C] weights in use
   DevBuf<float2> d_w;      // [M/2+1][C]
   bool dirty = true;
@@ -140,6 +141,13 @@ static void blocking_matrix(const zc* d, int C, zc* B)       // NC = 1, beamform
   }
 }
 
+static void update_wl(BfState& s, int f)          // calcSidelobeCancellerP_f / U_f: wl = B wa (beamformer.cc:761-799)
+{
+  const int C = s.C, bs = C - 1;
+  if (s.wl.size() != (size_t) s.M * C) s.wl.assign((size_t) s.M * C, zc(0, 0));
+  for (int i = 0; i < C; i++) { zc a(0, 0); for (int j = 0; j < bs; j++) a += s.B[((size_t) f * C + i) * bs + j] * s.wa[(size_t) f * bs + j]; s.wl[(size_t) f * C + i] = a; }
+}
+
 static void refresh_effective(BfState& s)
 {
   const int M = s.M, C = s.C, F = M / 2 + 1;
@@ -151,6 +159,11 @@ static void refresh_effective(BfState& s)
   } else if (s.mode == 1) {
     if (!s.haveMvdr) throw Error(DSR_E_ERROR, "call calcMVDRWeights() once");                    // :2591-2594
     s.eff = s.mvdr;
+  } else if (s.mode == 4) {                                                                        // SubbandMVDRGSC::next (beamformer.cc:2764-2817)
+    if (!s.haveB) throw Error(DSR_E_ERROR, "call calcArrayManifoldVectorsX() once");
+    if (!s.haveMvdr) throw Error(DSR_E_ERROR, "call calcMVDRWeights() once");
+    for (int c = 0; c < C; c++) s.eff[c] = s.mvdr[c];
+    for (int f = 1; f < F; f++) for (int i = 0; i < C; i++) s.eff[(size_t) f * C + i] = s.mvdr[(size_t) f * C + i] - s.wl[(size_t) f * C + i];
   } else {
     if (!s.haveWq || !s.haveB) throw Error(DSR_E_ERROR, "call calcGSCWeightsX() once");          // :1310-1313
     const int bs = C - 1;
@@ -416,7 +429,7 @@ dsr_status dsr_bf_calc_gsc_weights(dsr_bf* s, double fs, const double* delays)
     if (s->C <= 1) throw Error(DSR_E_DIMENSION, "The number of channels must be > 1 but it is %d", s->C);
     calc_mainlobe(*s, fs, delays);
     const int C = s->C, M = s->M, bs = C - 1;
-    s->B.assign((size_t) M * C * bs, zc(0, 0)); s->wa.assign((size_t) M * bs, zc(0, 0));
+    s->B.assign((size_t) M * C * bs, zc(0, 0)); s->wa.assign((size_t) M * bs, zc(0, 0)); s->wl.assign((size_t) M * C, zc(0, 0));
     for (int f = 0; f < M; f++) blocking_matrix(&s->wq[(size_t) f * C], C, &s->B[(size_t) f * C * bs]);
     s->haveB = true; s->dirty = true;
   });
@@ -428,6 +441,7 @@ dsr_status dsr_bf_set_active_weights(dsr_bf* s, int f, const double* packed)
     if (!s->haveB) throw Error(DSR_E_ERROR, "call calcGSCWeightsX() once");
     if (f < 0 || f >= s->M) throw Error(DSR_E_DIMENSION, "Must be a frequency bin %d < the length of FFT %d", f, s->M);
     for (int c = 0; c < s->C - 1; c++) s->wa[(size_t) f * (s->C - 1) + c] = zc(packed[2 * c], packed[2 * c + 1]);
+    update_wl(*s, f);
     s->dirty = true;
   });
 }
@@ -435,11 +449,11 @@ dsr_status dsr_bf_zero_active_weights(dsr_bf* s)
 {
   return guard([&] {
     if (!s || !s->haveB) throw Error(DSR_E_ERROR, "call calcGSCWeightsX() once");
-    std::fill(s->wa.begin(), s->wa.end(), zc(0, 0)); s->dirty = true;
+    std::fill(s->wa.begin(), s->wa.end(), zc(0, 0)); for (int f = 0; f < s->M; f++) update_wl(*s, f); s->dirty = true;
   });
 }
 dsr_status dsr_bf_select(dsr_bf* s, int mode)
-{ return guard([&] { if (!s || mode < 0 || mode > 3) throw Error(DSR_E_PARAMETER, "bad mode"); s->mode = mode; s->dirty = true; }); }
+{ return guard([&] { if (!s || mode < 0 || mode > 4) throw Error(DSR_E_PARAMETER, "bad mode"); s->mode = mode; s->dirty = true; }); }
 
 dsr_status dsr_bf_get(const dsr_bf* cs, int kind, double* out, size_t nd)
 {
@@ -523,6 +537,61 @@ dsr_status dsr_bf_gsc_rls(dsr_bf* s, const float* X, int U, int Tmax, float* Y, 
     if (!s->rlsOn) throw Error(DSR_E_ERROR, "not a SubbandGSCRLS object: call dsr_bf_rls_config first");
     require_device();
     gsc_rls_apply(*s, X, U, Tmax, Y, wa_out_dev, (hipStream_t) stream);
+  });
+}
+
+
+// SubbandMVDRGSC (beamformer.h:394-425, beamformer.cc:2637-2817): the MVDR vector as the quiescent weight of a GSC whose active weights are
+// set from outside.  calcBlockingMatrix1: a fresh weight object with the delay-and-sum vectors and their blocking matrices (:2671-2676) -- the
+// same state as calcGSCWeights; calcBlockingMatrix2: fresh object, bins 1..M/2 get the MVDR vector as quiescent vector and its blocking
+// matrix (:2682-2706), everything else stays zero.
+dsr_status dsr_bf_calc_blocking_matrix2(dsr_bf* s)
+{
+  return guard([&] {
+    if (!s) throw Error(DSR_E_PARAMETER, "null argument");
+    if (!s->haveMvdr) throw Error(DSR_E_ERROR, "You have to call calcMVDRWeights() first");
+    if (s->halfBandShift) throw Error(DSR_E_ERROR, "Not yet implemented");
+    const int C = s->C, M = s->M, bs = C - 1;
+    s->wq.assign((size_t) M * C, zc(0, 0)); s->B.assign((size_t) M * C * bs, zc(0, 0)); s->wa.assign((size_t) M * bs, zc(0, 0)); s->wl.assign((size_t) M * C, zc(0, 0));
+    for (int f = 1; f <= M / 2; f++) {
+      for (int c = 0; c < C; c++) s->wq[(size_t) f * C + c] = s->mvdr[(size_t) f * C + c];
+      blocking_matrix(&s->wq[(size_t) f * C], C, &s->B[(size_t) f * C * bs]);
+    }
+    s->haveWq = true; s->haveB = true; s->dirty = true; s->rlsDirty = true;
+  });
+}
+// upgradeBlockingMatrix (:2708-2727): blocking matrices orthogonal to the entire weight wq - wl, bins 1..M-1; the cached wl stays as it is
+dsr_status dsr_bf_upgrade_blocking_matrix(dsr_bf* s)
+{
+  return guard([&] {
+    if (!s || !s->haveB) throw Error(DSR_E_ERROR, "call calcGSCWeightsX() once");
+    const int C = s->C, M = s->M, bs = C - 1; std::vector<zc> w(C);
+    if (s->wl.size() != (size_t) M * C) s->wl.assign((size_t) M * C, zc(0, 0));
+    for (int f = 1; f < M; f++) {
+      for (int c = 0; c < C; c++) w[c] = s->wq[(size_t) f * C + c] - s->wl[(size_t) f * C + c];
+      blocking_matrix(w.data(), C, &s->B[(size_t) f * C * bs]);
+    }
+    s->dirty = true; s->rlsDirty = true;
+  });
+}
+// blockingMatrixOutput(outChanX) (:2729-2753) for a batch: Y[u][t][f] = B_f[:, outChanX]^H X[u][:][t][f], f = 0..M/2
+dsr_status dsr_bf_blocking_matrix_output(dsr_bf* s, const float* X, int U, int Tmax, int outChanX, float* Y, void* stream)
+{
+  return guard([&] {
+    if (!s || !X || !Y) throw Error(DSR_E_PARAMETER, "null argument");
+    if (!s->haveB) throw Error(DSR_E_ERROR, "call calcGSCWeightsX() once");
+    const int C = s->C, bs = C - 1, F = s->M / 2 + 1;
+    if (outChanX < 0 || outChanX >= bs) throw Error(DSR_E_INDEX, "blocking matrix column %d of %d", outChanX, bs);
+    require_device();
+    if (U <= 0 || Tmax <= 0) return;
+    std::vector<float2> w((size_t) F * C);
+    for (int f = 0; f < F; f++) for (int c = 0; c < C; c++) { const zc b = s->B[((size_t) f * C + c) * bs + outChanX]; w[(size_t) f * C + c] = make_float2((float) b.real(), (float) b.imag()); }
+    static thread_local DevBuf<float2> dW; dW.upload(w);
+    const long perUtt = (long) Tmax * F; const size_t lds = sizeof(float2) * (size_t) F * C;
+    DSR_HIP(hipFuncSetAttribute((const void*) k_bf_apply, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
+    int gx = cdiv(perUtt, 256 * 4); if (gx < 1) gx = 1; if (gx > 4096) gx = 4096;
+    hipLaunchKernelGGL(k_bf_apply, dim3(gx, U), dim3(256), lds, (hipStream_t) stream, (const float2*) X, dW.p, (float2*) Y, C, Tmax, F, perUtt);
+    DSR_HIP(hipGetLastError());
   });
 }
 

@@ -69,6 +69,7 @@ def load():
         "dsr_bf_set_diffuse_noise_model": [vp, vp, f64, f64], "dsr_bf_divide_nondiagonal": [vp, f32],
         "dsr_bf_diagonal_loading": [vp, f32], "dsr_bf_set_noise_matrix": [vp, C.c_int, vp],
         "dsr_bf_calc_mvdr_weights": [vp, f64, f64], "dsr_bf_calc_gsc_weights": [vp, f64, vp],
+        "dsr_bf_calc_blocking_matrix2": [vp], "dsr_bf_upgrade_blocking_matrix": [vp], "dsr_bf_blocking_matrix_output": [vp, vp, C.c_int, C.c_int, C.c_int, vp, vp],
         "dsr_bf_rls_config": [vp, f32, f32], "dsr_bf_rls_init_precision": [vp, f32], "dsr_bf_rls_set_precision": [vp, C.c_int, vp],
         "dsr_bf_rls_quadratic_constraint": [vp, f32, C.c_int], "dsr_bf_rls_adapt": [vp, C.c_int], "dsr_bf_gsc_rls": [vp, vp, C.c_int, C.c_int, vp, vp, vp],
         "dsr_bf_set_active_weights": [vp, C.c_int, vp], "dsr_bf_zero_active_weights": [vp], "dsr_bf_select": [vp, C.c_int],
@@ -230,7 +231,7 @@ class Beamformer:
         check(_lib.dsr_bf_zero_active_weights(self.h))
 
     def select(self, mode):
-        check(_lib.dsr_bf_select(self.h, {"ds": 0, "mvdr": 1, "gsc": 2, "gsc_norm": 3}.get(mode, mode)))
+        check(_lib.dsr_bf_select(self.h, {"ds": 0, "mvdr": 1, "gsc": 2, "gsc_norm": 3, "mvdr_gsc": 4}.get(mode, mode)))
 
     def get(self, kind):
         F = self.M // 2 + 1
@@ -238,6 +239,27 @@ class Beamformer:
         out = np.zeros(shape, np.complex128)
         check(_lib.dsr_bf_get(self.h, kind, _ptr(out), out.size * 2))
         return out
+
+    # SubbandMVDRGSC (beamformer.h:394-425): the MVDR vector as quiescent weight, active weights from outside (select("mvdr_gsc"))
+    def calcBlockingMatrix1(self, sampleRate, delaysT):
+        self.calcGSCWeights(sampleRate, delaysT); return True
+
+    def calcBlockingMatrix2(self):
+        try:
+            check(_lib.dsr_bf_calc_blocking_matrix2(self.h)); return True
+        except DsrError:
+            return False                                       # "You have to call calcMVDRWeights() first": the reference returns false
+
+    def upgradeBlockingMatrix(self):
+        check(_lib.dsr_bf_upgrade_blocking_matrix(self.h))
+
+    def blockingMatrixOutput(self, X, outChanX=0):
+        """X: cuda complex64 [U][C][T][F] -> B[:, outChanX]^H X, [U][T][F]"""
+        import torch
+        U, Cn, T, F = X.shape
+        Y = torch.empty((U, T, F, 2), dtype=torch.float32, device=X.device)
+        check(_lib.dsr_bf_blocking_matrix_output(self.h, _dev(torch.view_as_real(X.contiguous())), U, T, int(outChanX), _dev(Y), cur_stream()))
+        return torch.view_as_complex(Y)
 
     # SubbandGSCRLS (beamformer.h:213-262): recursive-least-squares adaptation of the active weights
     def rlsConfig(self, myu=0.9, sigma2=0.0):

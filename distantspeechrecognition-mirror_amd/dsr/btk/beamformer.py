@@ -104,3 +104,24 @@ class SubbandMVDRPtr(_Subband):
 
 def calcDelaysPolar2(azimuth, elevation, micPositions):
     return K.calcDelaysPolar2(np.float32(azimuth), np.float32(elevation), micPositions)
+
+
+class SubbandMVDRGSCPtr(SubbandMVDRPtr):
+    """beamformer.i (SubbandMVDRGSC, beamformer.h:394-425): setChannel, calcArrayManifoldVectors, noise model, calcMVDRWeights,
+    calcBlockingMatrix1/2, setActiveWeights_f; next() = (w_mvdr - B wa)^H X."""
+    _MODE = 4
+
+    def setActiveWeights_f(self, fbinX, packedWeight):
+        self._weights().setActiveWeights_f(fbinX, packedWeight)
+
+    def zeroActiveWeights(self):
+        self._weights().zeroActiveWeights()
+
+    def calcBlockingMatrix1(self, sampleRate, delaysT):
+        return self._weights().calcBlockingMatrix1(sampleRate, delaysT)
+
+    def calcBlockingMatrix2(self):
+        return self._weights().calcBlockingMatrix2()
+
+    def upgradeBlockingMatrix(self):
+        self._weights().upgradeBlockingMatrix()

@@ -113,6 +113,12 @@ dsr_status dsr_bf_calc_mvdr_weights(dsr_bf*, double sampleRate, double dThreshol
 dsr_status dsr_bf_calc_gsc_weights(dsr_bf*, double sampleRate, const double* delays);
 dsr_status dsr_bf_set_active_weights(dsr_bf*, int fbinX, const double* packedWeight /*2*(C-1)*/);
 dsr_status dsr_bf_zero_active_weights(dsr_bf*);
+/* SubbandMVDRGSC (beamformer.h:394-425, beamformer.cc:2637-2817): mode 4 of dsr_bf_select = w_mvdr - wl with wl = B wa as cached by
+ * the last setActiveWeights_f / zeroActiveWeights.  calcBlockingMatrix1(sampleRate, delays) is dsr_bf_calc_gsc_weights; calcBlockingMatrix2(),
+ * upgradeBlockingMatrix(), blockingMatrixOutput(outChanX) for a batch (Y_dev [U][Tmax][M/2+1]) */
+dsr_status dsr_bf_calc_blocking_matrix2(dsr_bf*);
+dsr_status dsr_bf_upgrade_blocking_matrix(dsr_bf*);
+dsr_status dsr_bf_blocking_matrix_output(dsr_bf*, const float* X_dev, int U, int Tmax, int outChanX, float* Y_dev, void* stream);
 /* SubbandGSCRLS(fftLen, halfBandShift, myu, sigma2) (beamformer.h:213-262, beamformer.cc:1497-1698; SURVEY 8f rank 3, first operator): after
  * rls_config the object's apply is the GSC whose active weights follow a recursive-least-squares update after every frame; every utterance
  * of a batch starts from the precision matrices set here and zero active weights (the reference keeps adapting across reset()).
@@ -125,7 +131,7 @@ dsr_status dsr_bf_rls_quadratic_constraint(dsr_bf*, float alpha, int qctype);
 dsr_status dsr_bf_rls_adapt(dsr_bf*, int flag);
 /* X_dev [U][C][Tmax][M/2+1] complex64 -> Y_dev [U][Tmax][M/2+1]; wa_out_dev (optional) [U][M/2+1][C-1] complex128: the final active weights */
 dsr_status dsr_bf_gsc_rls(dsr_bf*, const float* X_dev, int U, int Tmax, float* Y_dev, double* wa_out_dev, void* stream);
-/* which weight set `apply` uses: 0 = delay-and-sum wq, 1 = MVDR, 2 = GSC (wq - B wa), 3 = GSC normalised */
+/* which weight set `apply` uses: 0 = delay-and-sum wq, 1 = MVDR, 2 = GSC (wq - B wa), 3 = GSC normalised, 4 = MVDR-GSC (w_mvdr - wl) */
 dsr_status dsr_bf_select(dsr_bf*, int mode);
 /* read back host copies: kind 0 = wq [fftLen][C], 1 = mvdr [fftLen/2+1][C], 2 = R [fftLen/2+1][C][C],
    3 = blocking matrix [fftLen][C][C-1], 4 = effective weights in use [fftLen/2+1][C]; complex double */

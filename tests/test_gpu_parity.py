@@ -946,6 +946,100 @@ def test_gsc_rls(dsr, oracle, cuda, Cn, myu, sigma2, qc, alpha, mode):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("which", [1, 2])
+def test_mvdr_gsc(dsr, oracle, cuda, which):
+    """SubbandMVDRGSC (beamformer.cc:2637-2817): w_mvdr - B wa with the blocking matrices of the delay-and-sum vector (1) or of the MVDR
+    vector (2), upgradeBlockingMatrix (the cached B wa stays), blockingMatrixOutput -- against the oracle's own pieces."""
+    import torch
+    rng = np.random.default_rng(40 + which)
+    Cn, U, T, M = 6, 2, 12, 32
+    F = M // 2 + 1
+    mp = synth.linear_array(Cn)
+    delays = dsr.calcDelaysPolar2(np.float32(0.6), np.float32(np.pi / 2), mp)
+    bf = dsr.Beamformer(M, Cn); bf.calcArrayManifoldVectors(16000.0, delays); bf.setDiffuseNoiseModel(mp, 16000.0, 343740.0)
+    bf.divideAllNonDiagonalElements(0.01)
+    if which == 2:
+        assert bf.calcBlockingMatrix2() is False                            # no MVDR weights yet
+    bf.calcMVDRWeights(16000.0, 1e-8); bf.select("mvdr_gsc")
+    assert (bf.calcBlockingMatrix1(16000.0, delays) if which == 1 else bf.calcBlockingMatrix2()) is True
+    mv = bf.get(1); wq = bf.get(0); B = bf.get(3)
+    for f in range(1, F):
+        ref, ok = oracle.blocking_matrix(wq[f] if which == 1 else mv[f])
+        assert ok and np.abs(B[f] - ref).max() < 1e-12
+        if which == 2:
+            assert np.abs(wq[f] - mv[f]).max() == 0.0                       # the MVDR vector became the quiescent vector
+    wa = (rng.standard_normal((F, Cn - 1)) + 1j * rng.standard_normal((F, Cn - 1))) * 0.1
+    for f in range(1, F):
+        bf.setActiveWeights_f(f, np.stack([wa[f].real, wa[f].imag], axis=1).reshape(-1))
+    X = (rng.standard_normal((U, Cn, T, F)) + 1j * rng.standard_normal((U, Cn, T, F))).astype(np.complex64)
+    Y = bf.apply(torch.from_numpy(X).to(cuda)).cpu().numpy()
+
+    def full_of(a):
+        f = np.zeros(a.shape[:2] + (M,), np.complex128); f[:, :, :F] = a; f[:, :, F:] = np.conj(a[:, :, 1:F - 1][:, :, ::-1]); return f
+    mvfull = np.zeros((M, Cn), complex); mvfull[:F] = mv
+    waz = wa.copy(); waz[0] = 0.0
+    for u in range(U):
+        Yo = oracle.gsc_apply(full_of(X[u]), mvfull, B[:F], waz)
+        assert np.abs(Y[u] - Yo[:, :F]).max() <= 2e-6 * np.abs(Yo).max()
+    # upgradeBlockingMatrix: new matrices orthogonal to wq - wl; the output does not move until the active weights are set again
+    wl = np.einsum("fcj,fj->fc", B[:F], waz)
+    bf.upgradeBlockingMatrix()
+    B2 = bf.get(3)
+    for f in range(1, F):
+        ref, ok = oracle.blocking_matrix(wq[f] - wl[f])
+        assert ok and np.abs(B2[f] - ref).max() < 1e-12
+    Y2 = bf.apply(torch.from_numpy(X).to(cuda)).cpu().numpy()
+    assert np.array_equal(Y2, Y)
+    Z = bf.blockingMatrixOutput(torch.from_numpy(X).to(cuda), 1).cpu().numpy()
+    ref = np.einsum("fc,uctf->utf", np.conj(B2[:F, :, 1]), X.astype(np.complex128))
+    assert np.abs(Z - ref).max() <= 2e-6 * np.abs(ref).max()
+    bf.zeroActiveWeights()
+    Y3 = bf.apply(torch.from_numpy(X).to(cuda)).cpu().numpy()
+    bm = dsr.Beamformer(M, Cn); bm.calcArrayManifoldVectors(16000.0, delays); bm.setDiffuseNoiseModel(mp, 16000.0, 343740.0)
+    bm.divideAllNonDiagonalElements(0.01); bm.calcMVDRWeights(16000.0, 1e-8); bm.select("mvdr")
+    assert np.abs(Y3 - bm.apply(torch.from_numpy(X).to(cuda)).cpu().numpy()).max() <= 1e-6 * np.abs(Y3).max()   # zero active weights: plain MVDR
+
+
+@pytest.mark.gpu
+def test_mvdr_gsc_stream(dsr, oracle, cuda):
+    """SubbandMVDRGSCPtr behind the stream protocol (usage order of beamformer.h:396-402)."""
+    from dsr.btk import stream as S, beamformer as Bm
+    rng = np.random.default_rng(23)
+    Cn, T, M = 4, 9, 16
+    F = M // 2 + 1
+    mp = synth.linear_array(Cn)
+    delays = dsr.calcDelaysPolar2(np.float32(0.2), np.float32(np.pi / 2), mp)
+
+    class Frames(object):
+        def __init__(self, a):
+            self.a = a
+
+        def size(self):
+            return self.a.shape[1]
+
+        def __iter__(self):
+            return iter(self.a)
+
+    half = (rng.standard_normal((Cn, T, F)) + 1j * rng.standard_normal((Cn, T, F))).astype(np.complex64)
+    full = np.zeros((Cn, T, M), np.complex128); full[:, :, :F] = half; full[:, :, F:] = np.conj(half[:, :, 1:F - 1][:, :, ::-1])
+    bf = Bm.SubbandMVDRGSCPtr(fftLen=M, halfBandShift=False)
+    for c in range(Cn):
+        bf.setChannel(S.PyVectorComplexFeatureStreamPtr(Frames(full[c])))
+    bf.calcArrayManifoldVectors(16000.0, delays); bf.setDiffuseNoiseModel(mp, 16000.0); bf.setAllLevelsOfDiagonalLoading(0.01)
+    assert bf.calcBlockingMatrix2() is False
+    bf.calcMVDRWeights(16000.0, 1e-8)
+    assert bf.calcBlockingMatrix2() is True
+    wa = (rng.standard_normal((F, Cn - 1)) + 1j * rng.standard_normal((F, Cn - 1))) * 0.2
+    for f in range(1, F):
+        bf.setActiveWeights_f(f, np.stack([wa[f].real, wa[f].imag], axis=1).reshape(-1))
+    rows = np.array([np.array(v) for v in bf])
+    w = bf._weights(); mv = w.get(1); B = w.get(3)[:F]
+    mvfull = np.zeros((M, Cn), complex); mvfull[:F] = mv; wa[0] = 0.0
+    Yo = oracle.gsc_apply(full, mvfull, B, wa)
+    assert rows.shape == Yo.shape and np.abs(rows - Yo).max() <= 4e-6 * np.abs(Yo).max()
+
+
+@pytest.mark.gpu
 def test_gsc_rls_stream(dsr, oracle, cuda):
     """SubbandGSCRLSPtr (beamformer.i:227-253) behind the stream protocol: setChannel / calcGSCWeights / initPrecisionMatrix / iteration."""
     from dsr.btk import stream as S, beamformer as Bm
