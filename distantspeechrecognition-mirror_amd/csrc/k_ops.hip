@@ -123,6 +123,17 @@ __global__ void k_op_expand_bins(const float2* in, int T, int F, int M, double2*
   if (f < F) { const float2 v = in[(long) t * F + f]; out[idx] = make_double2(v.x, v.y); }
   else { const float2 v = in[(long) t * F + (M - f)]; out[idx] = make_double2(v.x, -v.y); }
 }
+// highPassFilter::next (postfilter.cc:1232-1256): bin 0 and bins 1..cut-1 are zero, bins cut..M/2 pass and are mirrored; the mirror bins of
+// the cut ones stay at the zero the stream's vector was allocated with
+__global__ void k_op_highpass(const double2* in, int T, int M, int cut, double2* out)
+{
+  const long idx = (long) blockIdx.x * blockDim.x + threadIdx.x; if (idx >= (long) T * M) return;
+  const int t = (int) (idx / M), f = (int) (idx - (long) t * M), M2 = M / 2;
+  double2 v = make_double2(0.0, 0.0);
+  if (f <= M2) { if (f >= cut) v = in[(long) t * M + f]; }
+  else { const int k = M - f; if (k >= cut) { const double2 q = in[(long) t * M + k]; v = make_double2(q.x, -q.y); } }
+  out[idx] = v;
+}
 // complex128 [T][M] -> complex64 [T][F]
 __global__ void k_op_pack_bins(const double2* in, int T, int F, int M, float2* out)
 {
@@ -151,6 +162,7 @@ void op_log(const double* in, long n, double m, double a, int sphinx, float* out
 void op_sgemv(const float* in, int T, int cols, int rows, const float* A, float* out, hipStream_t st) { if (T > 0) hipLaunchKernelGGL(k_op_sgemv, GRID((long) T * rows), in, T, cols, rows, A, out); }
 void op_adjacent(const float* in, int T, int N, int delta, float* out, hipStream_t st) { if (T > 0) hipLaunchKernelGGL(k_op_adjacent, GRID((long) T * (2 * delta + 1) * N), in, T, N, delta, out); }
 void op_expand_bins(const float2* in, int T, int F, int M, double2* out, hipStream_t st) { if (T > 0) hipLaunchKernelGGL(k_op_expand_bins, GRID((long) T * M), in, T, F, M, out); }
+void op_highpass(const double2* in, int T, int M, int cutBin, double2* out, hipStream_t st) { if (T > 0) hipLaunchKernelGGL(k_op_highpass, GRID((long) T * M), in, T, M, cutBin, out); }
 void op_pack_bins(const double2* in, int T, int F, int M, float2* out, hipStream_t st) { if (T > 0) hipLaunchKernelGGL(k_op_pack_bins, GRID((long) T * F), in, T, F, M, out); }
 #undef GRID
 

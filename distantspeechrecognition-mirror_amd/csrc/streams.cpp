@@ -78,6 +78,7 @@ struct Hamming : dsr_stream {
     else op_hamming_f(ups[0]->d<float>(), nFrames, size_, w.p, d<float>(), S0);
   }
 };
+struct HighPassOp : dsr_stream { int cut = 1; void compute() override { alloc(ups[0]->nFrames); op_highpass(ups[0]->d<double2>(), nFrames, size_, cut, d<double2>(), S0); } };   // highPassFilter (postfilter.cc:1222-1261)
 struct FFTOp : dsr_stream { int L; DevBuf<double2> tw; void compute() override { alloc(ups[0]->nFrames); op_fft(ups[0]->d<float>(), nFrames, L, size_, tw.p, d<double2>(), S0); } };
 struct PowerOp : dsr_stream { int fftLen; void compute() override { alloc(ups[0]->nFrames); op_power(ups[0]->d<double2>(), nFrames, fftLen, size_, d<double>(), S0); } };
 struct VtlnOp : dsr_stream {
@@ -480,6 +481,17 @@ dsr_status dsr_hamming_create(dsr_stream* samp, const char* name, dsr_stream** o
     std::vector<double> w(samp->size_); const double temp = 2. * M_PI / (double) (samp->size_ - 1);
     for (int i = 0; i < samp->size_; i++) w[i] = 0.54 - 0.46 * cos(temp * i);
     require_device(); s->w.upload(w); s->add_up(samp); *out = s;
+  });
+}
+dsr_status dsr_highpass_filter_create(dsr_stream* output, float cutOffFreq, int sampleRate, const char* name, dsr_stream** out)
+{
+  return guard([&] {
+    need(output, DSR_T_COMPLEX, "highPassFilter"); if (!out) throw Error(DSR_E_PARAMETER, "null argument");
+    if (sampleRate <= 0) throw Error(DSR_E_PARAMETER, "sample rate %d", sampleRate);
+    const unsigned cut = (unsigned) ((float) output->size_ * cutOffFreq / (float) sampleRate);                 // postfilter.cc:1228
+    if (cut < 1 || cut > (unsigned) output->size_ / 2) throw Error(DSR_E_INDEX, "highPassFilter: the cut-off bin %u must lie in 1..%d (the reference writes outside its vector otherwise)", cut, output->size_ / 2);
+    HighPassOp* s = mk<HighPassOp>(name, "highPassFilter", output->size_, DSR_T_COMPLEX); s->cut = (int) cut; s->checkOrder = false;
+    s->add_up(output); *out = s;
   });
 }
 dsr_status dsr_fft_create(dsr_stream* samp, int fftLen, const char* name, dsr_stream** out)

@@ -74,3 +74,11 @@ class LefkimmiatisPostFilterPtr(McCowanPostFilterPtr):
 
     def calcInverseNoiseSpatialSpectralMatrix(self):
         return None
+
+
+class highPassFilterPtr(FeatureStreamPtr):
+    """postfilter.i:229-252 (highPassFilter, postfilter.cc:1222-1261)."""
+
+    def __init__(self, output, cutOffFreq, sampleRate, nm="highPassFilter"):
+        h, _ = _new(lib().dsr_highpass_filter_create, output._h, float(cutOffFreq), int(sampleRate), nm.encode())
+        FeatureStreamPtr.__init__(self, h, keep=(output,))

@@ -402,6 +402,8 @@ dsr_status dsr_zelinski_stream_set_channel(dsr_stream* pf, dsr_stream* chan);
    a = sampleRate, b = sspeed), 2 set(All)Level(s)OfDiagonalLoading(fbinX or -1, a), 3 divideAllNonDiagonalElements(a) */
 dsr_status dsr_mccowan_stream_create(dsr_stream* output, int fftLen, double alpha, int type, int minFrames, float threshold, const char* name, dsr_stream** out);
 dsr_status dsr_mccowan_stream_set_noise(dsr_stream* pf, int what, int fbinX, const double* data, int chanN, double a, double b);
+/* highPassFilter(output, cutOffFreq, sampleRate) (postfilter.h:209-220, postfilter.cc:1222-1261): bins below fftLen*cutOffFreq/sampleRate are cut */
+dsr_status dsr_highpass_filter_create(dsr_stream* output, float cutOffFreq, int sampleRate, const char* name, dsr_stream** out);
 /* LefkimmiatisPostFilter (postfilter.i, postfilter.h:180-204) on the same operator and setters */
 dsr_status dsr_lefkimmiatis_stream_create(dsr_stream* output, int fftLen, double minSV, int fbinX1, double alpha, int type, int minFrames, float threshold,
                                           const char* name, dsr_stream** out);

@@ -798,6 +798,36 @@ def test_lefkimmiatis_postfilter(dsr, oracle, cuda, Cn, ptype, alpha, minFrames,
     np.testing.assert_allclose(w2.cpu().numpy()[0][:, 0], ww2[:, 0], rtol=1e-5)
 
 
+@pytest.mark.gpu
+def test_highpass_filter_stream(dsr, cuda):
+    """postfilter.cc:1222-1261: bins below fftLen * cutOffFreq / sampleRate are zero (and bin 0, which the reference never writes), the rest
+    passes with its mirror; a cut-off bin of 0 would make the reference write outside its vector and is refused."""
+    from dsr.btk import stream as S, postfilter as P
+    rng = np.random.default_rng(3)
+    T, M = 7, 32
+    F = M // 2 + 1
+
+    class Frames(object):
+        def __init__(self, a):
+            self.a = a
+
+        def size(self):
+            return self.a.shape[1]
+
+        def __iter__(self):
+            return iter(self.a)
+
+    half = rng.standard_normal((T, F)) + 1j * rng.standard_normal((T, F))
+    full = np.zeros((T, M), np.complex128); full[:, :F] = half; full[:, F:] = np.conj(half[:, 1:F - 1][:, ::-1])
+    src = S.PyVectorComplexFeatureStreamPtr(Frames(full))
+    hp = P.highPassFilterPtr(src, 1600.0, 16000)                       # cut bin = 32 * 1600 / 16000 = 3
+    rows = np.array([np.array(v) for v in hp])
+    exp = full.copy(); exp[:, :3] = 0.0; exp[:, M - 2:] = 0.0
+    assert rows.shape == exp.shape and np.array_equal(rows, exp)
+    with pytest.raises(dsr.DsrError):
+        P.highPassFilterPtr(src, 100.0, 16000)                         # cut bin 0
+
+
 # ------------------------------------------------------------------------------------------- single-channel WPE (SURVEY 8f, rank 1)
 @pytest.mark.gpu
 @pytest.mark.parametrize("lowerN,upperN,iters,loadDb,bw", [(2, 9, 2, -20.0, 0.0), (1, 16, 3, -10.0, 0.0), (3, 6, 1, -30.0, 4000.0), (0, 3, 2, -20.0, 0.0)])
