@@ -134,6 +134,14 @@ __global__ void k_op_highpass(const double2* in, int T, int M, int cut, double2*
   else { const int k = M - f; if (k >= cut) { const double2 q = in[(long) t * M + k]; v = make_double2(q.x, -q.y); } }
   out[idx] = v;
 }
+// SubbandOrthogonalizer::next with outChanX > 0 (beamformer.cc:2831-2849): blockingMatrixOutput writes bins 0..M/2 into the beamformer's own
+// vector, whose upper bins still hold the mirror of the beamformer's output -- the operator hands out that vector
+__global__ void k_op_orth_assemble(const float2* low, const double2* full, int T, int F, int M, double2* out)
+{
+  const long idx = (long) blockIdx.x * blockDim.x + threadIdx.x; if (idx >= (long) T * M) return;
+  const int t = (int) (idx / M), f = (int) (idx - (long) t * M);
+  if (f < F) { const float2 v = low[(long) t * F + f]; out[idx] = make_double2(v.x, v.y); } else out[idx] = full[idx];
+}
 // complex128 [T][M] -> complex64 [T][F]
 __global__ void k_op_pack_bins(const double2* in, int T, int F, int M, float2* out)
 {
@@ -163,6 +171,7 @@ void op_sgemv(const float* in, int T, int cols, int rows, const float* A, float*
 void op_adjacent(const float* in, int T, int N, int delta, float* out, hipStream_t st) { if (T > 0) hipLaunchKernelGGL(k_op_adjacent, GRID((long) T * (2 * delta + 1) * N), in, T, N, delta, out); }
 void op_expand_bins(const float2* in, int T, int F, int M, double2* out, hipStream_t st) { if (T > 0) hipLaunchKernelGGL(k_op_expand_bins, GRID((long) T * M), in, T, F, M, out); }
 void op_highpass(const double2* in, int T, int M, int cutBin, double2* out, hipStream_t st) { if (T > 0) hipLaunchKernelGGL(k_op_highpass, GRID((long) T * M), in, T, M, cutBin, out); }
+void op_orth_assemble(const float2* low, const double2* full, int T, int F, int M, double2* out, hipStream_t st) { if (T > 0) hipLaunchKernelGGL(k_op_orth_assemble, GRID((long) T * M), low, full, T, F, M, out); }
 void op_pack_bins(const double2* in, int T, int F, int M, float2* out, hipStream_t st) { if (T > 0) hipLaunchKernelGGL(k_op_pack_bins, GRID((long) T * F), in, T, F, M, out); }
 #undef GRID
 

@@ -190,6 +190,17 @@ struct BfOp : dsr_stream {           // SubbandDS / SubbandGSC / SubbandMVDR as 
   }
 };
 
+struct OrthOp : dsr_stream {         // SubbandOrthogonalizer(beamformer, outChanX) (beamformer.cc:2817-2849): ups[0] = the SubbandMVDRGSC operator
+  int outChanX = 0; DevBuf<float2> Z;
+  void compute() override {
+    BfOp* bf = dynamic_cast<BfOp*>(ups[0]); if (!bf) throw Error(DSR_E_PARAMETER, "SubbandOrthogonalizer needs a subband beamformer");
+    const int T = bf->nFrames; alloc(T); if (T <= 0) return;
+    if (outChanX <= 0) { DSR_HIP(hipMemcpyAsync(d<double2>(), bf->d<double2>(), sizeof(double2) * (size_t) T * size_, hipMemcpyDeviceToDevice, S0)); return; }
+    const int F = bf->M / 2 + 1; Z.reserve((size_t) T * F);
+    dsr_status s = dsr_bf_blocking_matrix_output(bf->w, (const float*) bf->X.p, 1, T, outChanX - 1, (float*) Z.p, S0); if (s) throw Error(s, "%s", dsr_last_error());
+    op_orth_assemble(Z.p, bf->d<double2>(), T, F, bf->M, d<double2>(), S0);
+  }
+};
 struct WpeOp : dsr_stream {          // SingleChannelWPEDereverberationFeature (dereverberation.cc:28-300)
   int M = 0, lowerN = 0, upperN = 0, iterationsN = 2; double loadDb = -20.0, bandWidth = 0.0, sampleRate = 16000.0; DevBuf<float2> Y, O; DevBuf<int> nf;
   void compute() override {
@@ -461,6 +472,14 @@ dsr_status dsr_subband_bf_create(dsr_bf* weights, const char* name, dsr_stream**
   return guard([&] {
     if (!weights || !out) throw Error(DSR_E_PARAMETER, "null argument");
     BfOp* s = mk<BfOp>(name, "SubbandBeamformer", dsr_bf_fft_len(weights), DSR_T_COMPLEX); s->w = weights; s->M = dsr_bf_fft_len(weights); s->checkOrder = false; *out = s;
+  });
+}
+dsr_status dsr_subband_orthogonalizer_create(dsr_stream* beamformer, int outChanX, const char* name, dsr_stream** out)
+{
+  return guard([&] {
+    BfOp* q = dynamic_cast<BfOp*>(beamformer); if (!q || !out) throw Error(DSR_E_PARAMETER, "not a subband beamformer");
+    OrthOp* s = mk<OrthOp>(name, "SubbandOrthogonalizer", q->M, DSR_T_COMPLEX); s->outChanX = outChanX; s->checkOrder = false;
+    s->add_up(beamformer); *out = s;
   });
 }
 dsr_status dsr_subband_bf_set_channel(dsr_stream* bf, dsr_stream* chan)

@@ -125,3 +125,13 @@ class SubbandMVDRGSCPtr(SubbandMVDRPtr):
 
     def upgradeBlockingMatrix(self):
         self._weights().upgradeBlockingMatrix()
+
+
+class SubbandOrthogonalizerPtr(FeatureStreamPtr):
+    """beamformer.i (SubbandOrthogonalizer, beamformer.cc:2817-2849): outChanX <= 0 hands the beamformer's output on, outChanX > 0 the output
+    of column outChanX-1 of its blocking matrices."""
+
+    def __init__(self, beamformer, outChanX=0, nm="SubbandOrthogonalizer"):
+        beamformer._weights()
+        h, _ = _new(lib().dsr_subband_orthogonalizer_create, beamformer._h, int(outChanX), nm.encode())
+        FeatureStreamPtr.__init__(self, h, keep=(beamformer,))

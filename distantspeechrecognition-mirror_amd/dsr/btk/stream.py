@@ -31,6 +31,7 @@ def lib():
                "dsr_zelinski_stream_set_manifold": [vp, ci, vp, ci],
                "dsr_mccowan_stream_create": [vp, ci, C.c_double, ci, ci, C.c_float, C.c_char_p, vp],
                "dsr_highpass_filter_create": [vp, C.c_float, ci, C.c_char_p, vp],
+               "dsr_subband_orthogonalizer_create": [vp, ci, C.c_char_p, vp],
                "dsr_lefkimmiatis_stream_create": [vp, ci, C.c_double, ci, C.c_double, ci, ci, C.c_float, C.c_char_p, vp],
                "dsr_mccowan_stream_set_noise": [vp, ci, ci, vp, ci, C.c_double, C.c_double],
                "dsr_subband_bf_create": [vp, C.c_char_p, vp], "dsr_subband_bf_set_channel": [vp, vp],

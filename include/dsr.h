@@ -421,6 +421,10 @@ dsr_status dsr_wpe_multi_feature_set_filter_channel(dsr_stream* feature, int fil
 /* SubbandDS/GSC/MVDR as a stream: channels are analysis-bank streams (setChannel) */
 dsr_status dsr_subband_bf_create(dsr_bf* weights, const char* name, dsr_stream** out);
 dsr_status dsr_subband_bf_set_channel(dsr_stream* bf, dsr_stream* chan);
+/* SubbandOrthogonalizer(beamformer, outChanX) (beamformer.h:436-..., beamformer.cc:2817-2849) as a stream over a subband-beamformer operator:
+ * outChanX <= 0: the beamformer's output; > 0: column outChanX-1 of the blocking matrices applied to the same snapshots (bins above M/2 as the
+ * reference leaves them: the beamformer output's mirror) */
+dsr_status dsr_subband_orthogonalizer_create(dsr_stream* beamformer, int outChanX, const char* name, dsr_stream** out);
 dsr_status dsr_preemphasis_create(dsr_stream* samp, double mu, const char* name, dsr_stream** out);
 dsr_status dsr_hamming_create(dsr_stream* samp, const char* name, dsr_stream** out);
 dsr_status dsr_fft_create(dsr_stream* samp, int fftLen, const char* name, dsr_stream** out);

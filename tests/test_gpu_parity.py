@@ -1067,6 +1067,13 @@ def test_mvdr_gsc_stream(dsr, oracle, cuda):
     mvfull = np.zeros((M, Cn), complex); mvfull[:F] = mv; wa[0] = 0.0
     Yo = oracle.gsc_apply(full, mvfull, B, wa)
     assert rows.shape == Yo.shape and np.abs(rows - Yo).max() <= 4e-6 * np.abs(Yo).max()
+    # SubbandOrthogonalizer on the same beamformer: channel 0 = its output, channel k = column k-1 of the blocking matrices (lower bins;
+    # the upper bins keep the mirror of the beamformer's output, as the reference's shared vector does)
+    o0 = np.array([np.array(v) for v in Bm.SubbandOrthogonalizerPtr(bf, 0)])
+    assert np.array_equal(o0, rows)
+    o2 = np.array([np.array(v) for v in Bm.SubbandOrthogonalizerPtr(bf, 2)])
+    ref = np.einsum("fc,ctf->tf", np.conj(B[:, :, 1]), full[:, :, :F])
+    assert np.abs(o2[:, :F] - ref).max() <= 4e-6 * np.abs(ref).max() and np.array_equal(o2[:, F:], rows[:, F:])
 
 
 @pytest.mark.gpu
