@@ -80,6 +80,10 @@ class SubbandGSCRLSPtr(SubbandGSCPtr):
         self._weights().updateActiveWeightVecotrs(flag)
 
 
+class SubbandBlockingMatrixPtr(SubbandGSCPtr):
+    """beamformer.h:453-460: a SubbandGSC under another name (its next() is SubbandGSC::next, beamformer.cc:2852-2917)."""
+
+
 class SubbandMVDRPtr(_Subband):
     _MODE = 1
 
