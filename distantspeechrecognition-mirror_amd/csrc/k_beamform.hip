@@ -221,7 +221,7 @@ __device__ __forceinline__ double2 cmul2(double2 a, double2 b) { return make_dou
 __device__ __forceinline__ double2 cmulc2(double2 a, double2 b) { return make_double2(a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y); }     // a conj(b)
 
 // (CT: compile-time channel count -- the small vectors then live in registers and the loops unroll; 0: run-time count, arrays in scratch)
-template <int CT>
+template <int CT, bool REG>
 __global__ __launch_bounds__(64) void k_gsc_rls(const float2* __restrict__ X, const double2* __restrict__ wq, const double2* __restrict__ B,
                                                 const double2* __restrict__ P0, const double* __restrict__ diagW, double2* __restrict__ state,
                                                 float2* __restrict__ Y, double2* __restrict__ waOut, int U, int Crt, int Tmax, int F, double rmu,
@@ -239,7 +239,16 @@ __global__ __launch_bounds__(64) void k_gsc_rls(const float2* __restrict__ X, co
   double2* P = ldsState ? reinterpret_cast<double2*>(smem) + threadIdx.x : state + tix; double2* wa = P + (long) n * n * S;
   constexpr int CA = CT ? CT : 16;
   double2 x[CA], w[CA], Z[CA], PH[CA], g[CA], wn[CA];
-  if (f > 0) { for (int e = 0; e < n * n; e++) P[(long) e * S] = P0[(long) f * n * n + e]; for (int j = 0; j < n; j++) wa[(long) j * S] = make_double2(0.0, 0.0); }
+  // REG (needs CT): precision matrix and active weights in registers -- every index below is a compile-time constant after unrolling
+  double2 Pr[REG ? CA : 1][REG ? CA : 1], war[REG ? CA : 1];
+#define PX(i, j) (REG ? Pr[REG ? (i) : 0][REG ? (j) : 0] : P[(long) ((i) * n + (j)) * S])
+#define WA(j) (REG ? war[REG ? (j) : 0] : wa[(long) (j) * S])
+  if (f > 0) {
+    for (int i = 0; i < n; i++) {
+      for (int j = 0; j < n; j++) PX(i, j) = P0[(long) f * n * n + i * n + j];
+      WA(i) = make_double2(0.0, 0.0);
+    }
+  }
   const double dw = diagW[f];
   for (int t = 0; t < Tmax; t++) {
     for (int c = 0; c < C; c++) { const float2 v = Xu[((long) c * Tmax + t) * F + f]; x[c] = make_double2((double) v.x, (double) v.y); }
@@ -249,7 +258,7 @@ __global__ __launch_bounds__(64) void k_gsc_rls(const float2* __restrict__ X, co
       double nrm = 0.0;
       for (int i = 0; i < C; i++) {
         double2 wl = make_double2(0.0, 0.0);
-        for (int j = 0; j < n; j++) { const double2 q = cmul2(Bf[i * n + j], wa[(long) j * S]); wl.x += q.x; wl.y += q.y; }
+        for (int j = 0; j < n; j++) { const double2 q = cmul2(Bf[i * n + j], WA(j)); wl.x += q.x; wl.y += q.y; }
         w[i] = make_double2(wqf[i].x - wl.x, wqf[i].y - wl.y); nrm += w[i].x * w[i].x + w[i].y * w[i].y;
       }
       if (normalize) { nrm = sqrt(nrm) * (double) C; for (int i = 0; i < C; i++) { w[i].x /= nrm; w[i].y /= nrm; } }
@@ -258,23 +267,23 @@ __global__ __launch_bounds__(64) void k_gsc_rls(const float2* __restrict__ X, co
     Yu[(long) t * F + f] = make_float2((float) y.x, (float) y.y);
     if (f == 0 || !adapt) continue;
     for (int j = 0; j < n; j++) { double2 a = make_double2(0.0, 0.0); for (int c = 0; c < C; c++) { const double2 q = cmulc2(x[c], Bf[c * n + j]); a.x += q.x; a.y += q.y; } Z[j] = a; }
-    for (int j = 0; j < n; j++) { double2 a = make_double2(0.0, 0.0); for (int i = 0; i < n; i++) { const double2 q = cmulc2(Z[i], P[(long) (i * n + j) * S]); a.x += q.x; a.y += q.y; } PH[j] = a; }
-    for (int i = 0; i < n; i++) { double2 a = make_double2(0.0, 0.0); for (int j = 0; j < n; j++) { const double2 q = cmul2(P[(long) (i * n + j) * S], Z[j]); a.x += q.x; a.y += q.y; } g[i] = make_double2(a.x * rmu, a.y * rmu); }
+    for (int j = 0; j < n; j++) { double2 a = make_double2(0.0, 0.0); for (int i = 0; i < n; i++) { const double2 q = cmulc2(Z[i], PX(i, j)); a.x += q.x; a.y += q.y; } PH[j] = a; }
+    for (int i = 0; i < n; i++) { double2 a = make_double2(0.0, 0.0); for (int j = 0; j < n; j++) { const double2 q = cmul2(PX(i, j), Z[j]); a.x += q.x; a.y += q.y; } g[i] = make_double2(a.x * rmu, a.y * rmu); }
     double2 de = make_double2(0.0, 0.0);
     for (int j = 0; j < n; j++) { const double2 q = cmulc2(Z[j], PH[j]); de.x += q.x; de.y += q.y; }
     de = make_double2(de.x * rmu + 1.0, de.y * rmu);
     for (int i = 0; i < n; i++) g[i] = cdiv_gsl2(g[i].x, g[i].y, de.x, de.y);
     for (int i = 0; i < n; i++)
       for (int j = 0; j < n; j++) {
-        const double2 o = P[(long) (i * n + j) * S], q = cmulc2(g[i], PH[j]);
-        P[(long) (i * n + j) * S] = make_double2((o.x - q.x) * rmu, (o.y - q.y) * rmu);
+        const double2 o = PX(i, j), q = cmulc2(g[i], PH[j]);
+        PX(i, j) = make_double2((o.x - q.x) * rmu, (o.y - q.y) * rmu);
       }
     const double2 epA = make_double2(y.x, -y.y);
     for (int i = 0; i < n; i++) {
       double2 a = make_double2(0.0, 0.0);
       for (int j = 0; j < n; j++) {
-        const double2 p = P[(long) (i * n + j) * S]; double2 m1 = make_double2(p.x * (-dw), p.y * (-dw)); if (i == j) m1.x += 1.0;
-        const double2 q = cmul2(m1, wa[(long) j * S]); a.x += q.x; a.y += q.y;
+        const double2 p = PX(i, j); double2 m1 = make_double2(p.x * (-dw), p.y * (-dw)); if (i == j) m1.x += 1.0;
+        const double2 q = cmul2(m1, WA(j)); a.x += q.x; a.y += q.y;
       }
       const double2 q = cmul2(g[i], epA); wn[i] = make_double2(a.x + q.x, a.y + q.y);
     }
@@ -283,11 +292,13 @@ __global__ __launch_bounds__(64) void k_gsc_rls(const float2* __restrict__ X, co
       nr = sqrt(nr);
       if (qctype == 1 || nr * nr >= alpha) { const double sc = alpha / nr; for (int i = 0; i < n; i++) { wn[i].x *= sc; wn[i].y *= sc; } }
     }
-    for (int i = 0; i < n; i++) wa[(long) i * S] = wn[i];
+    for (int i = 0; i < n; i++) WA(i) = wn[i];
   }
-  if (waOut && f > 0) for (int j = 0; j < n; j++) waOut[((long) u * F + f) * n + j] = wa[(long) j * S];
+  if (waOut && f > 0) for (int j = 0; j < n; j++) waOut[((long) u * F + f) * n + j] = WA(j);
   if (waOut && f == 0) for (int j = 0; j < n; j++) waOut[((long) u * F) * n + j] = make_double2(0.0, 0.0);
 }
+#undef PX
+#undef WA
 
 struct dsr_bf : BfState {};
 
@@ -310,10 +321,15 @@ static void gsc_rls_apply(BfState& s, const float* X, int U, int Tmax, float* Y,
   const long S = (long) U * F;
   const size_t ldsB = (size_t) (n * n + n) * 16 * 64; const int ldsState = (ldsB <= 150 * 1024 && !getenv("DSR_RLS_MEMSTATE")) ? 1 : 0;
   s.d_state.reserve(ldsState ? 16 : (size_t) S * (n * n + n));
-#define RLS_LAUNCH(CTV) { if (ldsState) DSR_HIP(hipFuncSetAttribute((const void*) k_gsc_rls<CTV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) ldsB)); \
-  hipLaunchKernelGGL(k_gsc_rls<CTV>, dim3((unsigned) ((S + 63) / 64)), dim3(64), ldsState ? ldsB : 0, st, (const float2*) X, s.d_wq.p, s.d_B.p, s.d_P0.p, s.d_diag.p, s.d_state.p, \
+#define RLS_LAUNCH(CTV) { if (ldsState) DSR_HIP(hipFuncSetAttribute((const void*) k_gsc_rls<CTV, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) ldsB)); \
+  hipLaunchKernelGGL((k_gsc_rls<CTV, false>), dim3((unsigned) ((S + 63) / 64)), dim3(64), ldsState ? ldsB : 0, st, (const float2*) X, s.d_wq.p, s.d_B.p, s.d_P0.p, s.d_diag.p, s.d_state.p, \
                      (float2*) Y, (double2*) waOut, U, C, Tmax, F, 1.0 / s.rlsMyu, s.rlsAlpha, s.rlsQc, s.rlsAdapt ? 1 : 0, s.mode == 3 ? 1 : 0, ldsState); }
-  if (C == 8) RLS_LAUNCH(8) else if (C == 4) RLS_LAUNCH(4) else if (C == 6) RLS_LAUNCH(6) else RLS_LAUNCH(0)
+#define RLS_LAUNCH_REG(CTV) hipLaunchKernelGGL((k_gsc_rls<CTV, true>), dim3((unsigned) ((S + 63) / 64)), dim3(64), 0, st, (const float2*) X, s.d_wq.p, s.d_B.p, s.d_P0.p, s.d_diag.p, s.d_state.p, \
+                     (float2*) Y, (double2*) waOut, U, C, Tmax, F, 1.0 / s.rlsMyu, s.rlsAlpha, s.rlsQc, s.rlsAdapt ? 1 : 0, s.mode == 3 ? 1 : 0, 0);
+  const bool regs = getenv("DSR_RLS_NOREGS") == nullptr;       // precision matrix + active weights in registers (C = 8: 256 VGPRs, no scratch): 2x the LDS variant
+  if (regs && C == 8) { RLS_LAUNCH_REG(8) } else if (regs && C == 6) { RLS_LAUNCH_REG(6) } else if (regs && C == 4) { RLS_LAUNCH_REG(4) }
+  else if (C == 8) RLS_LAUNCH(8) else if (C == 4) RLS_LAUNCH(4) else if (C == 6) RLS_LAUNCH(6) else RLS_LAUNCH(0)
+#undef RLS_LAUNCH_REG
 #undef RLS_LAUNCH
   DSR_HIP(hipGetLastError());
 }
