@@ -71,13 +71,17 @@ __global__ __launch_bounds__(128) void k_zelinski(const float2* __restrict__ X, 
 __device__ __forceinline__ double2 cdiv_gsl(double ar, double ai, double br, double bi)
 { const double s = 1.0 / hypot(br, bi); const double sbr = s * br, sbi = s * bi; return make_double2((ar * sbr + ai * sbi) * s, (ai * sbr - ar * sbi) * s); }
 
+// (CT: compile-time channel count -- the densities then live in registers, C(C+1)/2 complex fp64 values per thread, and the kernel moves only
+// the algorithmic bytes; 0: run-time count, densities in the state array [entry][utterance x bin])
+template <int CT>
 __global__ __launch_bounds__(128) void k_mccowan(const float2* __restrict__ X, const float2* __restrict__ Y, const int* __restrict__ nframesArr,
                                                  const double2* __restrict__ wq, const double2* __restrict__ R, double2* __restrict__ state,
-                                                 float2* __restrict__ out, float* __restrict__ wp1, int U, int C, int Tmax, int F, double alphaCfg, int type,
+                                                 float2* __restrict__ out, float* __restrict__ wp1, int U, int Crt, int Tmax, int F, double alphaCfg, int type,
                                                  int minFrames, double thr, const double2* __restrict__ lambda, int fbinX1)
 {
   // lambda != nullptr: LefkimmiatisPostFilter (postfilter.cc:1065-1176) -- McCowan's clean-signal estimate against the noise estimate
   // sum (0.5 (phi_ii + phi_jj) - phi_ij) / (1 - R_ij), divided by d^H pinv(R) d from bin fbinX1 on
+  const int C = CT ? CT : Crt;
   const long n = (long) blockIdx.x * blockDim.x + threadIdx.x;
   if (n >= (long) U * F) return;
   const int u = (int) (n / F), f = (int) (n - (long) u * F);
@@ -88,7 +92,10 @@ __global__ __launch_bounds__(128) void k_mccowan(const float2* __restrict__ X, c
   float2* Ou = out + (long) u * Tmax * F;
   const double2* Rf = R + (long) f * C * C;
   const int NPp = C * (C - 1) / 2;
-  double2 ta[16]; double psd[16];
+  constexpr int CA = CT ? CT : 16;
+  double2 ta[CA]; double psd[CA];
+  double2 stR[CT ? CT * (CT + 1) / 2 : 1];
+#define ST(e) (CT ? stR[CT ? (e) : 0] : state[(long) (e) * S + n])
   for (int t = 0; t < Tmax; t++) {
     if (t >= T) { Ou[(long) t * F + f] = make_float2(0.f, 0.f); if (wp1) wp1[((long) u * Tmax + t) * F + f] = 0.f; continue; }
     const int frameX = t - 1;
@@ -104,21 +111,21 @@ __global__ __launch_bounds__(128) void k_mccowan(const float2* __restrict__ X, c
         const double ar = ta[i].x, ai = ta[i].y, br = ta[j].x, bi = -ta[j].y;
         const double pr = ar * br - ai * bi, pi = ar * bi + ai * br;
         double er = pr, ei = pi;
-        if (alpha > 0.0) { const double2 p = state[(long) e * S + n]; er = p.x * alpha + pr * (1.0 - alpha); ei = p.y * alpha + pi * (1.0 - alpha); }
-        state[(long) e * S + n] = make_double2(er, ei);
+        if (alpha > 0.0) { const double2 p = ST(e); er = p.x * alpha + pr * (1.0 - alpha); ei = p.y * alpha + pi * (1.0 - alpha); }
+        ST(e) = make_double2(er, ei);
       }
     double sumOfPSD = 0.0;
     for (int i = 0; i < C; i++) {
       const double a2 = ta[i].x * ta[i].x + ta[i].y * ta[i].y;
       double est = a2;
-      if (alpha > 0.0) est = alpha * state[(long) (NPp + i) * S + n].x + (1.0 - alpha) * a2;
-      sumOfPSD += est; psd[i] = est; state[(long) (NPp + i) * S + n] = make_double2(est, 0.0);
+      if (alpha > 0.0) est = alpha * ST(NPp + i).x + (1.0 - alpha) * a2;
+      sumOfPSD += est; psd[i] = est; ST(NPp + i) = make_double2(est, 0.0);
     }
     const double de = sumOfPSD / (double) C;
     double sr = 0.0, si = 0.0; e = 0;
     for (int i = 0; i < C - 1; i++)
       for (int j = i + 1; j < C; j++, e++) {
-        const double2 phi = state[(long) e * S + n];
+        const double2 phi = ST(e);
         double2 r = Rf[i * C + j];
         if (r.x > thr && r.y <= 0.0) r = make_double2(thr, 0.0);
         const double hs = 0.5 * (psd[i] + psd[j]);
@@ -132,7 +139,7 @@ __global__ __launch_bounds__(128) void k_mccowan(const float2* __restrict__ X, c
       double vr = 0.0, vi = 0.0; e = 0;
       for (int i = 0; i < C - 1; i++)
         for (int j = i + 1; j < C; j++, e++) {
-          const double2 phi = state[(long) e * S + n];
+          const double2 phi = ST(e);
           double2 r = Rf[i * C + j];
           if (r.x > thr) r = make_double2(thr, 0.0); else if (r.x == 1.0) r = make_double2(0.99, 0.0);
           const double2 q = cdiv_gsl((psd[i] + psd[j]) * 0.5 - phi.x, 0.0 - phi.y, -r.x + 1.0, -r.y);
@@ -149,6 +156,7 @@ __global__ __launch_bounds__(128) void k_mccowan(const float2* __restrict__ X, c
     Ou[(long) t * F + f] = (frameX >= minFrames) ? make_float2((float) ((double) y.x * W), (float) ((double) y.y * W)) : y;
   }
 }
+#undef ST
 
 // the same with the densities in registers (C(C-1)/2 complex + C real fp64 values per thread), for the usual small arrays:
 // no state traffic at all, the kernel then moves the algorithmic (C + 2) x 8 bytes per (frame, bin)
@@ -390,9 +398,12 @@ dsr_status dsr_zelinski_apply(dsr_zelinski* p, const float* X, const float* Y, c
         for (int f = 0; f < F; f++) lam[f] = lefkimmiatis_lambda(&p->h_R[(size_t) f * p->C * p->C * 2], &p->h_wq[(size_t) f * p->C * 2], p->C, p->minSV);
         p->lambda.upload(lam); p->dirtyL = false;
       }
-      p->state.reserve(S * NE);
-      hipLaunchKernelGGL(k_mccowan, dim3((unsigned) ((S + 127) / 128)), dim3(128), 0, st, (const float2*) X, (const float2*) Y, nframes_dev, p->wq.p, p->R.p, p->state.p,
+      const bool regsM = !getenv("DSR_PF_MEMSTATE") && (p->C == 2 || p->C == 3 || p->C == 4 || p->C == 6 || p->C == 8);
+      p->state.reserve(regsM ? 16 : S * NE);
+#define MC_LAUNCH(CTV) hipLaunchKernelGGL((k_mccowan<CTV>), dim3((unsigned) ((S + 127) / 128)), dim3(128), 0, st, (const float2*) X, (const float2*) Y, nframes_dev, p->wq.p, p->R.p, p->state.p, \
                          (float2*) out, wp1, U, p->C, Tmax, F, p->alpha, p->type, p->minFrames, p->threshold, p->kind == 2 ? p->lambda.p : nullptr, p->fbinX1);
+      if (!regsM) { MC_LAUNCH(0) } else if (p->C == 8) { MC_LAUNCH(8) } else if (p->C == 6) { MC_LAUNCH(6) } else if (p->C == 4) { MC_LAUNCH(4) } else if (p->C == 3) { MC_LAUNCH(3) } else { MC_LAUNCH(2) }
+#undef MC_LAUNCH
       DSR_HIP(hipGetLastError());
       return;
     }

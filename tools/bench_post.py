@@ -24,3 +24,15 @@ e0.record()
 for _ in range(a.reps): run()
 e1.record(); torch.cuda.synchronize(); ms = e0.elapsed_time(e1) / a.reps
 print("zelinski: %.3f ms  %.1f GB/s algorithmic (%d B x %d frame-bins)" % (ms, U * T * F * (Cn + 2) * 8 / ms / 1e6, (Cn + 2) * 8, U * T * F))
+# McCowan / Lefkimmiatis on the same data (diffuse noise model + loading)
+from tests import synth
+mp = synth.linear_array(Cn)
+for name, obj in (("mccowan", dsr.McCowanPostFilter(M, Cn, wq)), ("lefkimmiatis", dsr.LefkimmiatisPostFilter(M, Cn, wq))):
+    obj.setDiffuseNoiseModel(mp, 16000.0); obj.setAllLevelsOfDiagonalLoading(0.05)
+    def run2():
+        dsr.check(dsr._lib.dsr_zelinski_apply(obj.h, dsr._dev(X), dsr._dev(Y), dsr._dev(nf), U, T, dsr._dev(out), None, dsr.cur_stream()))
+    run2(); torch.cuda.synchronize()
+    e0.record()
+    for _ in range(a.reps): run2()
+    e1.record(); torch.cuda.synchronize(); ms = e0.elapsed_time(e1) / a.reps
+    print("%s: %.3f ms  %.1f GB/s algorithmic" % (name, ms, U * T * F * (Cn + 2) * 8 / ms / 1e6))
