@@ -148,17 +148,17 @@ __global__ __launch_bounds__(256) void k_wpe_multi(const float2* __restrict__ Y,
   for (int l = tid; l < PT; l += nthr) g[l] = make_double2(0.0, 0.0);
   if (tid == 0) s_fail = 0;
   __syncthreads();
-  auto lagv = [&](int t, int n) -> double2 {                     // lag_t of frame n: channel t / P, delay lowerN + t % P; zero before the start
-    const int ch = t / P, ix = n - lowerN - (t - ch * P);
-    if (ix < 0) return make_double2(0.0, 0.0);
-    const float2 v = y[ch * Nmax + ix]; return make_double2((double) v.x, (double) v.y);
-  };
   for (int it = 0; it < iterationsN; it++) {
     for (int n = tid; n < N; n += nthr) {                        // _calculateThetan
       const float2 v = y[c0 * Nmax + n]; double cr = (double) v.x, ci = (double) v.y;
       if (n >= lowerN) {
         double dr = 0.0, di = 0.0;
-        for (int t = 0; t < PT; t++) { const double2 a = lagv(t, n); const double gr = g[t].x, gi = -g[t].y; dr += gr * a.x - gi * a.y; di += gr * a.y + gi * a.x; }
+        for (int ch = 0; ch < C; ch++)
+          for (int l = 0; l < P; l++) {                             // t = ch * P + l, in the reference's order of the stacked lags
+            const int ix = n - lowerN - l; if (ix < 0) break;
+            const float2 v = y[ch * Nmax + ix]; const double gr = g[ch * P + l].x, gi = -g[ch * P + l].y;
+            dr += gr * (double) v.x - gi * (double) v.y; di += gr * (double) v.y + gi * (double) v.x;
+          }
         cr -= dr; ci -= di;
       }
       double th = hypot(cr, ci); if (th < 1.0E-03) th = 1.0E-03;
@@ -171,34 +171,46 @@ __global__ __launch_bounds__(256) void k_wpe_multi(const float2* __restrict__ Y,
       if (e < nEnt) {
         int row = (int) ((sqrt(8.0 * e + 1.0) - 1.0) * 0.5); while (row * (row + 1) / 2 > e) row--; while ((row + 1) * (row + 2) / 2 <= e) row++;
         const int col = e - row * (row + 1) / 2;
-        for (int n = lowerN; n < N; n++) { const double2 a = lagv(row, n), q = lagv(col, n); const double w = rth[n]; sr += (a.x * q.x + a.y * q.y) * w; si += (a.y * q.x - a.x * q.y) * w; }
+        const int chR = row / P, lR = row - chR * P, chC = col / P, lC = col - chC * P;
+        const float2* yr = y + chR * Nmax - lowerN - lR; const float2* yc = y + chC * Nmax - lowerN - lC;
+        for (int n = lowerN + (lR > lC ? lR : lC); n < N; n++) {    // a lag before the start of the utterance is zero: those frames add nothing
+          const float2 a = yr[n], q = yc[n]; const double w = rth[n];
+          sr += ((double) a.x * (double) q.x + (double) a.y * (double) q.y) * w; si += ((double) a.y * (double) q.x - (double) a.x * (double) q.y) * w;
+        }
         R[row * PT + col] = make_double2(sr, si);
       } else {
         const int l = e - nEnt;
-        for (int n = lowerN; n < N; n++) { const float2 v = y[c0 * Nmax + n]; const double2 a = lagv(l, n); const double w = rth[n];
-          sr += ((double) v.x * a.x + (double) v.y * a.y) * w; si += ((double) v.x * a.y - (double) v.y * a.x) * w; }
+        const int chL = l / P, lL = l - chL * P; const float2* yl = y + chL * Nmax - lowerN - lL;
+        for (int n = lowerN + lL; n < N; n++) { const float2 v = y[c0 * Nmax + n], a = yl[n]; const double w = rth[n];
+          sr += ((double) v.x * (double) a.x + (double) v.y * (double) a.y) * w; si += ((double) v.x * (double) a.y - (double) v.y * (double) a.x) * w; }
         r[l] = make_double2(sr, si);
       }
     }
     __syncthreads();
-    if (tid == 0) {                                              // _loadR, Cholesky (lower), two triangular solves
+    if (tid == 0) {                                              // _loadR
       double maxd = 0.0;
       for (int k = 0; k < PT; k++) { const double d = hypot(R[k * PT + k].x, R[k * PT + k].y); if (d > maxd) maxd = d; }
       for (int k = 0; k < PT; k++) { const double d = hypot(R[k * PT + k].x, R[k * PT + k].y) + maxd * loadFactor; R[k * PT + k] = make_double2(d, 0.0); }
-      bool ok = true;
-      for (int j = 0; j < PT && ok; j++) {
+    }
+    __syncthreads();
+    for (int j = 0; j < PT; j++) {                               // Cholesky (lower): the diagonal entry by one thread, the column below it by all
+      if (tid == 0) {
         double ajj = R[j * PT + j].x;
         for (int k = 0; k < j; k++) ajj -= R[j * PT + k].x * R[j * PT + k].x + R[j * PT + k].y * R[j * PT + k].y;
-        if (ajj <= 0.0) { ok = false; break; }
-        ajj = sqrt(ajj); R[j * PT + j] = make_double2(ajj, 0.0);
-        for (int i = j + 1; i < PT; i++) {
-          double sr = R[i * PT + j].x, si = R[i * PT + j].y;
-          for (int k = 0; k < j; k++) { const double2 a = R[i * PT + k], q = R[j * PT + k]; sr -= a.x * q.x + a.y * q.y; si -= a.y * q.x - a.x * q.y; }
-          R[i * PT + j] = make_double2(sr / ajj, si / ajj);
-        }
+        if (ajj <= 0.0) s_fail = 1; else R[j * PT + j] = make_double2(sqrt(ajj), 0.0);
       }
-      if (!ok) s_fail = 1;
-      else {
+      __syncthreads();
+      if (s_fail) break;
+      const double ajj = R[j * PT + j].x;
+      for (int i = j + 1 + tid; i < PT; i += nthr) {
+        double sr = R[i * PT + j].x, si = R[i * PT + j].y;
+        for (int k = 0; k < j; k++) { const double2 a = R[i * PT + k], q = R[j * PT + k]; sr -= a.x * q.x + a.y * q.y; si -= a.y * q.x - a.x * q.y; }
+        R[i * PT + j] = make_double2(sr / ajj, si / ajj);
+      }
+      __syncthreads();
+    }
+    if (tid == 0) {                                              // two triangular solves
+      if (!s_fail) {
         for (int i = 0; i < PT; i++) {
           double sr = r[i].x, si = r[i].y;
           for (int k = 0; k < i; k++) { const double2 a = R[i * PT + k]; sr -= a.x * g[k].x - a.y * g[k].y; si -= a.x * g[k].y + a.y * g[k].x; }
