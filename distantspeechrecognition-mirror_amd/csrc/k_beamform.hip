@@ -10,6 +10,7 @@
 // k_bf_apply: one thread per (frame, bin), channel spectra read coalesced along the bin axis from the
 // [chan][frame][bin] layout the analysis kernel writes, weights staged in LDS.
 #include "common.h"
+#include "svd_linpack.h"
 #include <complex>
 #include <cmath>
 
@@ -37,63 +38,10 @@ struct BfState {
   DevBuf<double2> d_wq, d_B, d_P0, d_state; DevBuf<double> d_diag; bool rlsDirty = true;
 };
 
-// Hestenes one-sided Jacobi SVD, complex<float>, square n x n, column-major a(i,j)=a[i+j*n].
-// On return: columns of a are u_j*s_j, v holds the right singular vectors.
-static void jacobi_svd_cf(std::vector<cf>& a, std::vector<cf>& v, int n)
-{
-  v.assign((size_t) n * n, cf(0.f, 0.f));
-  for (int i = 0; i < n; i++) v[i + (size_t) i * n] = cf(1.f, 0.f);
-  for (int sweep = 0; sweep < 64; sweep++) {
-    bool rotated = false;
-    for (int p = 0; p + 1 < n; p++)
-      for (int q = p + 1; q < n; q++) {
-        float alpha = 0.f, beta = 0.f; cf gamma(0.f, 0.f);
-        for (int i = 0; i < n; i++) {
-          const cf x = a[i + (size_t) p * n], y = a[i + (size_t) q * n];
-          alpha += std::norm(x); beta += std::norm(y); gamma += std::conj(x) * y;
-        }
-        const float g = std::abs(gamma);
-        if (g == 0.f || g <= 1e-7f * std::sqrt(alpha * beta)) continue;
-        rotated = true;
-        const cf phase = gamma / g;
-        const float zeta = (beta - alpha) / (2.f * g);
-        const float t = (zeta >= 0.f ? 1.f : -1.f) / (std::fabs(zeta) + std::sqrt(1.f + zeta * zeta));
-        const float cs = 1.f / std::sqrt(1.f + t * t), sn = cs * t;
-        const cf e1 = sn * std::conj(phase), e2 = sn * phase;
-        for (int i = 0; i < n; i++) {
-          cf& x = a[i + (size_t) p * n]; cf& y = a[i + (size_t) q * n];
-          const cf nx = cs * x - e1 * y, ny = e2 * x + cs * y; x = nx; y = ny;
-          cf& vx = v[i + (size_t) p * n]; cf& vy = v[i + (size_t) q * n];
-          const cf nvx = cs * vx - e1 * vy, nvy = e2 * vx + cs * vy; vx = nvx; vy = nvy;
-        }
-      }
-    if (!rotated) break;
-  }
-}
-
-// beamformer.cc:253-305.  A, invA row-major n x n.  Returns false when a singular value fell
-// below the threshold (the caller then uses identity, :2425-2427).
-static bool pseudoinverse_cf(const zc* A, zc* invA, int n, float thr)
-{
-  std::vector<cf> a((size_t) n * n), v;
-  for (int i = 0; i < n; i++) for (int j = 0; j < n; j++) a[i + (size_t) j * n] = cf((float) A[(size_t) i * n + j].real(), (float) A[(size_t) i * n + j].imag());
-  jacobi_svd_cf(a, v, n);
-  std::vector<float> sinv(n); bool ok = true;
-  std::vector<cf> u((size_t) n * n);
-  for (int j = 0; j < n; j++) {
-    float s = 0.f; for (int i = 0; i < n; i++) s += std::norm(a[i + (size_t) j * n]);
-    s = std::sqrt(s);
-    for (int i = 0; i < n; i++) u[i + (size_t) j * n] = s > 0.f ? a[i + (size_t) j * n] / s : cf(0.f, 0.f);
-    if (std::fabs(s) < thr) { sinv[j] = 0.f; ok = false; } else sinv[j] = 1.f / s;
-  }
-  for (int i = 0; i < n; i++)
-    for (int j = 0; j < n; j++) {
-      cf x(0.f, 0.f);
-      for (int k = 0; k < n; k++) x = x + v[j + (size_t) k * n] * sinv[k] * std::conj(u[i + (size_t) k * n]);
-      invA[(size_t) j * n + i] = zc(x.real(), x.imag());
-    }
-  return ok;
-}
+// beamformer.cc:253-305: the reference's pseudo-inverse runs LINPACK's csvdc in complex<float>; svd_linpack.cpp restates that routine
+// operation for operation (pinned against the reference's own csvdc: tests/golden/linpack_csvdc.npz).  A, invA row-major n x n.  Returns
+// false when a singular value fell below the threshold (the caller then uses identity, :2425-2427).
+static bool pseudoinverse_cf(const zc* A, zc* invA, int n, float thr) { return linpack::pseudoinverse(A, invA, n, n, thr); }
 
 static double sinc_pi(double x) { return std::fabs(x) < 1e-300 ? 1.0 : std::sin(M_PI * x) / (M_PI * x); }   // gsl_sf_sinc
 
@@ -413,6 +361,15 @@ dsr_status dsr_bf_set_noise_matrix(dsr_bf* s, int f, const double* Rnn)
     for (int i = 0; i < C * C; i++) s->R[(size_t) f * C * C + i] = zc(Rnn[2 * i], Rnn[2 * i + 1]);
   });
 }
+// pseudoinverse(A, invA, dThreshold) (beamformer.cc:253-305) by itself: host-side, no device needed
+dsr_status dsr_pseudoinverse(const double* A, int rows, int cols, float dThreshold, double* invA, int* ok, float* svals)
+{
+  return guard([&] {
+    if (!A || !invA || rows < 1 || cols < 1) throw Error(DSR_E_PARAMETER, "bad argument");
+    const bool r = linpack::pseudoinverse(reinterpret_cast<const zc*>(A), reinterpret_cast<zc*>(invA), rows, cols, dThreshold, svals);
+    if (ok) *ok = r ? 1 : 0;
+  });
+}
 dsr_status dsr_bf_calc_mvdr_weights(dsr_bf* s, double fs, double thr)
 {
   (void) fs;
@@ -433,7 +390,9 @@ dsr_status dsr_bf_calc_mvdr_weights(dsr_bf* s, double fs, double thr)
       for (int i = 0; i < C; i++) { zc acc(0, 0); for (int j = 0; j < C; j++) acc += std::conj(invR[(size_t) j * C + i]) * d[j]; tmpH[i] = acc; }
       zc Lambda(0, 0); for (int i = 0; i < C; i++) Lambda += std::conj(tmpH[i]) * d[i];
       const zc norm = Lambda * (double) C;
-      for (int c = 0; c < C; c++) s->mvdr[(size_t) f * C + c] = tmpH[c] / norm;
+      // gsl_complex_div (GSL complex/math.c): scale by 1/|b| first -- restated so that the last bit does not depend on a runtime's __divdc3
+      const double sN = 1.0 / std::hypot(norm.real(), norm.imag()), sbr = sN * norm.real(), sbi = sN * norm.imag();
+      for (int c = 0; c < C; c++) s->mvdr[(size_t) f * C + c] = zc((tmpH[c].real() * sbr + tmpH[c].imag() * sbi) * sN, (tmpH[c].imag() * sbr - tmpH[c].real() * sbi) * sN);
     }
     s->haveMvdr = true; s->dirty = true;
   });

@@ -9,6 +9,7 @@
 // so that a wave's accesses to one entry are contiguous.  Arithmetic is fp64 in the reference's order (this file is
 // compiled with -ffp-contract=off); the snapshots and the beamformer output are the pipe's complex64 arrays.
 #include "common.h"
+#include "svd_linpack.h"
 #include <complex>
 #include <cmath>
 
@@ -237,52 +238,20 @@ using namespace dsr;
 struct dsr_zelinski : ZelinskiPlan {};
 
 
-// d^H pinv(R) d with the Moore-Penrose pseudo-inverse through a one-sided Jacobi SVD in double precision (columns of A V are
-// orthogonalised by complex plane rotations; singular values = column norms).  The reference's pseudoinverse (beamformer.cc:253-300) runs
-// LINPACK csvdc in single precision and reports failure when a singular value is below minSV.
+// calcInverseNoiseSpatialSpectralMatrix + calcLambda (postfilter.cc:980-1009): invR = pseudoinverse(R, minSV) -- LINPACK csvdc in
+// complex<float>, restated in svd_linpack.cpp -- replaced by the identity when a singular value falls below minSV; tmpH = invR^H d,
+// Lambda = tmpH^H d in double.
 static double2 lefkimmiatis_lambda(const double* Rf, const double* df, int C, double minSV)
 {
   typedef std::complex<double> cd;
-  std::vector<cd> A((size_t) C * C), V((size_t) C * C, cd(0.0, 0.0));      // column major: A[i + j*C]
-  for (int i = 0; i < C; i++) { V[i + (size_t) i * C] = 1.0; for (int j = 0; j < C; j++) A[i + (size_t) j * C] = cd(Rf[2 * (i * C + j)], Rf[2 * (i * C + j) + 1]); }
-  for (int sweep = 0; sweep < 60; sweep++) {
-    double off = 0.0;
-    for (int p = 0; p < C - 1; p++)
-      for (int q = p + 1; q < C; q++) {
-        double al = 0.0, be = 0.0; cd g(0.0, 0.0);
-        for (int i = 0; i < C; i++) { al += std::norm(A[i + (size_t) p * C]); be += std::norm(A[i + (size_t) q * C]); g += std::conj(A[i + (size_t) p * C]) * A[i + (size_t) q * C]; }
-        const double ag = std::abs(g);
-        if (ag <= 1e-300 || ag <= 1e-15 * std::sqrt(al * be)) continue;
-        off += ag;
-        const cd ph = g / ag;                                                  // a_q e^{-i phi}: the inner product becomes real
-        const double zeta = (be - al) / (2.0 * ag);
-        const double t = (zeta >= 0.0 ? 1.0 : -1.0) / (std::fabs(zeta) + std::sqrt(1.0 + zeta * zeta));
-        const double c = 1.0 / std::sqrt(1.0 + t * t), sn = c * t;
-        for (int i = 0; i < C; i++) {
-          const cd ap = A[i + (size_t) p * C], aq = A[i + (size_t) q * C] * std::conj(ph);
-          A[i + (size_t) p * C] = c * ap - sn * aq; A[i + (size_t) q * C] = sn * ap + c * aq;
-          const cd vp = V[i + (size_t) p * C], vq = V[i + (size_t) q * C] * std::conj(ph);
-          V[i + (size_t) p * C] = c * vp - sn * vq; V[i + (size_t) q * C] = sn * vp + c * vq;
-        }
-      }
-    if (off == 0.0) break;
+  std::vector<cd> inv((size_t) C * C), tmpH(C);
+  if (!linpack::pseudoinverse(reinterpret_cast<const cd*>(Rf), inv.data(), C, C, (float) minSV)) {
+    std::fill(inv.begin(), inv.end(), cd(0.0, 0.0));
+    for (int i = 0; i < C; i++) inv[(size_t) i * C + i] = cd(1.0, 0.0);
   }
-  // pinv = V diag(1/s) U^H with U_k = A_k / s_k  =>  pinv = sum_k V_k A_k^H / s_k^2 ;  Lambda = (pinv^H d)^H d = d^H pinv d
-  // a matrix that loses a singular value to the floor is replaced by the identity (calcInverseNoiseSpatialSpectralMatrix, postfilter.cc:989-991:
-  // pseudoinverse() returns false then): Lambda = d^H d
-  for (int k = 0; k < C; k++) {
-    double s2 = 0.0; for (int i = 0; i < C; i++) s2 += std::norm(A[i + (size_t) k * C]);
-    if (std::sqrt(s2) < minSV) { double n2 = 0.0; for (int i = 0; i < C; i++) n2 += df[2 * i] * df[2 * i] + df[2 * i + 1] * df[2 * i + 1]; return make_double2(n2, 0.0); }
-  }
+  for (int i = 0; i < C; i++) { cd a(0.0, 0.0); for (int j = 0; j < C; j++) a += std::conj(inv[(size_t) j * C + i]) * cd(df[2 * j], df[2 * j + 1]); tmpH[i] = a; }
   cd lam(0.0, 0.0);
-  for (int k = 0; k < C; k++) {
-    double s2 = 0.0; for (int i = 0; i < C; i++) s2 += std::norm(A[i + (size_t) k * C]);
-    const double sv = std::sqrt(s2);
-    if (sv == 0.0) continue;
-    cd dv(0.0, 0.0), ad(0.0, 0.0);                                             // d^H V_k  and  A_k^H d
-    for (int i = 0; i < C; i++) { const cd d(df[2 * i], df[2 * i + 1]); dv += std::conj(d) * V[i + (size_t) k * C]; ad += std::conj(A[i + (size_t) k * C]) * d; }
-    lam += dv * ad / s2;
-  }
+  for (int i = 0; i < C; i++) lam += std::conj(tmpH[i]) * cd(df[2 * i], df[2 * i + 1]);
   return make_double2(lam.real(), lam.imag());
 }
 

@@ -6,6 +6,7 @@ a HIP device is missing the call raises.
 """
 import ctypes as C
 import os
+import re
 
 import numpy as np
 
@@ -47,6 +48,51 @@ class DecodeResult(C.Structure):
                 ("nWords", i32), ("status", i32), ("maxActiveSeen", i32), ("activeHypos", i64), ("placements", i64), ("registerFrames", i64)]
 
 
+_HEADER = os.path.join(os.path.dirname(os.path.dirname(_HERE)), "include", "dsr.h")
+_SCALARS = {"int": C.c_int, "dsr_status": C.c_int, "unsigned": C.c_uint, "unsigned int": C.c_uint, "uint32_t": C.c_uint32, "int32_t": C.c_int32,
+            "int64_t": C.c_int64, "size_t": C.c_size_t, "float": C.c_float, "double": C.c_double, "uint8_t": C.c_uint8}
+
+
+def _ctype_of(decl):
+    """ctypes type of one C parameter / return declaration of include/dsr.h (pointers are opaque: c_void_p; const char* is c_char_p)."""
+    d = re.sub(r"/\*.*?\*/", " ", decl).strip()
+    if "*" in d or "[" in d:
+        return C.c_char_p if re.match(r"^const\s+char\s*\*\s*\w*$", d) else C.c_void_p
+    d = re.sub(r"\bconst\b", " ", d).strip()
+    toks = d.split()
+    for k in (2, 1):                                   # "unsigned int x", "int x", or a bare type
+        for cand in (" ".join(toks[:k]),):
+            if cand in _SCALARS and len(toks) <= k + 1:
+                return _SCALARS[cand]
+    raise ValueError("include/dsr.h: cannot map parameter %r" % decl)
+
+
+def header_prototypes(path=None):
+    """{name: (restype, [argtypes])} for every function include/dsr.h declares -- the single source of the ctypes signatures, so that no
+    entry point is ever called with libffi's default int promotion (a 64-bit stride passed as a 32-bit int reads stack garbage)."""
+    text = open(path or _HEADER).read()
+    text = re.sub(r"/\*.*?\*/", " ", text, flags=re.S)
+    text = re.sub(r"//[^\n]*", " ", text)
+    text = re.sub(r"^\s*#.*$", " ", text, flags=re.M)
+    text = re.sub(r"typedef\s+struct\s*\{.*?\}\s*\w+\s*;", " ", text, flags=re.S)
+    text = re.sub(r"\benum\s*\{.*?\}\s*;", " ", text, flags=re.S)
+    out = {}
+    for m in re.finditer(r"([A-Za-z_][\w\s\*]*?)\b(dsr_\w+)\s*\(([^;{}]*?)\)\s*;", text):
+        ret, name, args = m.group(1).strip(), m.group(2), m.group(3).strip()
+        if ret.startswith("typedef") or not ret:
+            continue
+        restype = None if ret == "void" else _ctype_of(ret)
+        argtypes = [] if args in ("", "void") else [_ctype_of(a) for a in args.split(",")]
+        out[name] = (restype, argtypes)
+    return out
+
+
+def declare_from_header(L):
+    for name, (restype, argtypes) in header_prototypes().items():
+        fn = getattr(L, name)                          # AttributeError here = a declared symbol the library does not export
+        fn.restype = restype; fn.argtypes = argtypes
+
+
 def load():
     """Load the library.  torch is imported first so that its HIP runtime (same SONAME) is the one bound."""
     global _lib
@@ -56,58 +102,7 @@ def load():
     if not os.path.exists(_LIBPATH):
         raise ImportError("libdsr_hip.so is not built: run `python -c 'import __graft_entry__ as g; g.build()'` (%s)" % _LIBPATH)
     L = C.CDLL(_LIBPATH)
-    L.dsr_last_error.restype = C.c_char_p
-    L.dsr_version.restype = C.c_char_p
-    sig = {
-        "dsr_fb_create": [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp],
-        "dsr_fb_destroy": [vp], "dsr_fb_analysis_frames": [vp, C.c_int], "dsr_fb_synthesis_blocks": [vp, C.c_int],
-        "dsr_fb_processing_delay": [vp], "dsr_fb_block_len": [vp],
-        "dsr_fb_analysis": [vp, vp, vp, C.c_int, C.c_int, i64, C.c_int, vp, vp],
-        "dsr_fb_synthesis": [vp, vp, vp, C.c_int, C.c_int, i64, vp, vp],
-        "dsr_bf_create": [C.c_int, C.c_int, C.c_int, vp], "dsr_bf_destroy": [vp], "dsr_bf_fft_len": [vp], "dsr_bf_chan_n": [vp],
-        "dsr_bf_calc_array_manifold": [vp, f64, vp], "dsr_calc_delays_polar2": [f32, f32, vp, C.c_int, vp],
-        "dsr_bf_set_diffuse_noise_model": [vp, vp, f64, f64], "dsr_bf_divide_nondiagonal": [vp, f32],
-        "dsr_bf_diagonal_loading": [vp, f32], "dsr_bf_set_noise_matrix": [vp, C.c_int, vp],
-        "dsr_bf_calc_mvdr_weights": [vp, f64, f64], "dsr_bf_calc_gsc_weights": [vp, f64, vp],
-        "dsr_bf_calc_blocking_matrix2": [vp], "dsr_bf_upgrade_blocking_matrix": [vp], "dsr_bf_blocking_matrix_output": [vp, vp, C.c_int, C.c_int, C.c_int, vp, vp],
-        "dsr_bf_rls_config": [vp, f32, f32], "dsr_bf_rls_init_precision": [vp, f32], "dsr_bf_rls_set_precision": [vp, C.c_int, vp],
-        "dsr_bf_rls_quadratic_constraint": [vp, f32, C.c_int], "dsr_bf_rls_adapt": [vp, C.c_int], "dsr_bf_gsc_rls": [vp, vp, C.c_int, C.c_int, vp, vp, vp],
-        "dsr_bf_set_active_weights": [vp, C.c_int, vp], "dsr_bf_zero_active_weights": [vp], "dsr_bf_select": [vp, C.c_int],
-        "dsr_bf_get": [vp, C.c_int, vp, C.c_size_t], "dsr_bf_apply": [vp, vp, C.c_int, C.c_int, vp, vp],
-        "dsr_prfb_create": [vp, C.c_int, C.c_int, C.c_int, vp], "dsr_prfb_destroy": [vp], "dsr_prfb_fft_len": [vp], "dsr_prfb_block_len": [vp],
-        "dsr_prfb_analysis_frames": [vp, C.c_int], "dsr_prfb_synthesis_blocks": [vp, C.c_int],
-        "dsr_prfb_analysis": [vp, vp, vp, C.c_int, C.c_int, i64, C.c_int, vp, vp], "dsr_prfb_synthesis": [vp, vp, vp, C.c_int, C.c_int, i64, vp, vp],
-        "dsr_stft_create": [C.c_int, C.c_int, C.c_int, vp], "dsr_stft_destroy": [vp], "dsr_stft_frames": [vp, C.c_int], "dsr_stft_block_len": [vp],
-        "dsr_stft_analysis": [vp, vp, vp, C.c_int, C.c_int, i64, C.c_int, vp, vp],
-        "dsr_wpe_single": [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, f64, f64, f64, vp, vp, vp],
-        "dsr_wpe_multi": [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, f64, f64, f64, C.c_int, vp, vp, vp],
-        "dsr_zelinski_create": [C.c_int, C.c_int, f64, C.c_int, C.c_int, vp], "dsr_zelinski_destroy": [vp], "dsr_zelinski_set_manifold": [vp, C.c_int, vp],
-        "dsr_mccowan_create": [C.c_int, C.c_int, f64, C.c_int, C.c_int, f32, vp], "dsr_lefkimmiatis_create": [C.c_int, C.c_int, f64, C.c_int, f64, C.c_int, C.c_int, f32, vp], "dsr_mccowan_set_noise_matrix": [vp, C.c_int, vp],
-        "dsr_mccowan_set_diffuse_noise_model": [vp, vp, f64, f64], "dsr_mccowan_diagonal_loading": [vp, C.c_int, f32], "dsr_mccowan_divide_nondiagonal": [vp, f32],
-        "dsr_zelinski_apply": [vp, vp, vp, vp, C.c_int, C.c_int, vp, vp, vp],
-        "dsr_lpc_create": [C.c_int, C.c_int, C.c_int, f32, C.c_int, C.c_int, vp], "dsr_lpc_destroy": [vp], "dsr_lpc_size": [vp],
-        "dsr_lpc_run": [vp, vp, i64, vp, vp],
-        "dsr_mfcc_default_cfg": [vp], "dsr_mfcc_create": [vp, vp, vp], "dsr_mfcc_destroy": [vp], "dsr_mfcc_frames": [vp, C.c_int],
-        "dsr_mfcc_out_dim": [vp], "dsr_mfcc_run": [vp, vp, vp, C.c_int, i64, C.c_int, C.c_int, vp, vp],
-        "dsr_gmm_create": [C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, vp], "dsr_gmm_load": [C.c_char_p, C.c_char_p, vp],
-        "dsr_gmm_save": [vp, C.c_char_p, C.c_char_p], "dsr_gmm_destroy": [vp], "dsr_gmm_num_dists": [vp], "dsr_gmm_dim": [vp],
-        "dsr_gmm_score": [vp, vp, i64, C.c_int, vp, vp, vp],
-        "dsr_wfst_create": [vp], "dsr_wfst_destroy": [vp], "dsr_wfst_read": [vp, C.c_char_p, C.c_int],
-        "dsr_wfst_write": [vp, C.c_char_p, C.c_int], "dsr_wfst_add_arc": [vp, C.c_uint, C.c_uint, C.c_uint, C.c_uint, f32],
-        "dsr_wfst_add_final": [vp, C.c_uint, f32], "dsr_wfst_num_nodes": [vp], "dsr_wfst_num_arcs": [vp],
-        "dsr_wfst_export": [vp] * 9,
-        "dsr_decoder_default_cfg": [vp], "dsr_decoder_create": [vp, vp], "dsr_decoder_destroy": [vp], "dsr_decoder_set": [vp, vp],
-        "dsr_decoder_set_beam": [vp, f64], "dsr_decoder_enable_dump": [vp, C.c_int],
-        "dsr_decoder_decode_batch": [vp, vp, vp, C.c_int, C.c_int, C.c_int, vp, vp, vp, C.c_int, vp],
-        "dsr_decoder_get_dump": [vp] * 7,
-        "dsr_pipe_create": [vp, vp, vp, vp, vp, vp, C.c_int, vp], "dsr_pipe_destroy": [vp],
-        "dsr_pipe_run": [vp, vp, vp, vp, C.c_int, C.c_int, i64, vp, vp, vp, C.c_int, vp],
-        "dsr_pipe_stage_ms": [vp, vp], "dsr_pipe_intermediate": [vp, C.c_int, vp, vp],
-        "dsr_memcpy_dtoh": [vp, vp, C.c_size_t, vp],
-        "dsr_device_count": [vp], "dsr_set_device": [C.c_int], "dsr_stream_synchronize": [vp],
-    }
-    for name, args in sig.items():
-        getattr(L, name).argtypes = args
+    declare_from_header(L)
     _lib = L
     return L
 
@@ -561,7 +556,6 @@ class Wfst:
 
     def read_dynamic(self, fileName, noSelfLoops=False):
         """WFSTransducer::read (asr/fsm/fsm.cc:901-986)"""
-        _lib.dsr_wfst_read_dynamic.argtypes = [vp, C.c_char_p, C.c_int]
         check(_lib.dsr_wfst_read_dynamic(self.h, fileName.encode(), int(noSelfLoops)))
 
     def write(self, fileName, binary=True):

@@ -6,48 +6,11 @@ import numpy as np
 from .. import _capi as K
 
 _NP = {0: np.int8, 1: np.int16, 2: np.float32, 3: np.float64, 4: np.complex128}
-_declared = False
 
 
 def lib():
-    global _declared
-    L = K.load()
-    if not _declared:
-        vp, ci = C.c_void_p, C.c_int
-        L.dsr_stream_name.restype = C.c_char_p
-        sig = {"dsr_stream_next": [vp, ci, vp, vp], "dsr_stream_current": [vp, vp, vp], "dsr_stream_reset": [vp],
-               "dsr_stream_size": [vp], "dsr_stream_type": [vp], "dsr_stream_frameX": [vp], "dsr_stream_is_end": [vp],
-               "dsr_stream_name": [vp], "dsr_stream_retain": [vp], "dsr_stream_release": [vp],
-               "dsr_sample_feature_create": [ci, ci, ci, C.c_char_p, vp], "dsr_sample_feature_set_samples": [vp, vp, C.c_size_t, C.c_uint],
-               "dsr_frame_source_create": [ci, ci, C.c_char_p, vp], "dsr_frame_source_set_frames": [vp, vp, C.c_size_t],
-               "dsr_analysis_bank_create": [vp, vp, ci, ci, ci, ci, C.c_char_p, vp],
-               "dsr_synthesis_bank_create": [vp, vp, ci, ci, ci, ci, ci, C.c_char_p, vp],
-               "dsr_normal_fft_bank_create": [vp, ci, ci, ci, C.c_char_p, vp],
-               "dsr_pr_analysis_bank_create": [vp, vp, ci, ci, ci, C.c_char_p, vp], "dsr_pr_synthesis_bank_create": [vp, vp, ci, ci, ci, C.c_char_p, vp],
-               "dsr_wpe_single_stream_create": [vp, ci, ci, ci, C.c_double, C.c_double, C.c_double, C.c_char_p, vp],
-               "dsr_wpe_multi_feature_create": [vp, ci, ci, ci, ci, ci, C.c_double, C.c_double, C.c_double, C.c_char_p, vp],
-               "dsr_wpe_multi_feature_set_filter_channel": [vp, ci],
-               "dsr_zelinski_stream_create": [vp, ci, C.c_double, ci, ci, C.c_char_p, vp], "dsr_zelinski_stream_set_channel": [vp, vp],
-               "dsr_zelinski_stream_set_manifold": [vp, ci, vp, ci],
-               "dsr_mccowan_stream_create": [vp, ci, C.c_double, ci, ci, C.c_float, C.c_char_p, vp],
-               "dsr_highpass_filter_create": [vp, C.c_float, ci, C.c_char_p, vp],
-               "dsr_subband_orthogonalizer_create": [vp, ci, C.c_char_p, vp],
-               "dsr_lefkimmiatis_stream_create": [vp, ci, C.c_double, ci, C.c_double, ci, ci, C.c_float, C.c_char_p, vp],
-               "dsr_mccowan_stream_set_noise": [vp, ci, ci, vp, ci, C.c_double, C.c_double],
-               "dsr_subband_bf_create": [vp, C.c_char_p, vp], "dsr_subband_bf_set_channel": [vp, vp],
-               "dsr_preemphasis_create": [vp, C.c_double, C.c_char_p, vp], "dsr_hamming_create": [vp, C.c_char_p, vp],
-               "dsr_fft_create": [vp, ci, C.c_char_p, vp], "dsr_spectral_power_create": [vp, ci, C.c_char_p, vp],
-               "dsr_vtln_create": [vp, ci, C.c_double, C.c_double, ci, C.c_char_p, vp],
-               "dsr_mel_create": [vp, ci, C.c_float, C.c_float, C.c_float, ci, ci, C.c_char_p, vp],
-               "dsr_log_create": [vp, C.c_double, C.c_double, ci, C.c_char_p, vp], "dsr_cepstral_create": [vp, ci, ci, C.c_char_p, vp],
-               "dsr_lpc_feature_create": [vp, ci, ci, C.c_float, ci, ci, C.c_char_p, vp],
-               "dsr_storage_create": [vp, C.c_char_p, vp], "dsr_mean_subtraction_create": [vp, C.c_double, ci, C.c_char_p, vp],
-               "dsr_adjacent_create": [vp, ci, C.c_char_p, vp], "dsr_linear_transform_create": [vp, ci, C.c_char_p, vp],
-               "dsr_linear_transform_set": [vp, vp]}
-        for n, a in sig.items():
-            getattr(L, n).argtypes = a
-        _declared = True
-    return L
+    """the loaded library; every signature comes from include/dsr.h (dsr._capi.declare_from_header)"""
+    return K.load()
 
 
 class FeatureStreamPtr(object):

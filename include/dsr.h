@@ -108,6 +108,10 @@ dsr_status dsr_bf_divide_nondiagonal(dsr_bf*, float myu);
 dsr_status dsr_bf_diagonal_loading(dsr_bf*, float diagonalWeight);
 dsr_status dsr_bf_set_noise_matrix(dsr_bf*, int fbinX, const double* Rnn /*[C][C] complex*/);
 dsr_status dsr_bf_calc_mvdr_weights(dsr_bf*, double sampleRate, double dThreshold);
+/* pseudoinverse(A, invA, dThreshold) (beamformer.cc:253-305): LINPACK csvdc (btk/matrix/linpack_c.cc:9518, job 11) in complex<float>,
+   V diag(1/s) U^H with singular values below dThreshold dropped.  A [rows][cols] complex128 row major (host) -> invA [cols][rows];
+   *ok = the reference's return value (0: a singular value was dropped or csvdc did not converge); svals (optional) min(rows, cols) floats. */
+dsr_status dsr_pseudoinverse(const double* A, int rows, int cols, float dThreshold, double* invA, int* ok, float* svals);
 /* SubbandGSC: calcGSCWeights (blocking matrices), setActiveWeights_f, zeroActiveWeights
    (beamformer.cc:1373-1447, 761-799, 398-479) */
 dsr_status dsr_bf_calc_gsc_weights(dsr_bf*, double sampleRate, const double* delays);

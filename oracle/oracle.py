@@ -94,6 +94,7 @@ def _bind(L):
     L.orc_divide_nondiag.argtypes = [c_vp, c_int, c_int, c_flt]
     L.orc_diagonal_loading.argtypes = [c_vp, c_int, c_int, c_flt]
     L.orc_pseudoinverse.argtypes = [c_vp, c_int, c_vp, c_flt]
+    L.orc_csvdc.argtypes = [c_vp, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_int, c_vp, c_int]
     L.orc_mvdr_weights.argtypes = [c_vp, c_vp, c_int, c_int, c_dbl, c_vp]
     L.orc_preemphasis.argtypes = [c_vp, c_int, c_int, c_dbl, c_vp]
     L.orc_vtln.argtypes = [c_vp, c_int, c_int, c_dbl, c_dbl, c_int, c_vp]
@@ -206,6 +207,25 @@ def pseudoinverse(A, thr=1e-8):
     out = np.zeros((n, n), np.complex128)
     ok = lib().orc_pseudoinverse(_p(A.view(np.float64)), n, _p(out.view(np.float64)), thr)
     return out, bool(ok)
+
+
+def csvdc(A):
+    """LINPACK csvdc (job 11) as restated in orc_svd.c: A (n x p) -> (info, s[min(n, p)], U [n][n], V [p][p]) complex64"""
+    A = np.asarray(A); n, p = A.shape
+    a = np.asfortranarray(A.astype(np.complex64)); s = np.zeros(2 * (n + p) + 2, np.complex64); e = np.zeros(2 * (n + p) + 2, np.complex64)
+    u = np.zeros((n, n), np.complex64, order="F"); v = np.zeros((p, p), np.complex64, order="F")
+    info = lib().orc_csvdc(_p(a), n, n, p, _p(s), _p(e), _p(u), n, _p(v), p)
+    return info, s[:min(n, p)].copy(), u, v
+
+
+def ref_csvdc(A):
+    """the reference's own csvdc through oracle/_ref (authoring container only); same returns as csvdc()"""
+    R = ref_linpack()
+    A = np.asarray(A); n, p = A.shape
+    a = np.asfortranarray(A.astype(np.complex64)); s = np.zeros(2 * (n + p) + 2, np.complex64); e = np.zeros(2 * (n + p) + 2, np.complex64)
+    u = np.zeros((n, n), np.complex64, order="F"); v = np.zeros((p, p), np.complex64, order="F")
+    info = R.ref_csvdc(_p(a), n, n, p, _p(s), _p(e), _p(u), n, _p(v), p, 11)
+    return info, s[:min(n, p)].copy(), u, v
 
 
 def mvdr_weights(wq, R, thr=1e-8):

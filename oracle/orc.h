@@ -77,6 +77,8 @@ void orc_divide_nondiag(double* R, int C, int M, float mu);
 void orc_diagonal_loading(double* R, int C, int M, float w);
 /* complex<float> SVD based pseudo inverse (beamformer.cc:253-305). returns 1 ok / 0 failed */
 int  orc_pseudoinverse(const double* A, int n, double* invA, float thr);
+/* LINPACK csvdc, job 11 (orc_svd.c): interleaved complex<float>, column major; s, e hold 2 (n + p) + 2 entries */
+int  orc_csvdc(float* x, int ldx, int n, int p, float* s, float* e, float* u, int ldu, float* v, int ldv);
 void orc_mvdr_weights(const double* wq, const double* R, int C, int M, double thr,
                       double* w /*[M/2+1][C][2]*/);
 /* X: [C][T][M] complex double; W: [M/2+1][C] (DS uses wq[0..M/2]); Y: [T][M] */

@@ -11,10 +11,9 @@
  *   btk/beamformer/beamformer.cc:61-90,1137-1200,2583-2635 SnapShotArray + DS/MVDR next()
  *   btk/beamformer/beamformer.cc:398-479   _calcBlockingMatrix
  *   btk/beamformer/beamformer.cc:1251-1287,1297-1363 calcOutputOfGSC / SubbandGSC::next
- * The reference's SVD is LINPACK csvdc (in-tree third party, btk/matrix/linpack_c.cc:9518);
- * here the SVD is restated as a one-sided Jacobi iteration in complex<float>, and the
- * resulting pseudo-inverse is pinned against csvdc built from the reference sources
- * (oracle/_ref/, tests/test_oracle_linpack.py).
+ * The reference's SVD is LINPACK csvdc (in-tree third party, btk/matrix/linpack_c.cc:9518),
+ * restated in orc_svd.c and pinned bit for bit against csvdc built from the reference
+ * sources (oracle/_ref/, tests/test_oracle_cpu.py).
  */
 #include "orc.h"
 #include <math.h>
@@ -107,71 +106,7 @@ void orc_diagonal_loading(double* R, int C, int M, float w)
   }
 }
 
-/* One-sided (Hestenes) Jacobi SVD in complex<float>: A (n x n, column major a[i+j*n])
-   -> U diag(s) V^H.  Works on the columns of A; V accumulates the rotations. */
-static void csvd_jacobi(cc* a, int n, float* s, cc* u, cc* v)
-{
-  for (int i = 0; i < n; i++) for (int j = 0; j < n; j++) v[i + j*n] = (i == j) ? 1.0f : 0.0f;
-  for (int sweep = 0; sweep < 60; sweep++) {
-    float off = 0.0f;
-    for (int p = 0; p < n - 1; p++)
-      for (int q = p + 1; q < n; q++) {
-        float app = 0.0f, aqq = 0.0f; cc apq = 0.0f;
-        for (int i = 0; i < n; i++) {
-          app += crealf(a[i+p*n] * conjf(a[i+p*n]));
-          aqq += crealf(a[i+q*n] * conjf(a[i+q*n]));
-          apq += conjf(a[i+p*n]) * a[i+q*n];
-        }
-        float mag = cabsf(apq);
-        if (mag <= 1e-30f || mag <= 1e-7f * sqrtf(app * aqq)) continue;
-        off = fmaxf(off, mag / sqrtf(app * aqq + 1e-38f));
-        cc ph = apq / mag;                         /* unit phase */
-        float tau = (aqq - app) / (2.0f * mag);
-        float t = (tau >= 0.0f ? 1.0f : -1.0f) / (fabsf(tau) + sqrtf(1.0f + tau * tau));
-        float c = 1.0f / sqrtf(1.0f + t * t), sn = c * t;
-        for (int i = 0; i < n; i++) {
-          cc x = a[i+p*n], y = a[i+q*n];
-          a[i+p*n] = c * x - sn * conjf(ph) * y;
-          a[i+q*n] = sn * ph * x + c * y;
-          cc vx = v[i+p*n], vy = v[i+q*n];
-          v[i+p*n] = c * vx - sn * conjf(ph) * vy;
-          v[i+q*n] = sn * ph * vx + c * vy;
-        }
-      }
-    if (off < 1e-7f) break;
-  }
-  for (int j = 0; j < n; j++) {
-    float nr = 0.0f;
-    for (int i = 0; i < n; i++) nr += crealf(a[i+j*n] * conjf(a[i+j*n]));
-    nr = sqrtf(nr); s[j] = nr;
-    for (int i = 0; i < n; i++) u[i+j*n] = (nr > 0.0f) ? a[i+j*n] / nr : 0.0f;
-  }
-}
-
-int orc_pseudoinverse(const double* A, int n, double* invA, float thr)
-{
-  /* beamformer.cc:253-305: everything in complex<float>; singular values below the
-     threshold are zeroed and flag failure (the caller then substitutes identity). */
-  cc* a = (cc*) malloc(sizeof(cc) * n * n); cc* u = (cc*) malloc(sizeof(cc) * n * n);
-  cc* v = (cc*) malloc(sizeof(cc) * n * n); float* s = (float*) malloc(sizeof(float) * n);
-  cc* sinv = (cc*) malloc(sizeof(cc) * n);
-  int ret = 1;
-  for (int i = 0; i < n; i++) for (int j = 0; j < n; j++)
-    a[i + j*n] = (float) A[2*((size_t)i*n+j)] + I * (float) A[2*((size_t)i*n+j)+1];
-  csvd_jacobi(a, n, s, u, v);
-  for (int k = 0; k < n; k++) {
-    if (fabsf(s[k]) < thr) { sinv[k] = 0.0f; ret = 0; }
-    else sinv[k] = 1.0f / s[k];
-  }
-  for (int i = 0; i < n; i++)
-    for (int j = 0; j < n; j++) {
-      cc x = 0.0f;
-      for (int k = 0; k < n; k++) x = x + v[j+k*n] * sinv[k] * conjf(u[i+k*n]);
-      invA[2*((size_t)j*n+i)] = crealf(x); invA[2*((size_t)j*n+i)+1] = cimagf(x);
-    }
-  free(a); free(u); free(v); free(s); free(sinv);
-  return ret;
-}
+/* orc_pseudoinverse (beamformer.cc:253-305) and the LINPACK csvdc it rests on: orc_svd.c */
 
 void orc_mvdr_weights(const double* wq, const double* R, int C, int M, double thr, double* w)
 {
@@ -194,7 +129,13 @@ void orc_mvdr_weights(const double* wq, const double* R, int C, int M, double th
     zc Lambda = 0.0;                                        /* zdotc(tmpH, d) (:2431) */
     for (int i = 0; i < C; i++) Lambda += conj(tmpH[i]) * ZGET(d, i);
     zc norm = Lambda * (double) C;
-    for (int c = 0; c < C; c++) ZSET(w, (size_t) f * C + c, tmpH[c] / norm);
+    {                                                       /* gsl_complex_div(val, norm) (:2440): s = 1/|b|, then scaled products */
+      double sN = 1.0 / hypot(creal(norm), cimag(norm)), sbr = sN * creal(norm), sbi = sN * cimag(norm);
+      for (int c = 0; c < C; c++) {
+        double ar = creal(tmpH[c]), ai = cimag(tmpH[c]);
+        w[2 * ((size_t) f * C + c)] = (ar * sbr + ai * sbi) * sN; w[2 * ((size_t) f * C + c) + 1] = (ai * sbr - ar * sbi) * sN;
+      }
+    }
   }
   free(invR); free(tmpH);
 }

@@ -10,8 +10,9 @@ Outputs:
   proto_M*.npy              float64 [2][m*M]: row 0 analysis h, row 1 synthesis g
                             (text layout read by btk/src/superdirectiveBeamformer.cc:23-72)
   Lexicon.txt               copied verbatim (data)
-  linpack_csvdc.npz         seeded 8x8 / 4x4 complex matrices and the singular values + pseudo-inverse
-                            that the reference's own LINPACK csvdc (oracle/_ref) produces for them
+  linpack_csvdc.npz         seeded complex matrices (2x2 .. 64x64: random, diffuse-field coherence matrices of 8/16/64-microphone
+                            arrays, rank deficient, zero) and the singular values, U, V and pseudo-inverse that the reference's own
+                            LINPACK csvdc (oracle/_ref) produces for them
 """
 import os, sys, wave, shutil
 import numpy as np
@@ -31,35 +32,54 @@ for name in ("M=256-m=4-r=1", "M=512-m=2-r=2", "M=512-m=2-r=3"):
 shutil.copy(f"{REF}/asr/test/Lexicon.txt", f"{HERE}/Lexicon.txt")
 
 # --- LINPACK csvdc goldens through oracle/_ref (the reference's own sources) ---
-import ctypes as C
 from oracle import oracle as O
 O.build_ref()
-L = O.ref_linpack()
 rng = np.random.default_rng(20240607)
-mats, svals, pinvs = [], [], []
-for n in (8, 8, 8, 4, 2):
-    A = rng.standard_normal((n, n)) + 1j * rng.standard_normal((n, n))
-    if len(mats) == 1:   # a diffuse-noise-like Hermitian, badly conditioned matrix
-        d = np.abs(np.subtract.outer(np.arange(n), np.arange(n))) * 41.0
-        A = np.sinc(2 * 16000 * 3 / (256 * 343740.0) * d) / 1.01
-        np.fill_diagonal(A, 1.0); A = A.astype(np.complex128)
-    a = np.asfortranarray(A.astype(np.complex64))
-    s = np.zeros(2 * n, np.complex64); e = np.zeros(2 * n, np.complex64)
-    u = np.zeros((n, n), np.complex64, order="F"); v = np.zeros((n, n), np.complex64, order="F")
-    acopy = a.copy(order="F")
-    info = L.ref_csvdc(acopy.ctypes.data_as(C.c_void_p), n, n, n, s.ctypes.data_as(C.c_void_p), e.ctypes.data_as(C.c_void_p),
-                       u.ctypes.data_as(C.c_void_p), n, v.ctypes.data_as(C.c_void_p), n, 11)
-    assert info == 0
-    # pinv assembled exactly as beamformer.cc:284-302
-    sinv = np.where(np.abs(s[:n]) < 1e-8, 0, 1.0 / s[:n]).astype(np.complex64)
+
+
+def diffuse(n, f, pitch, M=256, fs=16000.0, c=343740.0, planar=False, mu=0.01):
+    """coherence matrix of a diffuse field as setDiffuseNoiseModel + divideAllNonDiagonalElements build it (beamformer.cc:2486-2553)"""
+    if planar:
+        k = int(round(np.sqrt(n))); pos = np.array([(i * pitch, j * pitch) for i in range(k) for j in range(k)], float)
+    else:
+        pos = np.stack([np.arange(n) * pitch, np.zeros(n)], 1)
+    d = np.sqrt(((pos[:, None, :] - pos[None, :, :]) ** 2).sum(-1))
+    A = np.sinc(2 * fs * f / (M * c) * d) / (1.0 + mu)
+    np.fill_diagonal(A, 1.0)
+    return A.astype(np.complex128)
+
+
+cases = [("rand8", rng.standard_normal((8, 8)) + 1j * rng.standard_normal((8, 8))),
+         ("diffuse8_f3", diffuse(8, 3, 41.0)),
+         ("rand8b", rng.standard_normal((8, 8)) + 1j * rng.standard_normal((8, 8))),
+         ("rand4", rng.standard_normal((4, 4)) + 1j * rng.standard_normal((4, 4))),
+         ("rand2", rng.standard_normal((2, 2)) + 1j * rng.standard_normal((2, 2))),
+         # round 2: the array sizes of BASELINE configs[4] (64 channels) and what lies between
+         ("rand16", rng.standard_normal((16, 16)) + 1j * rng.standard_normal((16, 16))),
+         ("diffuse16_f1", diffuse(16, 1, 20.0)),
+         ("diffuse64_f1", diffuse(64, 1, 20.0, planar=True)),
+         ("diffuse64_f40", diffuse(64, 40, 20.0, planar=True)),
+         ("diffuse64_f128", diffuse(64, 128, 20.0, planar=True)),
+         ("rand64", rng.standard_normal((64, 64)) + 1j * rng.standard_normal((64, 64))),
+         ("rank6of8", None), ("hermitian33", None), ("zero3", np.zeros((3, 3), complex))]
+B = rng.standard_normal((8, 6)) + 1j * rng.standard_normal((8, 6)); cases[11] = ("rank6of8", B @ B.conj().T)
+H = rng.standard_normal((33, 33)) + 1j * rng.standard_normal((33, 33)); cases[12] = ("hermitian33", H @ H.conj().T / 33)
+out = {}
+for i, (name, A) in enumerate(cases):
+    n = A.shape[0]
+    info, s, u, v = O.ref_csvdc(A)
+    # pinv assembled exactly as beamformer.cc:284-302 (complex<float> accumulation, k ascending)
+    thr = np.float32(1e-8)
+    sinv = np.array([np.complex64(0) if np.abs(x) < thr else np.complex64(1) / x for x in s], np.complex64)
     P = np.zeros((n, n), np.complex64)
-    for i in range(n):
-        for j in range(n):
+    for a_ in range(n):
+        for b_ in range(n):
             acc = np.complex64(0)
             for k in range(n):
-                acc = np.complex64(acc + v[j, k] * sinv[k] * np.conj(u[i, k]))
-            P[j, i] = acc
-    mats.append(A); svals.append(s[:n].copy()); pinvs.append(P)
-np.savez(f"{HERE}/linpack_csvdc.npz", **{f"A{i}": m for i, m in enumerate(mats)},
-         **{f"s{i}": m for i, m in enumerate(svals)}, **{f"P{i}": m for i, m in enumerate(pinvs)})
+                acc = np.complex64(acc + np.complex64(np.complex64(v[b_, k] * sinv[k]) * np.conj(u[a_, k])))
+            P[b_, a_] = acc
+    out["A%d" % i] = A; out["s%d" % i] = s; out["P%d" % i] = P; out["U%d" % i] = np.ascontiguousarray(u); out["V%d" % i] = np.ascontiguousarray(v)
+    out["info%d" % i] = np.int32(info)
+out["names"] = np.array([c[0] for c in cases])
+np.savez_compressed(f"{HERE}/linpack_csvdc.npz", **out)
 print("fixtures written to", HERE)

@@ -71,34 +71,48 @@ def test_normal_fft_bank(oracle):
 
 
 # ------------------------------------------------------------------ beamformer
-def test_pseudoinverse_pinned_by_linpack(oracle):
+def _csvdc_cases():
     z = np.load(os.path.join(GOLDEN, "linpack_csvdc.npz"))
-    for i in range(5):
-        A, P = z["A%d" % i], z["P%d" % i]
+    return z, [str(n) for n in z["names"]]
+
+
+def test_pseudoinverse_pinned_by_linpack(oracle):
+    """The oracle's csvdc restatement (orc_svd.c) against the outputs of the reference's own csvdc (built from the reference sources by
+    oracle/Makefile:_ref, outputs committed by tests/golden/make_fixtures.py): singular values, U, V and the pseudo-inverse assembled as
+    beamformer.cc:284-302 -- BIT FOR BIT, on 2x2 .. 64x64 matrices incl. the diffuse-field coherence matrices of 8/16/64-microphone arrays."""
+    z, names = _csvdc_cases()
+    assert len(names) >= 14 and "diffuse64_f1" in names
+    for i, name in enumerate(names):
+        A = z["A%d" % i]
+        info, s, u, v = oracle.csvdc(A)
+        assert info == int(z["info%d" % i]), name
+        assert np.array_equal(s.view(np.float32), z["s%d" % i].view(np.float32)), name
+        assert np.array_equal(np.ascontiguousarray(u).view(np.float32), z["U%d" % i].view(np.float32)), name
+        assert np.array_equal(np.ascontiguousarray(v).view(np.float32), z["V%d" % i].view(np.float32)), name
         Po, ok = oracle.pseudoinverse(A)
-        assert ok
-        assert np.abs(Po - P).max() / np.abs(P).max() < 1e-4
-        # singular values agree with csvdc's
-        s = np.sort(np.abs(z["s%d" % i]))[::-1]
-        assert np.abs(np.sort(np.linalg.svd(A.astype(np.complex64), compute_uv=False))[::-1] - s).max() / s[0] < 1e-5
+        assert np.array_equal(Po.astype(np.complex64).view(np.float32), z["P%d" % i].view(np.float32)), name
+        assert ok == bool(np.all(np.abs(z["s%d" % i]) >= np.float32(1e-8)) and info == 0), name
+        # and the routine is an SVD: singular values agree with LAPACK's on the same complex64 matrix
+        sl = np.linalg.svd(A.astype(np.complex64).astype(np.complex128), compute_uv=False)
+        assert np.abs(np.sort(s.real)[::-1] - sl).max() <= 2e-5 * max(sl[0], 1e-30), name
 
 
 def test_linpack_ref_live(oracle):
-    """When the reference sources are present (authoring container) run csvdc itself again."""
+    """When the reference sources are present (authoring container) run csvdc itself again, on fresh matrices: same bits."""
     if oracle.build_ref() is None:
         pytest.skip("/root/reference not present")
-    import ctypes as C
-    L = oracle.ref_linpack()
     rng = np.random.default_rng(99)
-    n = 6
-    A = (rng.standard_normal((n, n)) + 1j * rng.standard_normal((n, n)))
-    a = np.asfortranarray(A.astype(np.complex64)); s = np.zeros(2 * n, np.complex64); e = np.zeros(2 * n, np.complex64)
-    u = np.zeros((n, n), np.complex64, order="F"); v = np.zeros((n, n), np.complex64, order="F")
-    vp = lambda q: q.ctypes.data_as(C.c_void_p)
-    assert L.ref_csvdc(vp(a), n, n, n, vp(s), vp(e), vp(u), n, vp(v), n, 11) == 0
-    P = (v * (1.0 / s[:n])[None, :]) @ np.conj(u.T)
-    Po, ok = oracle.pseudoinverse(A)
-    assert ok and np.abs(Po - P).max() / np.abs(P).max() < 1e-4
+    for n, p in ((6, 6), (1, 1), (5, 9), (9, 5), (17, 17), (40, 40)):
+        for k in range(3):
+            A = rng.standard_normal((n, p)) + 1j * rng.standard_normal((n, p))
+            if k == 2 and n == p and n > 2:
+                B = rng.standard_normal((n, n - 2)); A = (B @ B.T).astype(np.complex128)         # rank deficient, real symmetric
+            ir, sr, ur, vr = oracle.ref_csvdc(A)
+            io, so, uo, vo = oracle.csvdc(A)
+            assert ir == io
+            assert np.array_equal(sr.view(np.float32), so.view(np.float32)), (n, p, k)
+            assert np.array_equal(np.ascontiguousarray(ur).view(np.float32), np.ascontiguousarray(uo).view(np.float32)), (n, p, k)
+            assert np.array_equal(np.ascontiguousarray(vr).view(np.float32), np.ascontiguousarray(vo).view(np.float32)), (n, p, k)
 
 
 def test_mvdr_weights_properties(oracle):
