@@ -110,7 +110,7 @@ dsr_status dsr_pipe_submit(dsr_pipe* p, const float* x, const int32_t* nsamp_dev
     DSR_HIP(hipEventRecord(p->ev[0], st));
     check(dsr_fb_analysis(p->ana, x, nsamp_dev, U, C, sampStride, Tmax, p->X.p, st));
     DSR_HIP(hipEventRecord(p->ev[1], st));
-    check(dsr_bf_apply(p->bf, p->X.p, U, Tmax, p->Y.p, st));
+    check(dsr_bf_apply_frames(p->bf, p->X.p, p->d_T.p, U, Tmax, p->Y.p, st));     // an adapting beamformer stops at each utterance's last frame
     DSR_HIP(hipEventRecord(p->ev[2], st));
     check(dsr_fb_synthesis(p->syn, p->Y.p, p->d_T.p, U, Tmax, nyMax, p->y.p, st));
     DSR_HIP(hipEventRecord(p->ev[3], st));

@@ -36,6 +36,9 @@ struct BfState {
   std::vector<double> rlsDiag;   // [M/2+1] _diagonalWeights (the constructor's sigma2)
   std::vector<zc> rlsP0;         // [M/2+1][C-1][C-1] precision matrices every utterance starts from
   DevBuf<double2> d_wq, d_B, d_P0, d_state; DevBuf<double> d_diag; bool rlsDirty = true;
+  // carried adaptation state (dsr_bf_rls_carry): [entry][U x F] precision matrices + active weights as the last call left them; the next call of
+  // the same batch shape continues from it -- block streaming, and the reference's "keeps adapting across reset()" (beamformer.cc:1552-1612)
+  bool rlsCarry = false, rlsHaveState = false; int rlsStateU = 0; DevBuf<double2> d_carry;
 };
 
 // beamformer.cc:253-305: the reference's pseudo-inverse runs LINPACK's csvdc in complex<float>; svd_linpack.cpp restates that routine
@@ -169,11 +172,16 @@ __device__ __forceinline__ double2 cmul2(double2 a, double2 b) { return make_dou
 __device__ __forceinline__ double2 cmulc2(double2 a, double2 b) { return make_double2(a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y); }     // a conj(b)
 
 // (CT: compile-time channel count -- the small vectors then live in registers and the loops unroll; 0: run-time count, arrays in scratch)
-template <int CT, bool REG>
+// nframesArr (optional): utterance u is adapted over its first nframesArr[u] frames only and the rest of its rows is zero filled -- the reference
+// stops at the stream's last frame (beamformer.cc:1552-1612); adapting on zero-padded frames would still scale P by 1/myu and wa by (I - sigma2 P).
+// carry (optional, [entry][U x F]): start from / leave the adaptation state there instead of P0 and wa = 0 (carryIn) / nowhere (carryOut).
+// CA: capacity of the per-thread vectors for the run-time channel count (16, or 64 for the large arrays of BASELINE configs[4]; those live in scratch).
+template <int CT, bool REG, int CAP>
 __global__ __launch_bounds__(64) void k_gsc_rls(const float2* __restrict__ X, const double2* __restrict__ wq, const double2* __restrict__ B,
                                                 const double2* __restrict__ P0, const double* __restrict__ diagW, double2* __restrict__ state,
                                                 float2* __restrict__ Y, double2* __restrict__ waOut, int U, int Crt, int Tmax, int F, double rmu,
-                                                double alpha, int qctype, int adapt, int normalize, int ldsState)
+                                                double alpha, int qctype, int adapt, int normalize, int ldsState,
+                                                const int* __restrict__ nframesArr, double2* __restrict__ carry, int carryIn, int carryOut)
 {
   const int C = CT ? CT : Crt;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -185,20 +193,23 @@ __global__ __launch_bounds__(64) void k_gsc_rls(const float2* __restrict__ X, co
   const float2* Xu = X + (long) u * C * Tmax * F; float2* Yu = Y + (long) u * Tmax * F;
   const double2* wqf = wq + (long) f * C; const double2* Bf = B + (long) f * C * n;
   double2* P = ldsState ? reinterpret_cast<double2*>(smem) + threadIdx.x : state + tix; double2* wa = P + (long) n * n * S;
-  constexpr int CA = CT ? CT : 16;
+  constexpr int CA = CT ? CT : CAP;
   double2 x[CA], w[CA], Z[CA], PH[CA], g[CA], wn[CA];
   // REG (needs CT): precision matrix and active weights in registers -- every index below is a compile-time constant after unrolling
   double2 Pr[REG ? CA : 1][REG ? CA : 1], war[REG ? CA : 1];
 #define PX(i, j) (REG ? Pr[REG ? (i) : 0][REG ? (j) : 0] : P[(long) ((i) * n + (j)) * S])
 #define WA(j) (REG ? war[REG ? (j) : 0] : wa[(long) (j) * S])
+  const long SC = (long) U * F;                                   // the carried state's entry pitch
   if (f > 0) {
     for (int i = 0; i < n; i++) {
-      for (int j = 0; j < n; j++) PX(i, j) = P0[(long) f * n * n + i * n + j];
-      WA(i) = make_double2(0.0, 0.0);
+      for (int j = 0; j < n; j++) PX(i, j) = carryIn ? carry[(long) (i * n + j) * SC + tix] : P0[(long) f * n * n + i * n + j];
+      WA(i) = carryIn ? carry[(long) (n * n + i) * SC + tix] : make_double2(0.0, 0.0);
     }
   }
   const double dw = diagW[f];
-  for (int t = 0; t < Tmax; t++) {
+  const int Tu = nframesArr ? (nframesArr[u] < Tmax ? nframesArr[u] : Tmax) : Tmax;
+  for (int t = Tu; t < Tmax; t++) Yu[(long) t * F + f] = make_float2(0.f, 0.f);
+  for (int t = 0; t < Tu; t++) {
     for (int c = 0; c < C; c++) { const float2 v = Xu[((long) c * Tmax + t) * F + f]; x[c] = make_double2((double) v.x, (double) v.y); }
     double2 y = make_double2(0.0, 0.0);
     if (f == 0) { for (int c = 0; c < C; c++) { const double2 q = cmulc2(x[c], wqf[c]); y.x += q.x; y.y += q.y; } }
@@ -242,6 +253,11 @@ __global__ __launch_bounds__(64) void k_gsc_rls(const float2* __restrict__ X, co
     }
     for (int i = 0; i < n; i++) WA(i) = wn[i];
   }
+  if (carryOut && f > 0)
+    for (int i = 0; i < n; i++) {
+      for (int j = 0; j < n; j++) carry[(long) (i * n + j) * SC + tix] = PX(i, j);
+      carry[(long) (n * n + i) * SC + tix] = WA(i);
+    }
   if (waOut && f > 0) for (int j = 0; j < n; j++) waOut[((long) u * F + f) * n + j] = WA(j);
   if (waOut && f == 0) for (int j = 0; j < n; j++) waOut[((long) u * F) * n + j] = make_double2(0.0, 0.0);
 }
@@ -251,12 +267,12 @@ __global__ __launch_bounds__(64) void k_gsc_rls(const float2* __restrict__ X, co
 struct dsr_bf : BfState {};
 
 
-static void gsc_rls_apply(BfState& s, const float* X, int U, int Tmax, float* Y, double* waOut, hipStream_t st)
+static void gsc_rls_apply(BfState& s, const float* X, const int32_t* nframes, int U, int Tmax, float* Y, double* waOut, hipStream_t st)
 {
   if (!s.haveB) throw Error(DSR_E_ERROR, "call calcGSCWeightsX() once");                                                    // beamformer.cc:1562-1565
   if (!s.haveP0) throw Error(DSR_E_ERROR, "set the precision matrix with initPrecisionMatrix() or setPrecisionMatrix()");   // :1566-1569
   if (s.halfBandShift) throw Error(DSR_E_ERROR, "not yet implemented");                                                     // :1580-1583
-  if (s.C > 16) throw Error(DSR_E_DIMENSION, "SubbandGSCRLS: at most 16 channels (%d)", s.C);
+  if (s.C > 64) throw Error(DSR_E_DIMENSION, "SubbandGSCRLS: at most 64 channels (%d)", s.C);
   if (U <= 0 || Tmax <= 0) return;
   const int C = s.C, n = C - 1, F = s.M / 2 + 1;
   if (s.rlsDirty || s.dirty) {
@@ -268,18 +284,33 @@ static void gsc_rls_apply(BfState& s, const float* X, int U, int Tmax, float* Y,
   }
   const long S = (long) U * F;
   const size_t ldsB = (size_t) (n * n + n) * 16 * 64; const int ldsState = (ldsB <= 150 * 1024 && !getenv("DSR_RLS_MEMSTATE")) ? 1 : 0;
-  s.d_state.reserve(ldsState ? 16 : (size_t) S * (n * n + n));
-#define RLS_LAUNCH(CTV) { if (ldsState) DSR_HIP(hipFuncSetAttribute((const void*) k_gsc_rls<CTV, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) ldsB)); \
-  hipLaunchKernelGGL((k_gsc_rls<CTV, false>), dim3((unsigned) ((S + 63) / 64)), dim3(64), ldsState ? ldsB : 0, st, (const float2*) X, s.d_wq.p, s.d_B.p, s.d_P0.p, s.d_diag.p, s.d_state.p, \
-                     (float2*) Y, (double2*) waOut, U, C, Tmax, F, 1.0 / s.rlsMyu, s.rlsAlpha, s.rlsQc, s.rlsAdapt ? 1 : 0, s.mode == 3 ? 1 : 0, ldsState); }
-#define RLS_LAUNCH_REG(CTV) hipLaunchKernelGGL((k_gsc_rls<CTV, true>), dim3((unsigned) ((S + 63) / 64)), dim3(64), 0, st, (const float2*) X, s.d_wq.p, s.d_B.p, s.d_P0.p, s.d_diag.p, s.d_state.p, \
-                     (float2*) Y, (double2*) waOut, U, C, Tmax, F, 1.0 / s.rlsMyu, s.rlsAlpha, s.rlsQc, s.rlsAdapt ? 1 : 0, s.mode == 3 ? 1 : 0, 0);
-  const bool regs = getenv("DSR_RLS_NOREGS") == nullptr;       // precision matrix + active weights in registers (C = 8: 256 VGPRs, no scratch): 2x the LDS variant
+  const bool regs = getenv("DSR_RLS_NOREGS") == nullptr && (C == 8 || C == 6 || C == 4);     // precision matrix + active weights in registers (C = 8: 256 VGPRs, no scratch)
+  // carried state: its own array (the register / LDS variants copy in and out; the memory variant works in it directly)
+  int carryIn = 0, carryOut = 0; double2* carry = nullptr;
+  if (s.rlsCarry) {
+    if (s.rlsHaveState && s.rlsStateU != U) throw Error(DSR_E_CONSISTENCY, "SubbandGSCRLS: the carried state holds %d streams, this call has %d (reset the state first)", s.rlsStateU, U);
+    s.d_carry.reserve((size_t) S * (n * n + n));
+    carry = s.d_carry.p; carryIn = s.rlsHaveState ? 1 : 0; carryOut = 1;
+  }
+  const bool memInPlace = !regs && !ldsState;                   // state array == working array
+  if (memInPlace && !s.rlsCarry) s.d_state.reserve((size_t) S * (n * n + n));
+  double2* work = memInPlace ? (s.rlsCarry ? s.d_carry.p : s.d_state.p) : (s.d_state.reserve(16), s.d_state.p);
+  // in-place memory variant with carry: the working array IS the carried one: reading "carry" at start and writing it at the end are no-ops on the
+  // same addresses (same [entry][U x F] layout), so the flags are passed as they are.
+#define RLS_ARGS (const float2*) X, s.d_wq.p, s.d_B.p, s.d_P0.p, s.d_diag.p, work, (float2*) Y, (double2*) waOut, U, C, Tmax, F, 1.0 / s.rlsMyu, s.rlsAlpha, s.rlsQc, \
+                 s.rlsAdapt ? 1 : 0, s.mode == 3 ? 1 : 0
+#define RLS_TAIL nframes, carry, carryIn, carryOut
+#define RLS_LAUNCH(CTV, CAPV) { if (ldsState) DSR_HIP(hipFuncSetAttribute((const void*) k_gsc_rls<CTV, false, CAPV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) ldsB)); \
+  hipLaunchKernelGGL((k_gsc_rls<CTV, false, CAPV>), dim3((unsigned) ((S + 63) / 64)), dim3(64), ldsState ? ldsB : 0, st, RLS_ARGS, ldsState, RLS_TAIL); }
+#define RLS_LAUNCH_REG(CTV) hipLaunchKernelGGL((k_gsc_rls<CTV, true, 16>), dim3((unsigned) ((S + 63) / 64)), dim3(64), 0, st, RLS_ARGS, 0, RLS_TAIL);
   if (regs && C == 8) { RLS_LAUNCH_REG(8) } else if (regs && C == 6) { RLS_LAUNCH_REG(6) } else if (regs && C == 4) { RLS_LAUNCH_REG(4) }
-  else if (C == 8) RLS_LAUNCH(8) else if (C == 4) RLS_LAUNCH(4) else if (C == 6) RLS_LAUNCH(6) else RLS_LAUNCH(0)
+  else if (C == 8) RLS_LAUNCH(8, 16) else if (C == 4) RLS_LAUNCH(4, 16) else if (C == 6) RLS_LAUNCH(6, 16) else if (C <= 16) RLS_LAUNCH(0, 16) else RLS_LAUNCH(0, 64)
 #undef RLS_LAUNCH_REG
 #undef RLS_LAUNCH
+#undef RLS_ARGS
+#undef RLS_TAIL
   DSR_HIP(hipGetLastError());
+  if (s.rlsCarry) { s.rlsHaveState = true; s.rlsStateU = U; }
 }
 
 extern "C" {
@@ -449,7 +480,7 @@ dsr_status dsr_bf_apply(dsr_bf* s, const float* X, int U, int Tmax, float* Y, vo
   return guard([&] {
     if (!s || !X || !Y) throw Error(DSR_E_PARAMETER, "null argument");
     require_device();
-    if (s->rlsOn) { gsc_rls_apply(*s, X, U, Tmax, Y, nullptr, (hipStream_t) stream); return; }
+    if (s->rlsOn) { gsc_rls_apply(*s, X, nullptr, U, Tmax, Y, nullptr, (hipStream_t) stream); return; }
     if (s->dirty) refresh_effective(*s);
     if (U <= 0 || Tmax <= 0) return;
     const int F = s->M / 2 + 1; const long perUtt = (long) Tmax * F;
@@ -485,7 +516,7 @@ dsr_status dsr_bf_rls_init_precision(dsr_bf* s, float sigma2)
     s->rlsP0.assign((size_t) F * n * n, zc(0, 0));
     for (int f = 0; f < F; f++) for (int i = 0; i < n; i++) s->rlsP0[((size_t) f * n + i) * n + i] = zc((double) (1 / sigma2), 0.0);
     std::fill(s->wa.begin(), s->wa.end(), zc(0, 0));
-    s->haveP0 = true; s->rlsDirty = true; s->dirty = true;
+    s->haveP0 = true; s->rlsDirty = true; s->dirty = true; s->rlsHaveState = false;
   });
 }
 // setPrecisionMatrix(fbinX, Pz) (:1540-1552); Pz [C-1][C-1] complex128
@@ -498,22 +529,34 @@ dsr_status dsr_bf_rls_set_precision(dsr_bf* s, int fbinX, const double* Pz)
     if (fbinX < 0 || fbinX >= F) throw Error(DSR_E_DIMENSION, "Must be a frequency bin %d <= %d", fbinX, F - 1);
     if (s->rlsP0.size() != (size_t) F * n * n) s->rlsP0.assign((size_t) F * n * n, zc(0, 0));
     for (int e = 0; e < n * n; e++) s->rlsP0[(size_t) fbinX * n * n + e] = zc(Pz[2 * e], Pz[2 * e + 1]);
-    s->haveP0 = true; s->rlsDirty = true;
+    s->haveP0 = true; s->rlsDirty = true; s->rlsHaveState = false;
   });
 }
 dsr_status dsr_bf_rls_quadratic_constraint(dsr_bf* s, float alpha, int qctype)
 { return guard([&] { if (!s || qctype < 0 || qctype > 2) throw Error(DSR_E_PARAMETER, "bad quadratic constraint type"); s->rlsAlpha = (double) alpha; s->rlsQc = qctype; }); }
 dsr_status dsr_bf_rls_adapt(dsr_bf* s, int flag) { return guard([&] { if (!s) throw Error(DSR_E_PARAMETER, "null argument"); s->rlsAdapt = flag != 0; }); }
 // batch entry with the final active weights: wa_out_dev (optional) [U][M/2+1][C-1] complex128
-dsr_status dsr_bf_gsc_rls(dsr_bf* s, const float* X, int U, int Tmax, float* Y, double* wa_out_dev, void* stream)
+dsr_status dsr_bf_gsc_rls(dsr_bf* s, const float* X, const int32_t* nframes_dev, int U, int Tmax, float* Y, double* wa_out_dev, void* stream)
 {
   return guard([&] {
     if (!s || !X || !Y) throw Error(DSR_E_PARAMETER, "null argument");
     if (!s->rlsOn) throw Error(DSR_E_ERROR, "not a SubbandGSCRLS object: call dsr_bf_rls_config first");
     require_device();
-    gsc_rls_apply(*s, X, U, Tmax, Y, wa_out_dev, (hipStream_t) stream);
+    gsc_rls_apply(*s, X, nframes_dev, U, Tmax, Y, wa_out_dev, (hipStream_t) stream);
   });
 }
+// dsr_bf_apply with per-utterance frame counts: rows t >= nframes[u] are zero; an adapting (RLS) object stops adapting there
+dsr_status dsr_bf_apply_frames(dsr_bf* s, const float* X, const int32_t* nframes_dev, int U, int Tmax, float* Y, void* stream)
+{
+  if (s && s->rlsOn) return dsr_bf_gsc_rls(s, X, nframes_dev, U, Tmax, Y, nullptr, stream);
+  return dsr_bf_apply(s, X, U, Tmax, Y, stream);               // fixed weights: the padded rows of X are zero, so are the outputs
+}
+// carry on: every call continues from the precision matrices and active weights the previous call left (same U); the first call after
+// rls_reset_state / rls_init_precision / rls_set_precision starts from those matrices and zero weights
+dsr_status dsr_bf_rls_carry(dsr_bf* s, int on)
+{ return guard([&] { if (!s) throw Error(DSR_E_PARAMETER, "null argument"); s->rlsCarry = on != 0; if (!on) s->rlsHaveState = false; }); }
+dsr_status dsr_bf_rls_reset_state(dsr_bf* s)
+{ return guard([&] { if (!s) throw Error(DSR_E_PARAMETER, "null argument"); s->rlsHaveState = false; }); }
 
 
 // SubbandMVDRGSC (beamformer.h:394-425, beamformer.cc:2637-2817): the MVDR vector as the quiescent weight of a GSC whose active weights are

@@ -24,6 +24,10 @@ struct FbPlan {
   DevBuf<float2> d_tw;       // tw[k] = e^{+2 pi j k / M}
 };
 
+// per-call frame bookkeeping: a whole-utterance call uses the plan's look-ahead and tail (laN, pd) and no history; a block of a longer stream
+// (dsr_fb_analysis_block / dsr_fb_synthesis_block) carries the samples / subband frames that came before it
+struct FbCall { int pd, laN; const float* hist; int histN; int tsMin; };
+
 // ---------------------------------------------------------------------------------------------
 // Stockham autosort FFT of `nfft` independent length-N sequences living in LDS (sequence f at
 // x + f*N).  tw[k*twStep] = e^{+2 pi j k / N}.  sign=+1: e^{+...} (gsl backward), -1: forward.
@@ -74,12 +78,17 @@ __device__ __forceinline__ float2* fft_lds(float2* x, float2* y, const float2* t
   return x;
 }
 
+// Sample n of a (stream, channel) row: the block's own samples for 0 <= n < nsamp, the carried history (the histN samples that came before
+// the block, dsr_fb_analysis_block) for -histN <= n < 0, zero elsewhere (before the stream's start / after its end).
+__device__ __forceinline__ float ld_sample(const float* __restrict__ xs, const float* __restrict__ hs, int histN, long n, int nsamp)
+{ return (n >= 0) ? (n < nsamp ? xs[n] : 0.0f) : ((hs && n >= -(long) histN) ? hs[histN + n] : 0.0f); }
+
 // LDS layout (dynamic): [tw: M float2][proto: m*M float][win: winLen float][bufA: FB*M float][bufB: FB*M float]
 template <int M>
 __global__ __launch_bounds__(256) void k_analysis(const float* __restrict__ x, const int* __restrict__ nsampArr,
                                                   const float* __restrict__ proto, const float2* __restrict__ twG,
                                                   float2* __restrict__ X, int C, long sampStride, int Tmax,
-                                                  int m, int r, int pd, int laN, int gain, int TF, int FB)
+                                                  int m, int r, int pd, int laN, int gain, int TF, int FB, const float* __restrict__ hist, int histN)
 {
   constexpr int N = M / 2;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -102,10 +111,8 @@ __global__ __launch_bounds__(256) void k_analysis(const float* __restrict__ x, c
   for (int i = tid; i < M; i += nthr) tw[i] = twG[i];
   for (int i = tid; i < m * M; i += nthr) h[i] = proto[i];
   const long lo = (long) (t0 + laN + 1) * D - (long) m * M;
-  for (int i = tid; i < winLen; i += nthr) {
-    const long n = lo + i;
-    win[i] = (n >= 0 && n < nsamp) ? xs[n] : 0.0f;
-  }
+  const float* hs = hist ? hist + ((long) u * C + c) * histN : nullptr;
+  for (int i = tid; i < winLen; i += nthr) win[i] = ld_sample(xs, hs, histN, lo + i, nsamp);
   __syncthreads();
 
   for (int fb0 = 0; fb0 < TF; fb0 += FB) {
@@ -162,7 +169,7 @@ template <int M, int MT>
 __global__ __launch_bounds__(256) void k_analysis_w(const float* __restrict__ x, const int* __restrict__ nsampArr,
                                                     const float* __restrict__ proto, const float2* __restrict__ twG,
                                                     float2* __restrict__ X, int C, long sampStride, int Tmax,
-                                                    int r, int pd, int laN, int gain, int TF)
+                                                    int r, int pd, int laN, int gain, int TF, const float* __restrict__ hist, int histN)
 {
   constexpr int N = M / 2, R = N / 64, LOGN = (N == 64 ? 6 : N == 128 ? 7 : N == 256 ? 8 : N == 512 ? 9 : 10);
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -182,10 +189,8 @@ __global__ __launch_bounds__(256) void k_analysis_w(const float* __restrict__ x,
 
   for (int i = tid; i < M; i += nthr) tw[i] = twG[i];
   const long lo = (long) (t0 + laN + 1) * D - (long) MT * M;
-  for (int i = tid; i < winLen; i += nthr) {
-    const long n = lo + i;
-    win[i] = (n >= 0 && n < nsamp) ? xs[n] : 0.0f;
-  }
+  const float* hs = hist ? hist + ((long) u * C + c) * histN : nullptr;
+  for (int i = tid; i < winLen; i += nthr) win[i] = ld_sample(xs, hs, histN, lo + i, nsamp);
   // Element <-> lane map.  The six cross-lane butterfly stages flip element-index bits 5..0; bit b is tied to the lane
   // exchange xor{32,16,8,7,2,1}: the four row-local ones are single DPP controls (row_ror:8, row_half_mirror, quad_perm),
   // so lane L holds element  el = (L0^L2) | (L1^L2)<<1 | L2<<2 | L3<<3 | L[5:4]<<4  of every 64-point group.
@@ -299,7 +304,7 @@ template <int M>
 __global__ __launch_bounds__(256) void k_synthesis(const float2* __restrict__ Y, const int* __restrict__ nframesArr,
                                                    const float* __restrict__ proto, const float2* __restrict__ twG,
                                                    float* __restrict__ y, int Tmax, long outStride,
-                                                   int m, int r, int pd, int gain, int TO, int FB)
+                                                   int m, int r, int pd, int gain, int TO, int FB, const float2* __restrict__ hist, int histN, int tsMin)
 {
   constexpr int N = M / 2;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -329,9 +334,12 @@ __global__ __launch_bounds__(256) void k_synthesis(const float2* __restrict__ Y,
       const int fr = idx / N, f = idx - fr * N;
       const int tau = tA + b0 + fr;
       float2 zc = make_float2(0.0f, 0.0f);
-      if (b0 + fr < NV && tau >= 0 && tau < Tu) {
-        float2 gf = Yu[(long) tau * (N + 1) + f];
-        float2 gn = Yu[(long) tau * (N + 1) + (N - f)];
+      // subband frame tau of this call; tau < 0: one of the histN frames carried over from the calls before (dsr_fb_synthesis_block)
+      const bool inHist = hist && tau < 0 && tau >= -histN;
+      if (b0 + fr < NV && ((tau >= 0 && tau < Tu) || inHist)) {
+        const float2* Yr = inHist ? hist + ((long) u * histN + (histN + tau)) * (N + 1) : Yu + (long) tau * (N + 1);
+        float2 gf = Yr[f];
+        float2 gn = Yr[N - f];
         if (f == 0) { gf.y = 0.0f; gn.y = 0.0f; }      // G[0], G[N]: real parts only
         gn.y = -gn.y;                                    // conj(G[N-f])
         const float2 s = make_float2(gf.x + gn.x, gf.y + gn.y);
@@ -360,7 +368,7 @@ __global__ __launch_bounds__(256) void k_synthesis(const float2* __restrict__ Y,
     if (t < nOut) {
       for (int i = 0; i < R; i++) {
         const int ts = t - R + 1 + i;                    // s_{ts}
-        if (ts < 0) continue;
+        if (ts < tsMin) continue;                        // before the stream's first output block (tsMin = 0 for a whole utterance)
         const int k = d + i * D;
         float s = 0.0f;
         for (int q = 0; q < m; q++) {
@@ -375,7 +383,7 @@ __global__ __launch_bounds__(256) void k_synthesis(const float2* __restrict__ Y,
   }
 }
 
-template <int M> static void launch_analysis(const FbPlan& p, const float* x, const int* nsamp, int U, int C,
+template <int M> static void launch_analysis(const FbPlan& p, const FbCall& k, const float* x, const int* nsamp, int U, int C,
                                              long sampStride, int Tmax, float* X, hipStream_t st)
 {
   const int D = p.D;
@@ -387,7 +395,7 @@ template <int M> static void launch_analysis(const FbPlan& p, const float* x, co
   DSR_HIP(hipFuncSetAttribute((const void*) k_analysis<M>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
   dim3 grid(cdiv(Tmax, TF), C, U);
   hipLaunchKernelGGL(k_analysis<M>, grid, dim3(256), lds, st, x, nsamp, p.d_proto.p, p.d_tw.p, (float2*) X, C,
-                     sampStride, Tmax, p.m, p.r, p.pd, p.laN, p.gain, TF, FB);
+                     sampStride, Tmax, p.m, p.r, k.pd, k.laN, p.gain, TF, FB, k.hist, k.histN);
   DSR_HIP(hipGetLastError());
 }
 
@@ -432,7 +440,7 @@ template <int MT, int PF>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_analysis_q256(const float* __restrict__ x, const int* __restrict__ nsampArr,
                                                        const float* __restrict__ proto, const float2* __restrict__ twG,
                                                        float2* __restrict__ X, int C, long sampStride, int Tmax,
-                                                       int pd, int laN, int gain, int TF)
+                                                       int pd, int laN, int gain, int TF, const float* __restrict__ hist, int histN)
 {
   constexpr int M = 256, N = 128, D = 128;                     // r = 1
   constexpr int NQ = 1;                                        // quads of frames a wave works on side by side (independent chains to interleave)
@@ -461,7 +469,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 
   for (int i = tid; i < M; i += nthr) tw[i] = twG[i];
   const long lo0 = (long) (laN + 1) * D - (long) MT * M;       // first sample of the first tile's window (negative: zeros)
-  for (int i = tid; i < winLen; i += nthr) { const long n = lo0 + i; win[i + 32 * (i >> 7)] = (n >= 0 && n < nsamp) ? xs[n] : 0.0f; }
+  const float* hs = hist ? hist + ((long) u * C + c) * histN : nullptr;            // carried history: only the first tile's window reaches before the block
+  for (int i = tid; i < winLen; i += nthr) win[i + 32 * (i >> 7)] = ld_sample(xs, hs, histN, lo0 + i, nsamp);
   const int step = TF * D, keep = winLen - step;               // samples a tile brings in / shares with the tile before (multiples of 128)
   const int stepPhys = step + 32 * (step >> 7), keepPhys = keep + 32 * (keep >> 7);
   const bool vec = ((((uintptr_t) xs) | (uintptr_t) (sampStride * 4)) & 15) == 0;
@@ -587,7 +596,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
   }
 }
 
-template <int M> static void launch_synthesis(const FbPlan& p, const float* Y, const int* nframes, int U, int Tmax,
+template <int M> static void launch_synthesis(const FbPlan& p, const FbCall& k, const float* Y, const int* nframes, int U, int Tmax,
                                               long outStride, float* y, hipStream_t st)
 {
   int FB = 4096 / M; if (FB < 1) FB = 1;
@@ -599,7 +608,7 @@ template <int M> static void launch_synthesis(const FbPlan& p, const float* Y, c
   const int nblkMax = (int) (outStride / p.D);
   dim3 grid(cdiv(nblkMax > 0 ? nblkMax : 1, TO), U);
   hipLaunchKernelGGL(k_synthesis<M>, grid, dim3(256), lds, st, (const float2*) Y, nframes, p.d_proto.p, p.d_tw.p, y,
-                     Tmax, outStride, p.m, p.r, p.pd, p.gain, TO, FB);
+                     Tmax, outStride, p.m, p.r, k.pd, p.gain, TO, FB, (const float2*) k.hist, k.histN, k.tsMin);
   DSR_HIP(hipGetLastError());
 }
 
@@ -741,7 +750,7 @@ __global__ void k_pr_synth_out(const float* __restrict__ V, const int* __restric
   case 256: CALL(256); break; case 512: CALL(512); break; case 1024: CALL(1024); break; case 2048: CALL(2048); break; \
   default: throw Error(DSR_E_DIMENSION, "unsupported number of subbands M=%d (power of two in [16,2048])", M_); }
 
-template <int M, int MT> static void launch_analysis_w(const FbPlan& p, const float* x, const int* nsamp, int U, int C,
+template <int M, int MT> static void launch_analysis_w(const FbPlan& p, const FbCall& k, const float* x, const int* nsamp, int U, int C,
                                                        long sampStride, int Tmax, float* X, hipStream_t st)
 {
   int TF = 32; const int waves = 4;
@@ -752,11 +761,11 @@ template <int M, int MT> static void launch_analysis_w(const FbPlan& p, const fl
   DSR_HIP(hipFuncSetAttribute((const void*) k_analysis_w<M, MT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
   dim3 grid(cdiv(Tmax, TF), C, U);
   hipLaunchKernelGGL((k_analysis_w<M, MT>), grid, dim3(64 * waves), lds, st, x, nsamp, p.d_proto.p, p.d_tw.p, (float2*) X, C,
-                     sampStride, Tmax, p.r, p.pd, p.laN, p.gain, TF);
+                     sampStride, Tmax, p.r, k.pd, k.laN, p.gain, TF, k.hist, k.histN);
   DSR_HIP(hipGetLastError());
 }
 
-template <int MT> static void launch_analysis_q256(const FbPlan& p, const float* x, const int* nsamp, int U, int C,
+template <int MT> static void launch_analysis_q256(const FbPlan& p, const FbCall& k, const float* x, const int* nsamp, int U, int C,
                                                    long sampStride, int Tmax, float* X, hipStream_t st)
 {
   constexpr int M = 256;
@@ -769,26 +778,26 @@ template <int MT> static void launch_analysis_q256(const FbPlan& p, const float*
   dim3 grid((unsigned) U * (unsigned) C, 1, 1);
   if (TF == 16) {
     DSR_HIP(hipFuncSetAttribute((const void*) k_analysis_q256<MT, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
-    hipLaunchKernelGGL((k_analysis_q256<MT, 2>), grid, dim3(64 * waves), lds, st, x, nsamp, p.d_proto.p, p.d_tw.p, (float2*) X, C, sampStride, Tmax, p.pd, p.laN, p.gain, TF);
+    hipLaunchKernelGGL((k_analysis_q256<MT, 2>), grid, dim3(64 * waves), lds, st, x, nsamp, p.d_proto.p, p.d_tw.p, (float2*) X, C, sampStride, Tmax, k.pd, k.laN, p.gain, TF, k.hist, k.histN);
   } else {
     DSR_HIP(hipFuncSetAttribute((const void*) k_analysis_q256<MT, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
-    hipLaunchKernelGGL((k_analysis_q256<MT, 4>), grid, dim3(64 * waves), lds, st, x, nsamp, p.d_proto.p, p.d_tw.p, (float2*) X, C, sampStride, Tmax, p.pd, p.laN, p.gain, TF);
+    hipLaunchKernelGGL((k_analysis_q256<MT, 4>), grid, dim3(64 * waves), lds, st, x, nsamp, p.d_proto.p, p.d_tw.p, (float2*) X, C, sampStride, Tmax, k.pd, k.laN, p.gain, TF, k.hist, k.histN);
   }
   DSR_HIP(hipGetLastError());
 }
 
-void fb_analysis(const FbPlan& p, const float* x, const int* nsamp, int U, int C, long sampStride, int Tmax, float* X, hipStream_t st)
+void fb_analysis(const FbPlan& p, const FbCall& k, const float* x, const int* nsamp, int U, int C, long sampStride, int Tmax, float* X, hipStream_t st)
 {
   if (!getenv("DSR_FB_GENERIC") && !getenv("DSR_FB_WAVE")) {
-    if (p.M == 256 && p.m == 2 && p.r == 1) { launch_analysis_q256<2>(p, x, nsamp, U, C, sampStride, Tmax, X, st); return; }
-    if (p.M == 256 && p.m == 4 && p.r == 1) { launch_analysis_q256<4>(p, x, nsamp, U, C, sampStride, Tmax, X, st); return; }
+    if (p.M == 256 && p.m == 2 && p.r == 1) { launch_analysis_q256<2>(p, k, x, nsamp, U, C, sampStride, Tmax, X, st); return; }
+    if (p.M == 256 && p.m == 4 && p.r == 1) { launch_analysis_q256<4>(p, k, x, nsamp, U, C, sampStride, Tmax, X, st); return; }
   }
   if (!getenv("DSR_FB_GENERIC")) {
-#define W(MM, TT) if (p.M == MM && p.m == TT) { launch_analysis_w<MM, TT>(p, x, nsamp, U, C, sampStride, Tmax, X, st); return; }
+#define W(MM, TT) if (p.M == MM && p.m == TT) { launch_analysis_w<MM, TT>(p, k, x, nsamp, U, C, sampStride, Tmax, X, st); return; }
     W(128, 2) W(128, 4) W(256, 2) W(256, 4) W(512, 2) W(512, 4) W(1024, 2) W(1024, 4)
 #undef W
   }
-#define CALL(MM) launch_analysis<MM>(p, x, nsamp, U, C, sampStride, Tmax, X, st)
+#define CALL(MM) launch_analysis<MM>(p, k, x, nsamp, U, C, sampStride, Tmax, X, st)
   DSR_M_DISPATCH(p.M, CALL)
 #undef CALL
 }
@@ -826,17 +835,38 @@ template <int M2> static void launch_pr_synth_fft(PrPlan& p, const float* Y, con
   hipLaunchKernelGGL(k_pr_synth_fft<M2>, dim3(cdiv(Tmax, FB), U), dim3(256), lds, st, (const float2*) Y, nframes, p.tw.p, p.wS.p, p.V.p, Tmax, FB);
   DSR_HIP(hipGetLastError());
 }
-void fb_synthesis(const FbPlan& p, const float* Y, const int* nframes, int U, int Tmax, long outStride, float* y, hipStream_t st)
+void fb_synthesis(const FbPlan& p, const FbCall& k, const float* Y, const int* nframes, int U, int Tmax, long outStride, float* y, hipStream_t st)
 {
-#define CALL(MM) launch_synthesis<MM>(p, Y, nframes, U, Tmax, outStride, y, st)
+#define CALL(MM) launch_synthesis<MM>(p, k, Y, nframes, U, Tmax, outStride, y, st)
   DSR_M_DISPATCH(p.M, CALL)
 #undef CALL
+}
+
+// carried history of a stream after a block: the last H items of (old history ++ the block's n valid items), item = one sample of a
+// (stream, channel) row or one subband frame of rowLen floats; written to the other buffer of the pair (a call reads one and writes the other)
+__global__ void k_hist_update(const float* __restrict__ oldH, float* __restrict__ newH, const float* __restrict__ blk, const int* __restrict__ nArr,
+                              int rowsPerStream, long blkRowStride, int H, int rowLen, int haveOld, int nUnit /* items per count unit */)
+{
+  const long row = blockIdx.y;                                   // (stream, channel) row
+  const int u = (int) (row / rowsPerStream);
+  const long nItems = (long) nArr[u] * nUnit;
+  const long total = (long) H * rowLen;
+  for (long i = (long) blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long) gridDim.x * blockDim.x) {
+    const long it = i / rowLen, w = i - it * rowLen;             // item index in the new history, word inside the item
+    const long src = nItems - H + it;                            // item index in the block (negative: still in the old history)
+    float v = 0.0f;
+    if (src >= 0) v = blk[row * blkRowStride + src * rowLen + w];
+    else if (haveOld && H + src >= 0) v = oldH[row * total + (H + src) * rowLen + w];
+    newH[row * total + i] = v;
+  }
 }
 
 }  // namespace dsr
 
 using namespace dsr;
 struct dsr_fb : FbPlan {};
+// state a filter bank carries from one block of a stream to the next (dsr_fb_analysis_block / dsr_fb_synthesis_block)
+struct dsr_fb_state { int U = 0, C = 0, H = 0, rowLen = 1; bool synthesis = false, started = false; long emitted = 0; int cur = 0; DevBuf<float> hist[2]; };
 
 extern "C" {
 
@@ -970,7 +1000,8 @@ dsr_status dsr_fb_analysis(const dsr_fb* p, const float* x, const int32_t* nsamp
     if (p->synthesis) throw Error(DSR_E_CONSISTENCY, "plan was created for synthesis");
     if (U <= 0 || C <= 0 || Tmax <= 0) return;
     if (C > 65535 || U > 65535) throw Error(DSR_E_DIMENSION, "U and C must be <= 65535 per call");
-    fb_analysis(*p, x, nsamp, U, C, (long) sampStride, Tmax, X, (hipStream_t) stream);
+    const FbCall k = { p->pd, p->laN, nullptr, 0, 0 };
+    fb_analysis(*p, k, x, nsamp, U, C, (long) sampStride, Tmax, X, (hipStream_t) stream);
   });
 }
 dsr_status dsr_fb_synthesis(const dsr_fb* p, const float* Y, const int32_t* nframes, int U, int Tmax,
@@ -981,7 +1012,91 @@ dsr_status dsr_fb_synthesis(const dsr_fb* p, const float* Y, const int32_t* nfra
     if (!p->synthesis) throw Error(DSR_E_CONSISTENCY, "plan was created for analysis");
     if (U <= 0 || Tmax <= 0 || outStride <= 0) return;
     if (U > 65535) throw Error(DSR_E_DIMENSION, "U must be <= 65535 per call");
-    fb_synthesis(*p, Y, nframes, U, Tmax, (long) outStride, y, (hipStream_t) stream);
+    const FbCall k = { p->pd, 0, nullptr, 0, 0 };
+    fb_synthesis(*p, k, Y, nframes, U, Tmax, (long) outStride, y, (hipStream_t) stream);
+  });
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Block-wise processing of long streams (BASELINE configs[4]: 10-minute streams in 10-second blocks).  The reference operators keep ring buffers
+// of the last m*M samples (analysis, modulated.h:79-163, modulated.cc:400-452) and of the last R*m subband frames (synthesis, :586-664); here
+// a state object carries exactly those between calls: m*M - D samples per (stream, channel), R*m - 1 subband frames per stream.
+dsr_status dsr_fb_state_create(const dsr_fb* p, int U, int C, dsr_fb_state** out)
+{
+  return guard([&] {
+    if (!p || !out || U < 1 || (!p->synthesis && C < 1)) throw Error(DSR_E_PARAMETER, "bad argument");
+    require_device();
+    dsr_fb_state* s = new dsr_fb_state(); s->U = U; s->synthesis = p->synthesis != 0;
+    if (p->synthesis) { s->C = 1; s->H = p->R * p->m - 1; s->rowLen = 2 * (p->M / 2 + 1); }
+    else { s->C = C; s->H = p->m * p->M - p->D; s->rowLen = 1; }
+    const size_t n = (size_t) U * s->C * (s->H > 0 ? s->H : 1) * s->rowLen;
+    s->hist[0].reserve(n); s->hist[1].reserve(n);
+    *out = s;
+  });
+}
+void dsr_fb_state_destroy(dsr_fb_state* s) { delete s; }
+dsr_status dsr_fb_state_reset(dsr_fb_state* s)
+{ return guard([&] { if (!s) throw Error(DSR_E_PARAMETER, "null argument"); s->started = false; s->emitted = 0; }); }
+
+// frames a block of nsampBlock new samples yields: the stream's first block spends the look-ahead (laN source blocks, delayCompensationType 2,
+// modulated.cc:467-474), its last one adds the processingDelay zero-input frames (:493-501)
+int dsr_fb_analysis_block_frames(const dsr_fb* p, const dsr_fb_state* s, int nsampBlock, int last)
+{
+  if (!p || !s) return 0;
+  const int nblk = (nsampBlock + p->D - 1) / p->D, la = s->started ? 0 : p->laN;
+  return nblk < la ? 0 : nblk - la + (last ? p->pd : 0);
+}
+dsr_status dsr_fb_analysis_block(const dsr_fb* p, dsr_fb_state* s, const float* x, const int32_t* nsamp_dev, int U, int C, int64_t sampStride,
+                                 int last, int Tmax, float* X, void* stream)
+{
+  return guard([&] {
+    if (!p || !s || !x || !nsamp_dev || !X) throw Error(DSR_E_PARAMETER, "null argument");
+    if (p->synthesis || s->synthesis) throw Error(DSR_E_CONSISTENCY, "plan / state were created for synthesis");
+    if (U != s->U || C != s->C) throw Error(DSR_E_DIMENSION, "state holds %d x %d rows, call has %d x %d", s->U, s->C, U, C);
+    if (s->H != p->m * p->M - p->D) throw Error(DSR_E_CONSISTENCY, "state belongs to another filter bank");
+    if (Tmax <= 0) return;
+    hipStream_t st = (hipStream_t) stream;
+    const FbCall k = { last ? p->pd : 0, s->started ? 0 : p->laN, s->started ? s->hist[s->cur].p : nullptr, s->H, 0 };
+    fb_analysis(*p, k, x, nsamp_dev, U, C, (long) sampStride, Tmax, X, st);
+    if (s->H > 0) {
+      int gx = cdiv(s->H, 256); if (gx < 1) gx = 1;
+      hipLaunchKernelGGL(k_hist_update, dim3(gx, (unsigned) U * C), dim3(256), 0, st, s->hist[s->cur].p, s->hist[s->cur ^ 1].p, x, nsamp_dev, C, (long) sampStride,
+                         s->H, 1, s->started ? 1 : 0, 1);
+      DSR_HIP(hipGetLastError());
+      s->cur ^= 1;
+    }
+    s->started = true;
+  });
+}
+// output blocks a call with nframesBlock new subband frames yields: the first call keeps processingDelay frames of look-ahead back (modulated.cc:631-634)
+int dsr_fb_synthesis_block_blocks(const dsr_fb* p, const dsr_fb_state* s, int nframesBlock)
+{
+  if (!p || !s) return 0;
+  if (s->started) return nframesBlock;
+  return nframesBlock - p->pd > 0 ? nframesBlock - p->pd : 0;
+}
+dsr_status dsr_fb_synthesis_block(const dsr_fb* p, dsr_fb_state* s, const float* Y, const int32_t* nframes_dev, int nframesHostMax, int U, int Tmax,
+                                  int64_t outStride, float* y, void* stream)
+{
+  return guard([&] {
+    if (!p || !s || !Y || !nframes_dev || !y) throw Error(DSR_E_PARAMETER, "null argument");
+    if (!p->synthesis || !s->synthesis) throw Error(DSR_E_CONSISTENCY, "plan / state were created for analysis");
+    if (U != s->U) throw Error(DSR_E_DIMENSION, "state holds %d streams, call has %d", s->U, U);
+    if (s->H != p->R * p->m - 1) throw Error(DSR_E_CONSISTENCY, "state belongs to another filter bank");
+    if (Tmax <= 0 || outStride <= 0) return;
+    if (!s->started && nframesHostMax < p->pd + p->R * p->m) throw Error(DSR_E_DIMENSION, "the first block of a stream must hold at least %d subband frames", p->pd + p->R * p->m);
+    hipStream_t st = (hipStream_t) stream;
+    // later calls: local frame tau = absolute frame minus the frames of the calls before; the look-ahead is already inside the history shift
+    const FbCall k = { s->started ? 0 : p->pd, 0, s->started ? s->hist[s->cur].p : nullptr, s->H, s->started ? -(p->R - 1) : 0 };
+    fb_synthesis(*p, k, Y, nframes_dev, U, Tmax, (long) outStride, y, st);
+    if (s->H > 0) {
+      int gx = cdiv((long) s->H * s->rowLen, 256); if (gx < 1) gx = 1; if (gx > 64) gx = 64;
+      hipLaunchKernelGGL(k_hist_update, dim3(gx, (unsigned) U), dim3(256), 0, st, s->hist[s->cur].p, s->hist[s->cur ^ 1].p, Y, nframes_dev, 1, (long) Tmax * s->rowLen,
+                         s->H, s->rowLen, s->started ? 1 : 0, 1);
+      DSR_HIP(hipGetLastError());
+      s->cur ^= 1;
+    }
+    s->started = true;
   });
 }
 

@@ -15,9 +15,12 @@
 
 namespace dsr {
 
+// Carried state (block streaming, dsr_zelinski_carry): seenIn[u] = frames of stream u the earlier calls have filtered (the recursions start from
+// scratch only on the stream's own first two frames), seenOut[u] = that plus this call's; the densities are read from / left in `state`.
 __global__ __launch_bounds__(128) void k_zelinski(const float2* __restrict__ X, const float2* __restrict__ Y, const int* __restrict__ nframesArr,
                                                   const double2* __restrict__ wq, double2* __restrict__ state, float2* __restrict__ out,
-                                                  float* __restrict__ wp1, int U, int C, int Tmax, int F, double alphaCfg, int type, int minFrames)
+                                                  float* __restrict__ wp1, int U, int C, int Tmax, int F, double alphaCfg, int type, int minFrames,
+                                                  const int* __restrict__ seenIn, int* __restrict__ seenOut)
 {
   const long n = (long) blockIdx.x * blockDim.x + threadIdx.x;
   if (n >= (long) U * F) return;
@@ -27,10 +30,12 @@ __global__ __launch_bounds__(128) void k_zelinski(const float2* __restrict__ X, 
   const float2* Xu = X + (long) u * C * Tmax * F;
   const float2* Yu = Y + (long) u * Tmax * F;
   float2* Ou = out + (long) u * Tmax * F;
-  double2 ta[16];                                                // time-aligned channels (C <= 16 here; larger arrays: see the launcher)
+  double2 ta[16];                                                // time-aligned channels (C <= 16 here; larger arrays: k_pf_wave)
+  const int seen = seenIn ? seenIn[u] : 0;
+  if (seenOut && f == 0) seenOut[u] = seen + T;
   for (int t = 0; t < Tmax; t++) {
     if (t >= T) { Ou[(long) t * F + f] = make_float2(0.f, 0.f); if (wp1) wp1[((long) u * Tmax + t) * F + f] = 0.f; continue; }
-    const int frameX = t - 1;                                    // _frameX before _increment() (postfilter.cc:463-476)
+    const int frameX = seen + t - 1;                             // _frameX before _increment() (postfilter.cc:463-476)
     const double alpha = (frameX > 0) ? alphaCfg : 0.0;
     const int pfType = (frameX < minFrames) ? 0 : type;
 #pragma unroll 4
@@ -78,7 +83,8 @@ template <int CT>
 __global__ __launch_bounds__(128) void k_mccowan(const float2* __restrict__ X, const float2* __restrict__ Y, const int* __restrict__ nframesArr,
                                                  const double2* __restrict__ wq, const double2* __restrict__ R, double2* __restrict__ state,
                                                  float2* __restrict__ out, float* __restrict__ wp1, int U, int Crt, int Tmax, int F, double alphaCfg, int type,
-                                                 int minFrames, double thr, const double2* __restrict__ lambda, int fbinX1)
+                                                 int minFrames, double thr, const double2* __restrict__ lambda, int fbinX1,
+                                                 const int* __restrict__ seenIn, int* __restrict__ seenOut, int carryIn, int carryOut)
 {
   // lambda != nullptr: LefkimmiatisPostFilter (postfilter.cc:1065-1176) -- McCowan's clean-signal estimate against the noise estimate
   // sum (0.5 (phi_ii + phi_jj) - phi_ij) / (1 - R_ij), divided by d^H pinv(R) d from bin fbinX1 on
@@ -97,9 +103,12 @@ __global__ __launch_bounds__(128) void k_mccowan(const float2* __restrict__ X, c
   double2 ta[CA]; double psd[CA];
   double2 stR[CT ? CT * (CT + 1) / 2 : 1];
 #define ST(e) (CT ? stR[CT ? (e) : 0] : state[(long) (e) * S + n])
+  const int seen = seenIn ? seenIn[u] : 0;
+  if (seenOut && f == 0) seenOut[u] = seen + T;
+  if (CT && carryIn) for (int e = 0; e < (CT ? CT * (CT + 1) / 2 : 0); e++) stR[CT ? e : 0] = state[(long) e * S + n];
   for (int t = 0; t < Tmax; t++) {
     if (t >= T) { Ou[(long) t * F + f] = make_float2(0.f, 0.f); if (wp1) wp1[((long) u * Tmax + t) * F + f] = 0.f; continue; }
-    const int frameX = t - 1;
+    const int frameX = seen + t - 1;
     const double alpha = (frameX > 0) ? alphaCfg : 0.0;
     for (int i = 0; i < C; i++) {
       const double2 d = wq[(long) f * C + i]; const float2 x = Xu[((long) i * Tmax + t) * F + f];
@@ -156,6 +165,7 @@ __global__ __launch_bounds__(128) void k_mccowan(const float2* __restrict__ X, c
     const float2 y = Yu[(long) t * F + f];
     Ou[(long) t * F + f] = (frameX >= minFrames) ? make_float2((float) ((double) y.x * W), (float) ((double) y.y * W)) : y;
   }
+  if (CT && carryOut) for (int e = 0; e < (CT ? CT * (CT + 1) / 2 : 0); e++) state[(long) e * S + n] = stR[CT ? e : 0];
 }
 #undef ST
 
@@ -164,7 +174,8 @@ __global__ __launch_bounds__(128) void k_mccowan(const float2* __restrict__ X, c
 template <int C>
 __global__ __launch_bounds__(64) void k_zelinski_reg(const float2* __restrict__ X, const float2* __restrict__ Y, const int* __restrict__ nframesArr,
                                                      const double2* __restrict__ wq, float2* __restrict__ out, float* __restrict__ wp1,
-                                                     int U, int Tmax, int F, double alphaCfg, int type, int minFrames)
+                                                     int U, int Tmax, int F, double alphaCfg, int type, int minFrames,
+                                                     const int* __restrict__ seenIn, int* __restrict__ seenOut, double2* __restrict__ state, int carryIn, int carryOut)
 {
   constexpr int NP = C * (C - 1) / 2;
   const long n = (long) blockIdx.x * blockDim.x + threadIdx.x;
@@ -182,9 +193,18 @@ __global__ __launch_bounds__(64) void k_zelinski_reg(const float2* __restrict__ 
   for (int e = 0; e < NP; e++) csd[e] = make_double2(0.0, 0.0);
 #pragma unroll
   for (int i = 0; i < C; i++) psd[i] = 0.0;
+  const long S = (long) U * F;
+  const int seen = seenIn ? seenIn[u] : 0;
+  if (seenOut && f == 0) seenOut[u] = seen + T;
+  if (carryIn) {
+#pragma unroll
+    for (int e = 0; e < NP; e++) csd[e] = state[(long) e * S + n];
+#pragma unroll
+    for (int i = 0; i < C; i++) psd[i] = state[(long) (NP + i) * S + n].x;
+  }
   for (int t = 0; t < Tmax; t++) {
     if (t >= T) { Ou[(long) t * F + f] = make_float2(0.f, 0.f); if (wp1) wp1[((long) u * Tmax + t) * F + f] = 0.f; continue; }
-    const int frameX = t - 1;
+    const int frameX = seen + t - 1;
     const double alpha = (frameX > 0) ? alphaCfg : 0.0;
     const int pfType = (frameX < minFrames) ? 0 : type;
     double2 ta[C];
@@ -226,11 +246,147 @@ __global__ __launch_bounds__(64) void k_zelinski_reg(const float2* __restrict__ 
     const float2 y = Yu[(long) t * F + f];
     Ou[(long) t * F + f] = (pfType == 0) ? y : make_float2((float) (W * (double) y.x), (float) (W * (double) y.y));
   }
+  if (carryOut) {
+#pragma unroll
+    for (int e = 0; e < NP; e++) state[(long) e * S + n] = csd[e];
+#pragma unroll
+    for (int i = 0; i < C; i++) state[(long) (NP + i) * S + n] = make_double2(psd[i], 0.0);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Large arrays (16 < C <= 64, BASELINE configs[4]: 64 channels = 2016 microphone pairs): one WAVEFRONT per (utterance, bin).  Lane c time-aligns
+// channel c and owns its auto-density; the cross densities are dealt round-robin over the lanes (pair e belongs to lane e mod 64: at most 32 per
+// lane, in registers together with the pair's noise coherence); the time-aligned snapshot of the frame goes through a 1.5 KB LDS strip of the
+// wave; the sums over pairs and channels are wave reductions (fp64 adds in a tree, not in the reference's pair order: 1e-15 relative).
+// One kernel for the three filters: kind 0 Zelinski, 1 McCowan, 2 Lefkimmiatis (lambda != nullptr).
+__device__ __forceinline__ double wave_sum(double v)
+{
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+template <int KIND>
+__global__ __launch_bounds__(64) void k_pf_wave(const float2* __restrict__ X, const float2* __restrict__ Y, const int* __restrict__ nframesArr,
+                                                const double2* __restrict__ wq, const double2* __restrict__ R, const unsigned short* __restrict__ pairIJ,
+                                                double2* __restrict__ state, float2* __restrict__ out, float* __restrict__ wp1, int U, int C, int Tmax, int F,
+                                                double alphaCfg, int type, int minFrames, double thr, const double2* __restrict__ lambda, int fbinX1,
+                                                const int* __restrict__ seenIn, int* __restrict__ seenOut, int carryIn, int carryOut)
+{
+  constexpr int KP = 32;                                         // pairs per lane (64 channels: 2016 = 31.5 x 64)
+  __shared__ double2 taS[64]; __shared__ double psdS[64];
+  const long n = blockIdx.x; const int lane = threadIdx.x;
+  const int u = (int) (n / F), f = (int) (n - (long) u * F);
+  const long S = (long) U * F;
+  const int NP = C * (C - 1) / 2;
+  const int T = nframesArr[u] < Tmax ? nframesArr[u] : Tmax;
+  const float2* Xl = X + ((long) u * C + (lane < C ? lane : 0)) * Tmax * F + f;
+  const float2* Yu = Y + (long) u * Tmax * F;
+  float2* Ou = out + (long) u * Tmax * F;
+  const int seen = seenIn ? seenIn[u] : 0;
+  if (seenOut && f == 0 && lane == 0) seenOut[u] = seen + T;
+  double2 dconj = make_double2(0.0, 0.0);
+  if (lane < C) { dconj = wq[(long) f * C + lane]; dconj.y = -dconj.y; }
+  // the pairs' noise coherences (McCowan / Lefkimmiatis) wait in LDS, [pair]: 32 KB at 64 channels, read as lane-contiguous 16-byte words
+  extern __shared__ __attribute__((aligned(16))) unsigned char smemPf[];
+  double2* rrS = reinterpret_cast<double2*>(smemPf);
+  unsigned short ij[KP]; double2 csd[KP];
+#pragma unroll
+  for (int k = 0; k < KP; k++) {
+    const int e = lane + 64 * k;
+    ij[k] = e < NP ? pairIJ[e] : (unsigned short) 0;
+    csd[k] = (carryIn && e < NP) ? state[(long) e * S + n] : make_double2(0.0, 0.0);
+    if (KIND && e < NP) rrS[e] = R[(long) f * C * C + (ij[k] & 255) * C + (ij[k] >> 8)];
+  }
+  double psdSt = (carryIn && lane < C) ? state[(long) (NP + lane) * S + n].x : 0.0;
+  float2 xn = (T > 0 && lane < C) ? Xl[0] : make_float2(0.f, 0.f);
+  for (int t = 0; t < Tmax; t++) {
+    if (t >= T) { if (lane == 0) { Ou[(long) t * F + f] = make_float2(0.f, 0.f); if (wp1) wp1[((long) u * Tmax + t) * F + f] = 0.f; } continue; }
+    const float2 x = xn;
+    if (t + 1 < T && lane < C) xn = Xl[(long) (t + 1) * F];       // the next frame's snapshot is in flight while this one is worked on
+    const int frameX = seen + t - 1;
+    const double alpha = (frameX > 0) ? alphaCfg : 0.0;
+    const double xr = (double) x.x, xi = (double) x.y;
+    const double2 ta = make_double2(dconj.x * xr - dconj.y * xi, dconj.x * xi + dconj.y * xr);
+    double est = 0.0;
+    if (lane < C) {
+      const double a2 = ta.x * ta.x + ta.y * ta.y;
+      est = (alpha > 0.0) ? alpha * psdSt + (1.0 - alpha) * a2 : a2;
+      psdSt = est; taS[lane] = ta; psdS[lane] = est;
+    }
+    __syncthreads();                                             // one wave per workgroup: an LDS fence
+    double sr = 0.0, si = 0.0, vr = 0.0, vi = 0.0;
+#pragma unroll
+    for (int k = 0; k < KP; k++) {
+      const int e = lane + 64 * k;
+      if (e < NP) {
+        const int i = ij[k] & 255, j = ij[k] >> 8;
+        const double2 a = taS[i], b = taS[j];
+        const double pr = a.x * b.x + a.y * b.y, pi = a.y * b.x - a.x * b.y;          // a conj(b)
+        double er = pr, ei = pi;
+        if (alpha > 0.0) { er = csd[k].x * alpha + pr * (1.0 - alpha); ei = csd[k].y * alpha + pi * (1.0 - alpha); }
+        csd[k] = make_double2(er, ei);
+        if (KIND == 0) { sr += er; si += ei; }
+        else {
+          const double2 r0 = rrS[e];
+          double2 r = r0;
+          if (r.x > thr && r.y <= 0.0) r = make_double2(thr, 0.0);
+          const double hs = 0.5 * (psdS[i] + psdS[j]);
+          const double2 q = cdiv_gsl(er - r.x * hs, ei - r.y * hs, -r.x + 1.0, -r.y);
+          sr += q.x; si += q.y;
+          if (KIND == 2) {
+            double2 r2 = r0;
+            if (r2.x > thr) r2 = make_double2(thr, 0.0); else if (r2.x == 1.0) r2 = make_double2(0.99, 0.0);
+            const double2 q2 = cdiv_gsl(hs - er, 0.0 - ei, -r2.x + 1.0, -r2.y);
+            vr += q2.x; vi += q2.y;
+          }
+        }
+      }
+    }
+    __syncthreads();
+    sr = wave_sum(sr); si = wave_sum(si);
+    const double sumPSD = wave_sum(est);
+    if (KIND == 2) { vr = wave_sum(vr); vi = wave_sum(vi); }
+    if (lane == 0) {
+      double W; bool pass;
+      if (KIND == 0) {
+        const int pfType = (frameX < minFrames) ? 0 : type;
+        double numerator;
+        if (1 & pfType) { numerator = sr; if (numerator < 0.0) numerator = 0.0; } else numerator = hypot(sr, si);
+        W = (numerator / sumPSD) * (2.0 / ((double) C - 1.0));
+        if (W >= 1.0) W = 1.0;
+        pass = pfType == 0;
+      } else {
+        const double de = sumPSD / (double) C;
+        const double avg = (1 & type) ? sr : hypot(sr, si);
+        const double nu = 2.0 * avg / (double) (C * (C - 1));
+        W = nu / de;
+        if (KIND == 2) {
+          const double phi_vv = 2.0 * ((1 & type) ? vr : hypot(vr, vi)) / (double) (C * (C - 1));
+          if (f < fbinX1) W = nu / (nu + phi_vv);
+          else { const double2 l = lambda[f]; W = nu / (nu + phi_vv / ((1 & type) ? l.x : hypot(l.x, l.y))); }
+        }
+        if (W > 1.0) W = 1.0;
+        pass = !(frameX >= minFrames);
+      }
+      if (W < 0.0001) W = 0.0001;
+      if (wp1) wp1[((long) u * Tmax + t) * F + f] = (float) W;
+      const float2 y = Yu[(long) t * F + f];
+      Ou[(long) t * F + f] = pass ? y : make_float2((float) (W * (double) y.x), (float) (W * (double) y.y));
+    }
+  }
+  if (carryOut) {
+#pragma unroll
+    for (int k = 0; k < KP; k++) { const int e = lane + 64 * k; if (e < NP) state[(long) e * S + n] = csd[k]; }
+    if (lane < C) state[(long) (NP + lane) * S + n] = make_double2(psdSt, 0.0);
+  }
 }
 
 struct ZelinskiPlan { int M = 0, C = 0, type = 2, minFrames = 0; double alpha = 0.6; std::vector<double> h_wq; bool dirty = true; DevBuf<double2> wq, state;
                       int kind = 0; double threshold = 0.99; std::vector<double> h_R; bool haveR = false, dirtyR = true; DevBuf<double2> R;       // kind 1: McCowan
-                      double minSV = 1e-8; int fbinX1 = 0; bool dirtyL = true; DevBuf<double2> lambda; };                                               // kind 2: Lefkimmiatis
+                      double minSV = 1e-8; int fbinX1 = 0; bool dirtyL = true; DevBuf<double2> lambda;                                                 // kind 2: Lefkimmiatis
+                      DevBuf<unsigned short> pairIJ;                                                                                                      // wave kernel: pair e -> i | j << 8
+                      bool carry = false, haveState = false; int stateU = 0; DevBuf<int> seen[2]; int seenCur = 0; };                                      // carried state (block streaming)
 
 }  // namespace dsr
 
@@ -263,7 +419,7 @@ dsr_status dsr_zelinski_create(int fftLen, int chanN, double alpha, int type, in
     if (!out) throw Error(DSR_E_PARAMETER, "null argument");
     if (fftLen < 2 || (fftLen & 1)) throw Error(DSR_E_DIMENSION, "bad fftLen %d", fftLen);
     if (chanN <= 1) throw Error(DSR_E_DIMENSION, "The number of channels %d is <= 1", chanN);          // postfilter.cc:63-66
-    if (chanN > 16) throw Error(DSR_E_DIMENSION, "post-filter kernel: at most 16 channels in this round (%d)", chanN);
+    if (chanN > 64) throw Error(DSR_E_DIMENSION, "post-filter kernels: at most 64 channels (%d)", chanN);
     require_device();
     dsr_zelinski* p = new dsr_zelinski(); p->M = fftLen; p->C = chanN; p->alpha = alpha; p->type = type; p->minFrames = minFrames;
     p->h_wq.assign((size_t) (fftLen / 2 + 1) * chanN * 2, 0.0);
@@ -355,37 +511,67 @@ dsr_status dsr_zelinski_apply(dsr_zelinski* p, const float* X, const float* Y, c
     if (!p || !X || !Y || !nframes_dev || !out) throw Error(DSR_E_PARAMETER, "null argument");
     if (U <= 0 || Tmax <= 0) return;
     hipStream_t st = (hipStream_t) stream;
-    const int F = p->M / 2 + 1;
-    if (p->dirty) { std::vector<double2> w((size_t) F * p->C); for (size_t i = 0; i < w.size(); i++) w[i] = make_double2(p->h_wq[2 * i], p->h_wq[2 * i + 1]); p->wq.upload(w); p->dirty = false; p->dirtyL = true; }
-    const size_t S = (size_t) U * F, NE = (size_t) p->C * (p->C + 1) / 2;
+    const int F = p->M / 2 + 1, C = p->C;
+    if (p->dirty) { std::vector<double2> w((size_t) F * C); for (size_t i = 0; i < w.size(); i++) w[i] = make_double2(p->h_wq[2 * i], p->h_wq[2 * i + 1]); p->wq.upload(w); p->dirty = false; p->dirtyL = true; }
+    const size_t S = (size_t) U * F, NE = (size_t) C * (C + 1) / 2;
+    // carried state: densities [entry][U x F] + frames seen per stream (double buffered: a call reads one array and writes the other)
+    int carryIn = 0, carryOut = 0; const int* seenIn = nullptr; int* seenOut = nullptr;
+    if (p->carry) {
+      if (p->haveState && p->stateU != U) throw Error(DSR_E_CONSISTENCY, "post-filter: the carried state holds %d streams, this call has %d (reset the state first)", p->stateU, U);
+      p->state.reserve(S * NE); p->seen[0].reserve(U); p->seen[1].reserve(U);
+      carryIn = p->haveState ? 1 : 0; carryOut = 1;
+      seenIn = p->haveState ? p->seen[p->seenCur].p : nullptr; seenOut = p->seen[p->seenCur ^ 1].p;
+    }
+    const bool wave = C > 16 || getenv("DSR_PF_WAVE");
+    if (wave) {
+      if (!p->pairIJ.p) { std::vector<unsigned short> t; for (int i = 0; i < C - 1; i++) for (int j = i + 1; j < C; j++) t.push_back((unsigned short) (i | (j << 8))); p->pairIJ.upload(t); }
+      if (!p->carry) p->state.reserve(16);
+    }
     if (p->kind >= 1) {
       if (!p->haveR) throw Error(DSR_E_ERROR, "McCowanPostFilter: construct/set a noise coherence matrix");             // postfilter.cc:835-838
       const bool newR = p->dirtyR;
-      if (p->dirtyR) { std::vector<double2> r((size_t) F * p->C * p->C); for (size_t i = 0; i < r.size(); i++) r[i] = make_double2(p->h_R[2 * i], p->h_R[2 * i + 1]); p->R.upload(r); p->dirtyR = false; }
+      if (p->dirtyR) { std::vector<double2> r((size_t) F * C * C); for (size_t i = 0; i < r.size(); i++) r[i] = make_double2(p->h_R[2 * i], p->h_R[2 * i + 1]); p->R.upload(r); p->dirtyR = false; }
       if (p->kind == 2 && (newR || p->dirtyL)) {                                 // calcInverseNoiseSpatialSpectralMatrix + calcLambda (postfilter.cc:981-1009)
         std::vector<double2> lam(F);
-        for (int f = 0; f < F; f++) lam[f] = lefkimmiatis_lambda(&p->h_R[(size_t) f * p->C * p->C * 2], &p->h_wq[(size_t) f * p->C * 2], p->C, p->minSV);
+        for (int f = 0; f < F; f++) lam[f] = lefkimmiatis_lambda(&p->h_R[(size_t) f * C * C * 2], &p->h_wq[(size_t) f * C * 2], C, p->minSV);
         p->lambda.upload(lam); p->dirtyL = false;
       }
-      const bool regsM = !getenv("DSR_PF_MEMSTATE") && (p->C == 2 || p->C == 3 || p->C == 4 || p->C == 6 || p->C == 8);
-      p->state.reserve(regsM ? 16 : S * NE);
-#define MC_LAUNCH(CTV) hipLaunchKernelGGL((k_mccowan<CTV>), dim3((unsigned) ((S + 127) / 128)), dim3(128), 0, st, (const float2*) X, (const float2*) Y, nframes_dev, p->wq.p, p->R.p, p->state.p, \
-                         (float2*) out, wp1, U, p->C, Tmax, F, p->alpha, p->type, p->minFrames, p->threshold, p->kind == 2 ? p->lambda.p : nullptr, p->fbinX1);
-      if (!regsM) { MC_LAUNCH(0) } else if (p->C == 8) { MC_LAUNCH(8) } else if (p->C == 6) { MC_LAUNCH(6) } else if (p->C == 4) { MC_LAUNCH(4) } else if (p->C == 3) { MC_LAUNCH(3) } else { MC_LAUNCH(2) }
-#undef MC_LAUNCH
-      DSR_HIP(hipGetLastError());
-      return;
     }
-    const bool regs = !getenv("DSR_PF_MEMSTATE");
-#define ZREG(CC) if (regs && p->C == CC) { hipLaunchKernelGGL(k_zelinski_reg<CC>, dim3((unsigned) ((S + 63) / 64)), dim3(64), 0, st, (const float2*) X, (const float2*) Y, \
-      nframes_dev, p->wq.p, (float2*) out, wp1, U, Tmax, F, p->alpha, p->type, p->minFrames); DSR_HIP(hipGetLastError()); return; }
-    ZREG(2) ZREG(3) ZREG(4) ZREG(6) ZREG(8)
+#define PF_TAIL seenIn, seenOut, carryIn, carryOut
+    if (wave) {
+      const size_t ldsPf = p->kind ? sizeof(double2) * (size_t) C * (C - 1) / 2 : 0;
+#define PFW(K) hipLaunchKernelGGL((k_pf_wave<K>), dim3((unsigned) S), dim3(64), ldsPf, st, (const float2*) X, (const float2*) Y, nframes_dev, p->wq.p, p->R.p, p->pairIJ.p, p->state.p, \
+                                  (float2*) out, wp1, U, C, Tmax, F, p->alpha, p->type, p->minFrames, p->threshold, p->kind == 2 ? p->lambda.p : nullptr, p->fbinX1, PF_TAIL)
+      if (p->kind == 0) PFW(0); else if (p->kind == 1) PFW(1); else PFW(2);
+#undef PFW
+    } else if (p->kind >= 1) {
+      const bool regsM = !getenv("DSR_PF_MEMSTATE") && (C == 2 || C == 3 || C == 4 || C == 6 || C == 8);
+      if (!p->carry) p->state.reserve(regsM ? 16 : S * NE);
+      // (state in memory: the working array is the carried one, in place -- the recursions restart by themselves on a stream's first two frames)
+#define MC_LAUNCH(CTV) hipLaunchKernelGGL((k_mccowan<CTV>), dim3((unsigned) ((S + 127) / 128)), dim3(128), 0, st, (const float2*) X, (const float2*) Y, nframes_dev, p->wq.p, p->R.p, p->state.p, \
+                         (float2*) out, wp1, U, C, Tmax, F, p->alpha, p->type, p->minFrames, p->threshold, p->kind == 2 ? p->lambda.p : nullptr, p->fbinX1, PF_TAIL);
+      if (!regsM) { MC_LAUNCH(0) } else if (C == 8) { MC_LAUNCH(8) } else if (C == 6) { MC_LAUNCH(6) } else if (C == 4) { MC_LAUNCH(4) } else if (C == 3) { MC_LAUNCH(3) } else { MC_LAUNCH(2) }
+#undef MC_LAUNCH
+    } else {
+      const bool regs = !getenv("DSR_PF_MEMSTATE") && (C == 2 || C == 3 || C == 4 || C == 6 || C == 8);
+      if (!p->carry) p->state.reserve(regs ? 16 : S * NE);
+#define ZREG(CC) if (C == CC) hipLaunchKernelGGL(k_zelinski_reg<CC>, dim3((unsigned) ((S + 63) / 64)), dim3(64), 0, st, (const float2*) X, (const float2*) Y, \
+      nframes_dev, p->wq.p, (float2*) out, wp1, U, Tmax, F, p->alpha, p->type, p->minFrames, seenIn, seenOut, p->state.p, carryIn, carryOut);
+      if (regs) { ZREG(2) ZREG(3) ZREG(4) ZREG(6) ZREG(8) }
 #undef ZREG
-    p->state.reserve(S * NE);
-    hipLaunchKernelGGL(k_zelinski, dim3((unsigned) ((S + 127) / 128)), dim3(128), 0, st, (const float2*) X, (const float2*) Y, nframes_dev, p->wq.p, p->state.p,
-                       (float2*) out, wp1, U, p->C, Tmax, F, p->alpha, p->type, p->minFrames);
+      else hipLaunchKernelGGL(k_zelinski, dim3((unsigned) ((S + 127) / 128)), dim3(128), 0, st, (const float2*) X, (const float2*) Y, nframes_dev, p->wq.p, p->state.p,
+                              (float2*) out, wp1, U, C, Tmax, F, p->alpha, p->type, p->minFrames, seenIn, seenOut);
+    }
+#undef PF_TAIL
     DSR_HIP(hipGetLastError());
+    if (p->carry) { p->haveState = true; p->stateU = U; p->seenCur ^= 1; }
   });
 }
+// Carried densities (block streaming): carry = 1 makes every apply of the same U continue the recursions of the call before it (stream u of one call
+// = stream u of the next; alpha = 0 only on a stream's own first two frames, minFrames counted from its start); reset_state starts new streams.
+dsr_status dsr_zelinski_carry(dsr_zelinski* p, int on)
+{ return guard([&] { if (!p) throw Error(DSR_E_PARAMETER, "null argument"); p->carry = on != 0; if (!on) p->haveState = false; }); }
+dsr_status dsr_zelinski_reset_state(dsr_zelinski* p)
+{ return guard([&] { if (!p) throw Error(DSR_E_PARAMETER, "null argument"); p->haveState = false; }); }
 
 }  // extern "C"

@@ -17,7 +17,7 @@ namespace dsr {
 
 __global__ __launch_bounds__(256) void k_wpe(const float2* __restrict__ Y, const int* __restrict__ nframesArr, float2* __restrict__ out,
                                              double2* __restrict__ gnOut, int U, int Nmax, int F, int M, int lowerN, int P, int iterationsN,
-                                             double loadFactor, int lowerBW)
+                                             double loadFactor, int lowerBW, const double2* __restrict__ gnIn)
 {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   double2* y = reinterpret_cast<double2*>(smem);                 // [N]
@@ -32,7 +32,7 @@ __global__ __launch_bounds__(256) void k_wpe(const float2* __restrict__ Y, const
   const float2* Yu = Y + (long) u * Nmax * F; float2* Ou = out + (long) u * Nmax * F;
   const bool selected = (b <= lowerBW) || (b >= M - lowerBW);    // dereverberation.cc:204,241
   for (int n = tid; n < N; n += nthr) { const float2 v = Yu[(long) n * F + b]; y[n] = make_double2((double) v.x, (double) v.y); }
-  for (int l = tid; l < P; l += nthr) g[l] = make_double2(0.0, 0.0);
+  for (int l = tid; l < P; l += nthr) g[l] = gnIn ? gnIn[((long) u * F + b) * P + l] : make_double2(0.0, 0.0);   // reset() keeps _gn, nextSpeaker() zeroes it (:258-277)
   if (tid == 0) s_fail = 0;
   __syncthreads();
   auto predict = [&](int n) -> double2 {                         // zdotc(gn, lags(n - lowerN)) = sum_l conj(g_l) y[n - lowerN - l]
@@ -264,11 +264,21 @@ extern "C" {
 // Y_dev [U][Nmax][M/2+1] complex64 (one channel's subband snapshots or a beamformer output), nframes_dev [U] -> out_dev same shape;
 // gn_dev (optional) [U][M/2+1][P] complex128 prediction filters.  A subband whose loaded correlation matrix is not positive definite
 // (GSL would abort there) yields NaNs.
+static dsr_status wpe_single_impl(const float* Y_dev, const int32_t* nframes_dev, int U, int Nmax, int fftLen, int lowerN, int upperN, int iterationsN,
+                                  double loadDb, double bandWidth, double sampleRate, float* out_dev, double* gn_dev, bool warm, void* stream);
 dsr_status dsr_wpe_single(const float* Y_dev, const int32_t* nframes_dev, int U, int Nmax, int fftLen, int lowerN, int upperN, int iterationsN,
                           double loadDb, double bandWidth, double sampleRate, float* out_dev, double* gn_dev, void* stream)
+{ return wpe_single_impl(Y_dev, nframes_dev, U, Nmax, fftLen, lowerN, upperN, iterationsN, loadDb, bandWidth, sampleRate, out_dev, gn_dev, false, stream); }
+// the same for the next utterance (or block of a long stream) of an object that was reset() but not nextSpeaker()-ed: gn_dev (required) holds the
+// filters the utterance before left; they seed the first theta_n (dereverberation.cc:152-176) and are replaced by this utterance's
+dsr_status dsr_wpe_single_continue(const float* Y_dev, const int32_t* nframes_dev, int U, int Nmax, int fftLen, int lowerN, int upperN, int iterationsN,
+                                   double loadDb, double bandWidth, double sampleRate, float* out_dev, double* gn_dev, void* stream)
+{ return wpe_single_impl(Y_dev, nframes_dev, U, Nmax, fftLen, lowerN, upperN, iterationsN, loadDb, bandWidth, sampleRate, out_dev, gn_dev, true, stream); }
+static dsr_status wpe_single_impl(const float* Y_dev, const int32_t* nframes_dev, int U, int Nmax, int fftLen, int lowerN, int upperN, int iterationsN,
+                                  double loadDb, double bandWidth, double sampleRate, float* out_dev, double* gn_dev, bool warm, void* stream)
 {
   return guard([&] {
-    if (!Y_dev || !nframes_dev || !out_dev) throw Error(DSR_E_PARAMETER, "null argument");
+    if (!Y_dev || !nframes_dev || !out_dev || (warm && !gn_dev)) throw Error(DSR_E_PARAMETER, "null argument");
     if (upperN < lowerN || lowerN < 0 || iterationsN < 0) throw Error(DSR_E_PARAMETER, "bad prediction range [%d, %d]", lowerN, upperN);
     if (bandWidth > sampleRate / 2.0) throw Error(DSR_E_DIMENSION, "Bandwidth is greater than the Nyquist rate.");          // :261-262
     if (U <= 0 || Nmax <= 0) return;
@@ -279,7 +289,7 @@ dsr_status dsr_wpe_single(const float* Y_dev, const int32_t* nframes_dev, int U,
     if (lds > 150 * 1024) throw Error(DSR_E_DIMENSION, "WPE: %d frames x %d taps do not fit the LDS working set", Nmax, P);
     DSR_HIP(hipFuncSetAttribute((const void*) k_wpe, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
     hipLaunchKernelGGL(k_wpe, dim3(F, U), dim3(256), lds, (hipStream_t) stream, (const float2*) Y_dev, nframes_dev, (float2*) out_dev, (double2*) gn_dev,
-                       U, Nmax, F, fftLen, lowerN, P, iterationsN, pow(10.0, loadDb / 10.0), lowerBW);
+                       U, Nmax, F, fftLen, lowerN, P, iterationsN, pow(10.0, loadDb / 10.0), lowerBW, warm ? (const double2*) gn_dev : nullptr);
     DSR_HIP(hipGetLastError());
   });
 }

@@ -67,7 +67,19 @@ struct SampleSrc : dsr_stream {      // SampleFeature (feature.cc:222-689)
 };
 struct FrameSrc : dsr_stream {       // PyFeatureStream-like source: the caller hands over all frames (pyStream.h:44-130)
   std::vector<unsigned char> frames; int T = 0;
-  void compute() override { alloc(T); if (T > 0) DSR_HIP(hipMemcpy(dev.p, frames.data(), (size_t) T * rowBytes(), hipMemcpyHostToDevice)); }
+  // PyFeatureStream::reset() calls the Python object's reset() and starts a new iteration (pyStream.h:100-130).  A reset() that reaches this
+  // source through a downstream operator's cascade marks the frames stale; the owner's refill callback (it calls the Python reset() and hands
+  // the new frames over with dsr_frame_source_set_frames) runs before the next frame is served.
+  int (*refill)(void*) = nullptr; void* refillUser = nullptr; bool stale = false, filling = false;
+  void reset() override { dsr_stream::reset(); if (!filling) stale = true; }
+  void compute() override {
+    if (stale && refill) {
+      filling = true; const int rc = refill(refillUser); filling = false; stale = false;
+      if (rc != 0) throw Error(DSR_E_PYTHON, "the frame source's refill callback failed (%d)", rc);
+    }
+    stale = false;
+    alloc(T); if (T > 0) DSR_HIP(hipMemcpy(dev.p, frames.data(), (size_t) T * rowBytes(), hipMemcpyHostToDevice));
+  }
 };
 struct Preemph : dsr_stream { double mu; void compute() override { alloc(ups[0]->nFrames); op_preemph(ups[0]->d<float>(), nFrames, size_, mu, d<float>(), S0); } };
 struct Hamming : dsr_stream {
@@ -316,7 +328,15 @@ dsr_status dsr_frame_source_set_frames(dsr_stream* s, const void* data, size_t n
 {
   return guard([&] {
     FrameSrc* q = dynamic_cast<FrameSrc*>(s); if (!q || (!data && nframes)) throw Error(DSR_E_PARAMETER, "not a frame source");
-    q->frames.assign((const unsigned char*) data, (const unsigned char*) data + nframes * q->rowBytes()); q->T = (int) nframes; q->reset();
+    q->frames.assign((const unsigned char*) data, (const unsigned char*) data + nframes * q->rowBytes()); q->T = (int) nframes;
+    const bool f = q->filling; q->filling = true; q->reset(); q->filling = f; q->stale = false;          // fresh frames: nothing to refill
+  });
+}
+dsr_status dsr_frame_source_set_refill(dsr_stream* s, int (*refill)(void*), void* user)
+{
+  return guard([&] {
+    FrameSrc* q = dynamic_cast<FrameSrc*>(s); if (!q) throw Error(DSR_E_PARAMETER, "not a frame source");
+    q->refill = refill; q->refillUser = user;
   });
 }
 

@@ -8,6 +8,8 @@ import ctypes as C
 import os
 import re
 
+C_ = C
+
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -177,6 +179,45 @@ class FilterBank:
         return y
 
 
+class FilterBankState:
+    """what a filter bank carries from one block of a long stream to the next (dsr_fb_state): m*M - D samples per (stream, channel) for an
+    analysis plan, R*m - 1 subband frames per stream for a synthesis plan."""
+
+    def __init__(self, fb, U, C=1):
+        L = load(); self.h = vp(); self.fb, self.U, self.C = fb, U, C
+        check(L.dsr_fb_state_create(fb.h, U, C, C_.byref(self.h)))
+
+    def __del__(self):
+        if _lib is not None and getattr(self, "h", None):
+            _lib.dsr_fb_state_destroy(self.h)
+
+    def reset(self):
+        check(_lib.dsr_fb_state_reset(self.h))
+
+    def analysis_block(self, x, nsamp=None, last=False):
+        """x: cuda float32 [U][C][N] = the block's new samples -> complex64 [U][C][T][M/2+1], T = the frames this block yields"""
+        import torch
+        U, Cn, N = x.shape
+        ns = [N] * U if nsamp is None else [int(v) for v in nsamp]
+        nd = torch.tensor(ns, dtype=torch.int32, device=x.device)
+        T = max(1, max(_lib.dsr_fb_analysis_block_frames(self.fb.h, self.h, n, int(last)) for n in ns))
+        X = torch.empty((U, Cn, T, self.fb.M // 2 + 1, 2), dtype=torch.float32, device=x.device)
+        check(_lib.dsr_fb_analysis_block(self.fb.h, self.h, _dev(x), _dev(nd), U, Cn, N, int(last), T, _dev(X), cur_stream()))
+        return torch.view_as_complex(X)
+
+    def synthesis_block(self, Y, nframes=None):
+        """Y: cuda complex64 [U][T][M/2+1] = the block's new subband frames -> float32 [U][nblocks * D]"""
+        import torch
+        U, T, F = Y.shape
+        nf = [T] * U if nframes is None else [int(v) for v in nframes]
+        nd = torch.tensor(nf, dtype=torch.int32, device=Y.device)
+        nb = max(1, max(_lib.dsr_fb_synthesis_block_blocks(self.fb.h, self.h, n) for n in nf))
+        y = torch.zeros((U, nb * self.fb.D), dtype=torch.float32, device=Y.device)
+        Yr = torch.view_as_real(Y.contiguous())
+        check(_lib.dsr_fb_synthesis_block(self.fb.h, self.h, _dev(Yr), _dev(nd), max(nf), U, T, nb * self.fb.D, _dev(y), cur_stream()))
+        return y
+
+
 class Beamformer:
     """beamformerWeights + SubbandDS/GSC/MVDR weight design and apply (btk/beamformer/beamformer.h)."""
 
@@ -275,14 +316,21 @@ class Beamformer:
     def updateActiveWeightVecotrs(self, flag):
         check(_lib.dsr_bf_rls_adapt(self.h, int(bool(flag))))
 
-    def gsc_rls(self, X):
-        """X: cuda complex64 [U][C][T][F] -> (Y [U][T][F], final active weights [U][F][C-1] complex128)"""
+    def gsc_rls(self, X, nframes=None):
+        """X: cuda complex64 [U][C][T][F] -> (Y [U][T][F], final active weights [U][F][C-1] complex128); nframes: cuda int32 [U] valid frames"""
         import torch
         U, Cn, T, F = X.shape
         Y = torch.empty((U, T, F, 2), dtype=torch.float32, device=X.device)
         wa = torch.zeros((U, F, Cn - 1), dtype=torch.complex128, device=X.device)
-        check(_lib.dsr_bf_gsc_rls(self.h, _dev(torch.view_as_real(X.contiguous())), U, T, _dev(Y), _dev(wa), cur_stream()))
+        check(_lib.dsr_bf_gsc_rls(self.h, _dev(torch.view_as_real(X.contiguous())), _dev(nframes) if nframes is not None else None, U, T, _dev(Y), _dev(wa), cur_stream()))
         return torch.view_as_complex(Y), wa
+
+    def rlsCarry(self, on=True):
+        """keep adapting from call to call (block streaming; the reference's behaviour across reset())"""
+        check(_lib.dsr_bf_rls_carry(self.h, int(bool(on))))
+
+    def rlsResetState(self):
+        check(_lib.dsr_bf_rls_reset_state(self.h))
 
     def apply(self, X):
         """X: cuda complex64 [U][C][T][F] -> [U][T][F]"""
@@ -364,14 +412,19 @@ class NormalFFTBank:
         return X
 
 
-def wpe_single(Y, fftLen, lowerN, upperN, iterationsN=2, loadDb=-20.0, bandWidth=0.0, sampleRate=16000.0, nframes=None, want_filters=False):
-    """Single-channel WPE (dereverberation.cc:28-300): Y cuda complex64 [U][N][M/2+1] -> out (and the filters [U][M/2+1][P] complex128)."""
+def wpe_single(Y, fftLen, lowerN, upperN, iterationsN=2, loadDb=-20.0, bandWidth=0.0, sampleRate=16000.0, nframes=None, want_filters=False, gn=None):
+    """Single-channel WPE (dereverberation.cc:28-300): Y cuda complex64 [U][N][M/2+1] -> out (and the filters [U][M/2+1][P] complex128).
+    gn: the filters of the utterance / block before (reset() keeps them in the reference): used as the start and overwritten."""
     import torch
     load()
     U, N, F = Y.shape
     if nframes is None:
         nframes = torch.full((U,), N, dtype=torch.int32, device=Y.device)
     out = torch.zeros((U, N, F), dtype=torch.complex64, device=Y.device)
+    if gn is not None:
+        check(_lib.dsr_wpe_single_continue(_dev(Y.contiguous()), _dev(nframes), U, N, fftLen, lowerN, upperN, iterationsN, loadDb, bandWidth, sampleRate, _dev(out),
+                                           _dev(gn), cur_stream()))
+        return out, gn
     gn = torch.zeros((U, F, upperN - lowerN + 1), dtype=torch.complex128, device=Y.device) if want_filters else None
     check(_lib.dsr_wpe_single(_dev(Y.contiguous()), _dev(nframes), U, N, fftLen, lowerN, upperN, iterationsN, loadDb, bandWidth, sampleRate, _dev(out),
                               _dev(gn) if want_filters else None, cur_stream()))
@@ -417,6 +470,14 @@ class ZelinskiPostFilter:
         w = torch.zeros((U, T, F), dtype=torch.float32, device=X.device) if want_weights else None
         check(_lib.dsr_zelinski_apply(self.h, _dev(X.contiguous()), _dev(Y.contiguous()), _dev(nframes), U, T, _dev(out), _dev(w) if want_weights else None, cur_stream()))
         return (out, w) if want_weights else out
+
+
+    def carry(self, on=True):
+        """keep the spectral densities from call to call (block streaming)"""
+        check(_lib.dsr_zelinski_carry(self.h, int(bool(on))))
+
+    def resetState(self):
+        check(_lib.dsr_zelinski_reset_state(self.h))
 
 
 class McCowanPostFilter(ZelinskiPostFilter):

@@ -57,8 +57,9 @@ class SubbandGSCPtr(_Subband):
 
 
 class SubbandGSCRLSPtr(SubbandGSCPtr):
-    """beamformer.i:227-253 (SubbandGSCRLS, beamformer.cc:1497-1698).  Every reset() starts again from the precision matrices set
-    with initPrecisionMatrix()/setPrecisionMatrix() and zero active weights; the reference keeps adapting across reset()."""
+    """beamformer.i:227-253 (SubbandGSCRLS, beamformer.cc:1497-1698).  As in the reference the object keeps adapting across reset(): the
+    precision matrices and active weights an utterance leaves are where the next one starts (dsr_bf_rls_carry); only
+    initPrecisionMatrix()/setPrecisionMatrix() re-seed them."""
 
     def __init__(self, fftLen=512, halfBandShift=False, myu=0.9, sigma2=0.01, nm="SubbandGSCRLS"):
         SubbandGSCPtr.__init__(self, fftLen, halfBandShift, nm); self._myu, self._sigma2 = myu, sigma2
@@ -66,6 +67,7 @@ class SubbandGSCRLSPtr(SubbandGSCPtr):
     def calcGSCWeights(self, sampleRate, delaysT):
         SubbandGSCPtr.calcGSCWeights(self, sampleRate, delaysT)
         self._weights().rlsConfig(self._myu, self._sigma2)
+        self._weights().rlsCarry(True)
 
     def initPrecisionMatrix(self, sigma2=0.01):
         self._weights().initPrecisionMatrix(sigma2)

@@ -67,6 +67,9 @@ class FeatureStreamPtr(object):
 VectorFloatFeatureStreamPtr = VectorFeatureStreamPtr = VectorComplexFeatureStreamPtr = VectorShortFeatureStreamPtr = FeatureStreamPtr
 
 
+_REFILL = C.CFUNCTYPE(C.c_int, C.c_void_p)
+
+
 def _new(fn, *args, keep=()):
     h = C.c_void_p(); K.check(fn(*args, C.byref(h))); return h, keep
 
@@ -75,11 +78,38 @@ class _PySource(FeatureStreamPtr):
     """PyVector*FeatureStreamPtr(iterable): adapts a Python iterable with size()/reset()/__iter__ (pyStream.h:44-152).
     The iterable is drained into a frame source at every reset()."""
     _TYPE = 2
+    _exc = None
 
     def __init__(self, src, name="PyFeatureStream"):
         self._src = src; sz = int(src.size())
         h, _ = _new(lib().dsr_frame_source_create, self._TYPE, sz, name.encode())
         FeatureStreamPtr.__init__(self, h); self._load()
+        # a reset() of any downstream operator cascades to this source in C++ (streams.cpp FrameSrc::reset): the refill callback then calls the
+        # Python iterable's reset() and drains it again before the next frame is served, as PyFeatureStream::reset does (pyStream.h:100-130)
+        self._exc = None
+        self._cb = _REFILL(self._refill)
+        K.check(lib().dsr_frame_source_set_refill(self._h, C.cast(self._cb, C.c_void_p), None))
+
+    def _refill(self, _user):
+        try:
+            if hasattr(self._src, "reset"):
+                self._src.reset()
+            self._load()
+            return 0
+        except BaseException as e:                                 # JPYTHON: re-raised by next() (jexception.i:181-183)
+            self._exc = e
+            return 1
+
+    def next(self, frameX=-5):
+        try:
+            return FeatureStreamPtr.next(self, frameX)
+        except K.DsrError as e:
+            if e.status == 10 and self._exc is not None:
+                exc, self._exc = self._exc, None
+                raise exc
+            raise
+
+    __next__ = next
 
     def _load(self):
         dt = _NP[self._TYPE]

@@ -85,6 +85,28 @@ dsr_status dsr_fb_analysis(const dsr_fb*, const float* x_dev, const int32_t* nsa
 dsr_status dsr_fb_synthesis(const dsr_fb*, const float* Y_dev, const int32_t* nframes_dev, int U,
                             int Tmax, int64_t outStride, float* y_dev, void* stream);
 
+/* Block-wise processing of long streams (BASELINE configs[4]: 10-minute streams handed over in 10-second blocks).  The reference operators are
+ * streaming by construction: they keep ring buffers of the last m*M samples (analysis: _RealBuffer, modulated.h:79-163, modulated.cc:400-452)
+ * and of the last R*m subband frames (synthesis: modulated.cc:586-664).  A dsr_fb_state carries exactly that from one call to the next
+ * (m*M - D samples per (stream, channel); R*m - 1 subband frames per stream), so that the frames of all blocks together are the frames of the whole
+ * stream.  All U streams advance in step: every block but a stream's last holds a multiple of D samples.
+ *   analysis_block : x_dev [U][C][sampStride] the block's new samples, nsamp_dev [U]; last != 0 appends the processingDelay zero-input frames
+ *                    (modulated.cc:493-501).  Frames written per stream: dsr_fb_analysis_block_frames(plan, state, nsamp, last), asked BEFORE the call
+ *                    (the stream's first block spends the look-ahead of delayCompensationType 2).  X_dev [U][C][Tmax][M/2+1].
+ *   synthesis_block: Y_dev [U][Tmax][M/2+1], nframes_dev [U] (nframesHostMax = their maximum); output blocks per stream:
+ *                    dsr_fb_synthesis_block_blocks(plan, state, nframes), asked before the call (the first call keeps processingDelay frames of
+ *                    look-ahead back, modulated.cc:631-634, and needs at least processingDelay + R*m frames).  y_dev [U][outStride]. */
+typedef struct dsr_fb_state dsr_fb_state;
+dsr_status dsr_fb_state_create(const dsr_fb*, int U, int C /* ignored for a synthesis plan */, dsr_fb_state** out);
+void       dsr_fb_state_destroy(dsr_fb_state*);
+dsr_status dsr_fb_state_reset(dsr_fb_state*);            /* the next block starts new streams */
+int        dsr_fb_analysis_block_frames(const dsr_fb*, const dsr_fb_state*, int nsampBlock, int last);
+dsr_status dsr_fb_analysis_block(const dsr_fb*, dsr_fb_state*, const float* x_dev, const int32_t* nsamp_dev, int U, int C, int64_t sampStride,
+                                 int last, int Tmax, float* X_dev, void* stream);
+int        dsr_fb_synthesis_block_blocks(const dsr_fb*, const dsr_fb_state*, int nframesBlock);
+dsr_status dsr_fb_synthesis_block(const dsr_fb*, dsr_fb_state*, const float* Y_dev, const int32_t* nframes_dev, int nframesHostMax, int U, int Tmax,
+                                  int64_t outStride, float* y_dev, void* stream);
+
 /* =====================================================================================
  * 2. Subband beamformers
  *    replaces beamformerWeights / SubbandDS / SubbandGSC / SubbandMVDR
@@ -133,8 +155,16 @@ dsr_status dsr_bf_rls_init_precision(dsr_bf*, float sigma2);
 dsr_status dsr_bf_rls_set_precision(dsr_bf*, int fbinX, const double* Pz /* [C-1][C-1] complex128 */);
 dsr_status dsr_bf_rls_quadratic_constraint(dsr_bf*, float alpha, int qctype);
 dsr_status dsr_bf_rls_adapt(dsr_bf*, int flag);
-/* X_dev [U][C][Tmax][M/2+1] complex64 -> Y_dev [U][Tmax][M/2+1]; wa_out_dev (optional) [U][M/2+1][C-1] complex128: the final active weights */
-dsr_status dsr_bf_gsc_rls(dsr_bf*, const float* X_dev, int U, int Tmax, float* Y_dev, double* wa_out_dev, void* stream);
+/* X_dev [U][C][Tmax][M/2+1] complex64 -> Y_dev [U][Tmax][M/2+1]; wa_out_dev (optional) [U][M/2+1][C-1] complex128: the final active weights.
+ * nframes_dev (optional) [U]: utterance u is adapted over its first nframes[u] frames only -- the reference stops adapting at the stream's last
+ * frame (beamformer.cc:1552-1612) -- and the rest of its rows is zero.  chanN <= 64. */
+dsr_status dsr_bf_gsc_rls(dsr_bf*, const float* X_dev, const int32_t* nframes_dev, int U, int Tmax, float* Y_dev, double* wa_out_dev, void* stream);
+/* Carried adaptation state.  The reference object keeps its precision matrices and active weights across reset() (beamformer.cc:1552-1700: only
+ * initPrecisionMatrix / setPrecisionMatrix re-seed them).  carry = 1: every dsr_bf_gsc_rls / dsr_bf_apply(_frames) call of the same U continues from
+ * the state the previous one left -- block-wise processing of long streams, stream u of one call = stream u of the next; rls_reset_state (and the
+ * precision-matrix setters) make the next call start from P0 and zero weights again.  carry = 0 (default): every call starts afresh. */
+dsr_status dsr_bf_rls_carry(dsr_bf*, int on);
+dsr_status dsr_bf_rls_reset_state(dsr_bf*);
 /* which weight set `apply` uses: 0 = delay-and-sum wq, 1 = MVDR, 2 = GSC (wq - B wa), 3 = GSC normalised, 4 = MVDR-GSC (w_mvdr - wl) */
 dsr_status dsr_bf_select(dsr_bf*, int mode);
 /* read back host copies: kind 0 = wq [fftLen][C], 1 = mvdr [fftLen/2+1][C], 2 = R [fftLen/2+1][C][C],
@@ -142,6 +172,8 @@ dsr_status dsr_bf_select(dsr_bf*, int mode);
 dsr_status dsr_bf_get(const dsr_bf*, int kind, double* out, size_t outDoubles);
 /* Y[u][t][f] = w_f^H X[u][:][t][f], f = 0..M/2 (SubbandDS::next / SubbandMVDR::next / SubbandGSC::next) */
 dsr_status dsr_bf_apply(dsr_bf*, const float* X_dev, int U, int Tmax, float* Y_dev, void* stream);
+/* the same with per-utterance frame counts nframes_dev [U]: rows t >= nframes[u] are zero; an adapting (SubbandGSCRLS) object adapts on the valid frames only */
+dsr_status dsr_bf_apply_frames(dsr_bf*, const float* X_dev, const int32_t* nframes_dev, int U, int Tmax, float* Y_dev, void* stream);
 
 /* =====================================================================================
  * 3. MFCC feature chain
@@ -336,6 +368,12 @@ dsr_status dsr_mccowan_divide_nondiagonal(dsr_zelinski*, float myu);
 dsr_status dsr_lefkimmiatis_create(int fftLen, int chanN, double minSV, int fbinX1, double alpha, int type, int minFrames, float threshold, dsr_zelinski** out);
 dsr_status dsr_zelinski_apply(dsr_zelinski*, const float* X_dev, const float* Y_dev, const int32_t* nframes_dev, int U, int Tmax,
                               float* out_dev, float* wp1_dev, void* stream);
+/* Carried densities for block-wise processing of long streams (BASELINE configs[4]).  The reference operator's auto/cross spectral densities
+ * (postfilter.cc:428-497) live as long as the object: carry = 1 makes every apply of the same U continue the recursions where the previous call
+ * stopped (stream u of one call = stream u of the next; the start-up alpha = 0 and minFrames count from a stream's own first frame);
+ * reset_state begins new streams.  carry = 0 (default): every call is a batch of whole utterances.  chanN <= 64. */
+dsr_status dsr_zelinski_carry(dsr_zelinski*, int on);
+dsr_status dsr_zelinski_reset_state(dsr_zelinski*);
 
 /* Single-channel WPE dereverberation of a subband sequence (SingleChannelWPEDereverberationFeature, btk/dereverberation/
  * dereverberation.cc:28-300; SWIG defaults iterationsN 2, loadDb -20, bandWidth 0, sampleRate 16000).  Y_dev [U][Nmax][M/2+1]
@@ -343,6 +381,10 @@ dsr_status dsr_zelinski_apply(dsr_zelinski*, const float* X_dev, const float* Y_
  * filters start from zero for every utterance (nextSpeaker() semantics). */
 dsr_status dsr_wpe_single(const float* Y_dev, const int32_t* nframes_dev, int U, int Nmax, int fftLen, int lowerN, int upperN,
                           int iterationsN, double loadDb, double bandWidth, double sampleRate, float* out_dev, double* gn_dev, void* stream);
+/* the next utterance -- or the next block of a long stream -- of an object that was reset() but not nextSpeaker()-ed (dereverberation.cc:258-277:
+ * reset() keeps _gn): gn_dev (required) holds the filters the call before left; they seed the first theta_n and are replaced by this call's */
+dsr_status dsr_wpe_single_continue(const float* Y_dev, const int32_t* nframes_dev, int U, int Nmax, int fftLen, int lowerN, int upperN,
+                                   int iterationsN, double loadDb, double bandWidth, double sampleRate, float* out_dev, double* gn_dev, void* stream);
 /* MultiChannelWPEDereverberation (dereverberation.h:89-157, dereverberation.cc:281-586): Y_dev [U][chanN][Nmax][fftLen/2+1] complex64 -> out_dev same shape;
  * gn_dev [U][chanN][fftLen/2+1][chanN*(upperN-lowerN+1)] complex128 (required).  filterChan < 0: own filter per channel; >= 0: all channels through that
  * channel's filter = the reference's getOutput when that channel's feature asks for the frame first (dereverberation.cc:381) */
@@ -387,6 +429,10 @@ dsr_status dsr_sample_feature_set_samples(dsr_stream*, const float* samples, siz
    type is DSR_T_SHORT / DSR_T_FLOAT / DSR_T_DOUBLE / DSR_T_COMPLEX, data = nframes rows of `size` items */
 dsr_status dsr_frame_source_create(int type, int size, const char* name, dsr_stream** out);
 dsr_status dsr_frame_source_set_frames(dsr_stream*, const void* data, size_t nframes);
+/* PyFeatureStream::reset() (pyStream.h:100-130) calls the Python object's reset() and iterates it afresh.  A reset() that reaches the source
+   through a downstream operator marks its frames stale; `refill(user)` then runs before the next frame is served: it resets the caller's
+   iterable and hands the new frames over with dsr_frame_source_set_frames; non-zero return = failure (DSR_E_PYTHON). */
+dsr_status dsr_frame_source_set_refill(dsr_stream*, int (*refill)(void* user), void* user);
 /* operators (ctor argument order as the reference headers) */
 dsr_status dsr_analysis_bank_create(dsr_stream* samp, const double* prototype, int M, int m, int r,
                                     int delayCompensationType, const char* name, dsr_stream** out);

@@ -342,12 +342,15 @@ def lefkimmiatis_postfilter(X, Y, wq, R, lam, alpha=0.6, type=2, minFrames=0, th
     return out, wp1
 
 
-def wpe_single(Y, lowerN, upperN, iterationsN=2, loadDb=-20.0, bandWidth=0.0, sampleRate=16000.0):
-    """SingleChannelWPEDereverberationFeature (dereverberation.cc:28-300): Y [N][M] complex -> (out [N][M], gn [M][P])."""
+def wpe_single(Y, lowerN, upperN, iterationsN=2, loadDb=-20.0, bandWidth=0.0, sampleRate=16000.0, gnInit=None):
+    """SingleChannelWPEDereverberationFeature (dereverberation.cc:28-300): Y [N][M] complex -> (out [N][M], gn [M][P]).
+    gnInit [M][P]: the filters left by the utterance before (reset() keeps them, nextSpeaker() zeroes them, :258-277)."""
     Y = np.ascontiguousarray(Y, np.complex128); N, M = Y.shape; P = upperN - lowerN + 1
     out = np.zeros((N, M), np.complex128); gn = np.zeros((M, P), np.complex128)
-    L = lib(); L.orc_wpe_single.restype = C.c_int
-    rc = L.orc_wpe_single(_p(Y), N, M, lowerN, upperN, iterationsN, C.c_double(loadDb), C.c_double(bandWidth), C.c_double(sampleRate), _p(out), _p(gn))
+    g0 = np.ascontiguousarray(gnInit, np.complex128) if gnInit is not None else None
+    L = lib(); L.orc_wpe_single_w.restype = C.c_int
+    rc = L.orc_wpe_single_w(_p(Y), N, M, lowerN, upperN, iterationsN, C.c_double(loadDb), C.c_double(bandWidth), C.c_double(sampleRate),
+                            _p(g0) if g0 is not None else None, _p(out), _p(gn))
     if rc != 0:
         raise ValueError("wpe_single failed (%d)" % rc)
     return out, gn

@@ -50,8 +50,15 @@ static void chol_solve(const double* L, int P, const double* b, double* x)
 }
 
 /* Y: [N][M] complex double -> out [N][M]; gn (optional) [M][P].  returns 0, -1 Cholesky failed (GSL would abort), -2 bad parameters */
+int orc_wpe_single_w(const double* Y, int N, int M, int lowerN, int upperN, int iterationsN, double loadDb, double bandWidth, double sampleRate,
+                     const double* gnInit, double* out, double* gnOut);
 int orc_wpe_single(const double* Y, int N, int M, int lowerN, int upperN, int iterationsN, double loadDb, double bandWidth, double sampleRate,
                    double* out, double* gnOut)
+{ return orc_wpe_single_w(Y, N, M, lowerN, upperN, iterationsN, loadDb, bandWidth, sampleRate, NULL, out, gnOut); }
+/* gnInit (optional, [M][P]): the prediction filters the object still holds from the utterance before -- reset() keeps _gn, only nextSpeaker()
+   zeroes it (dereverberation.cc:258-277), so the first theta_n of the next utterance is computed with the previous filters */
+int orc_wpe_single_w(const double* Y, int N, int M, int lowerN, int upperN, int iterationsN, double loadDb, double bandWidth, double sampleRate,
+                     const double* gnInit, double* out, double* gnOut)
 {
   if (upperN < lowerN || N <= 0) return -2;
   if (bandWidth > sampleRate / 2.0) return -2;
@@ -59,6 +66,7 @@ int orc_wpe_single(const double* Y, int N, int M, int lowerN, int upperN, int it
   const double loadFactor = pow(10.0, loadDb / 10.0);
   const unsigned lowerBW = wpe_band(bandWidth, sampleRate, M), upperBW = (unsigned) M - lowerBW;
   double* gn = (double*) calloc((size_t) M * P * 2, sizeof(double));
+  if (gnInit) memcpy(gn, gnInit, sizeof(double) * (size_t) M * P * 2);
   double* theta = (double*) calloc((size_t) N * M, sizeof(double));
   double* R = (double*) calloc((size_t) P * P * 2, sizeof(double)); double* r = (double*) calloc((size_t) P * 2, sizeof(double));
   double* lag = (double*) calloc((size_t) P * 2, sizeof(double));

@@ -126,8 +126,9 @@ def test_beamformer_weights(dsr, oracle, cuda):
     assert np.abs(bf.get(0) - wq).max() < 1e-15
     assert np.abs(bf.get(2) - R).max() < 1e-15
     got = bf.get(1)
-    # fp32 SVD on both sides, different sweeps: agree to fp32 conditioning
-    assert np.abs(got - w).max() / np.abs(w).max() < 2e-3
+    # both sides restate LINPACK csvdc bit for bit (pinned by tests/golden/linpack_csvdc.npz, the reference's own routine): the fp32 SVD no
+    # longer separates them; what is left is fp64 summation order (round 1: two different Jacobi SVDs, 2e-3)
+    assert np.abs(got - w).max() / np.abs(w).max() < 1e-12
     assert np.all(got[0] == 1.0)                       # DC bin weights are all ones (beamformer.cc:2413-2415)
     # distortionless response d^H w = 1/C ... w^H d = 1/C for f>0
     resp = np.einsum("fc,fc->f", np.conj(got[1:]), wq[1:129])
@@ -761,9 +762,9 @@ def test_mccowan_postfilter(dsr, oracle, cuda, Cn, ptype, alpha, minFrames, myu)
 @pytest.mark.parametrize("Cn,ptype,alpha,minFrames,fbinX1,load", [(8, 2, 0.6, 0, 0, 0.05), (4, 1, 0.8, 2, 5, 0.2), (6, 2, 0.0, 0, 40, 0.01)])
 def test_lefkimmiatis_postfilter(dsr, oracle, cuda, Cn, ptype, alpha, minFrames, fbinX1, load):
     """postfilter.cc:948-1210 on McCowan's recursions: noise estimate sum (0.5(phi_ii+phi_jj) - phi_ij)/(1 - R_ij), divided by d^H pinv(R) d
-    from bin fbinX1 on.  The pseudo-inverse (reference: single-precision LINPACK SVD) is a double-precision Jacobi SVD on the product
-    side; the oracle uses the reference's single-precision csvdc pseudo-inverse (restated, pinned against the reference's own csvdc):
-    with the diagonally loaded (full rank) coherence matrices used here the weights agree to 2e-4."""
+    from bin fbinX1 on.  The pseudo-inverse is the reference's single-precision LINPACK csvdc on both sides (product: csrc/svd_linpack.cpp,
+    oracle: orc_svd.c; both pinned bit for bit against the reference's own routine), so the weights agree as McCowan's do: 1e-6 (round 1: a
+    double-precision Jacobi SVD on the product side, 2e-4)."""
     import torch
     rng = np.random.default_rng(70 + Cn)
     U, T, M = 2, 25, 64
@@ -783,8 +784,8 @@ def test_lefkimmiatis_postfilter(dsr, oracle, cuda, Cn, ptype, alpha, minFrames,
     got, w = got.cpu().numpy(), w.cpu().numpy()
     for u in range(U):
         wo, ww = oracle.lefkimmiatis_postfilter(X[u].astype(np.complex128), Y[u].astype(np.complex128), wq, R, lam, alpha, ptype, minFrames, 0.99, fbinX1)
-        np.testing.assert_allclose(w[u], ww, rtol=2e-4)               # the oracle's pseudo-inverse is the reference's single-precision one
-        assert np.abs(got[u] - wo).max() <= 2e-4 * np.abs(wo).max()
+        np.testing.assert_allclose(w[u], ww, rtol=1e-6)
+        assert np.abs(got[u] - wo).max() <= 1e-6 * np.abs(wo).max()
     assert 0.0001 < w.min() < 0.9 or w.max() > 0.0001
     # a rank-deficient matrix (bin 0 of the unloaded diffuse model is all ones): a singular value under the floor makes the reference fall
     # back to the identity for that bin (postfilter.cc:989-991), Lambda = d^H d; the floor is chosen above single-precision round-off

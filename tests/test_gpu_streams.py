@@ -186,3 +186,52 @@ def test_decode_like_decodeTest(dsr, oracle, cuda, headset, tmp_path):
     with pytest.raises(dsr.DsrError) as e:
         bad.set(wfst)
     assert e.value.status == 11                                  # jkey_error
+
+
+def test_python_source_is_refilled_when_a_downstream_operator_resets(dsr, cuda, headset):
+    """ADVICE r1: PyFeatureStream::reset() calls the Python object's reset() and iterates it afresh (pyStream.h:100-130).  The usual driver
+    resets or iterates the LAST operator of a chain; that reset cascades to the source inside the library, which must then pull the
+    Python iterable again -- a chain that kept serving the previous utterance's frames would return stale output silently."""
+    from dsr.btk.stream import PyVectorShortFeatureStreamPtr
+    from dsr.btk.feature import HammingFeaturePtr, FFTFeaturePtr
+
+    class Utterances:
+        """one utterance per reset(), as a Python driver feeding a list of files would"""
+
+        def __init__(self, utts):
+            self.utts, self.k, self.resets = utts, -1, 0
+
+        def size(self):
+            return 320
+
+        def reset(self):
+            self.resets += 1; self.k = min(self.k + 1, len(self.utts) - 1)
+
+        def __iter__(self):
+            return iter(self.utts[max(self.k, 0)])
+
+    mk = lambda off, n: np.stack([headset[off + 160 * t:off + 160 * t + 320] for t in range(n)]).astype(np.int16)
+    u0, u1 = mk(6000, 12), mk(30000, 7)
+    it = Utterances([u0, u1])
+    src = PyVectorShortFeatureStreamPtr(it)
+    fft = FFTFeaturePtr(HammingFeaturePtr(src), fftLen=512)
+    win = 0.54 - 0.46 * np.cos(2 * np.pi * np.arange(320) / 319.0)
+    ref = lambda b: np.fft.fft((win * b.astype(np.float64)).astype(np.float32).astype(np.float64), 512, axis=1)
+    a = np.stack([np.array(v) for v in fft])                    # __iter__ resets the LAST operator only
+    assert a.shape[0] == 12 and np.abs(a - ref(u0)).max() <= 1e-9 * np.abs(ref(u0)).max()
+    r0 = it.resets
+    b = np.stack([np.array(v) for v in fft])                    # second utterance: the source must have been reset and drained again
+    assert it.resets == r0 + 1
+    assert b.shape[0] == 7 and np.abs(b - ref(u1)).max() <= 1e-9 * np.abs(ref(u1)).max()
+
+    class Broken(Utterances):
+        def reset(self):
+            Utterances.reset(self)
+            if self.resets >= 1:
+                raise RuntimeError("reset failed in Python")
+
+    src2 = PyVectorShortFeatureStreamPtr(Broken([u0, u1]))
+    ham2 = HammingFeaturePtr(src2)
+    ham2.reset()
+    with pytest.raises((RuntimeError, dsr.DsrError)):           # JPYTHON surfaces (jexception.i:181-183), never stale frames
+        ham2.next()
