@@ -24,6 +24,7 @@
 // non-contracted IEEE operations (this file is compiled with -ffp-contract=off).
 #include "common.h"
 #include "wfst_graph.h"
+#include "lattice.h"
 #include <cmath>
 #include <type_traits>
 
@@ -71,6 +72,10 @@ struct DecDev {
   int* queue; long long* prof;          // prof: optional per-phase wall-clock ticks (DSR_VITERBI_PROF), 16 per slot
   // dump (slot 0 only)
   int dumpOn; long dumpCap; long* dumpFrameOff; int* dumpNode; float* dumpAc; float* dumpLm; int* dumpArc; long* dumpCount;
+  // lattice bookkeeping (generateLattice, decoder.h:531-541,805-953): EVERY placement of every frame is kept, per utterance, in arrival order --
+  // {ac, lm, record, parent back pointer} + its unrounded total (the reference's 'worse' chains are an order-dependent function of exactly
+  // these; the host replays them, lattice.cpp) -- plus, per back-pointer record, the placement that won its state, and the final token list.
+  int latOn; long latCap; uint4* lat; double* latTtl; long* latFrameOff; int* arenaLat; int4* latFinal; int* latInfo;
 };
 
 __device__ __forceinline__ unsigned ld_u32(const unsigned* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
@@ -157,7 +162,7 @@ __global__ __launch_bounds__(kThreads) void k_viterbi(GraphDev G, DecDev Dd, con
   // first[] holds (tag << 24 | slot); tags count DOWN so every entry of an older frame compares larger and never
   // needs resetting; the table is wiped when the 8-bit tag runs out (and on the very first use of a slot)
   unsigned tag = Dd.tags[slot];
-  Bp* arena = Dd.arena + (size_t) slot * Dd.arenaCap;
+  Bp* arena = Dd.arena + (size_t) slot * Dd.arenaCap;                 // (lattice mode: one per utterance, set below)
   const int fastCapC = ((kFastK + 32) * nthr < kFastC) ? (kFastK + 32) * nthr : kFastC;
   const int fastCapN = kP1 * 64 * nw;                                   // kP1 rounds of 64 tokens per wave
   const bool fastOK = Dd.fastOK && hashN >= 8192;
@@ -170,6 +175,9 @@ __global__ __launch_bounds__(kThreads) void k_viterbi(GraphDev G, DecDev Dd, con
     __syncthreads();
     const int u = s_u;
     if (u >= U) break;
+    if (Dd.latOn) arena = Dd.arena + (size_t) u * Dd.arenaCap;       // the back pointers outlive the slot: the host builds the lattice from them
+    long latOff = 0;
+    if (Dd.latOn && tid == 0) Dd.latFrameOff[(size_t) u * (Tmax + 3)] = 0;
     if (Dd.prof && tid == 0) { const long long tn = (long long) wall_clock64(); if (s_prof[15]) s_prof[10] += tn - s_prof[15]; s_tlast = tn; }
     const int T = nframesArr[u] < Tmax ? nframesArr[u] : Tmax;
     const float* sc = scores + (size_t) u * Tmax * nDist;
@@ -202,7 +210,7 @@ __global__ __launch_bounds__(kThreads) void k_viterbi(GraphDev G, DecDev Dd, con
       const float* rowG = sc + (size_t) fr * nDist;                            // the frame's score row in memory
       int numNew = 0, numStat = -1;                                           // tokens written to the new list / tokens the reference's list would hold
       if (Dd.prof && tid == 0) s_tlast = (long long) wall_clock64();
-      bool fast = fastOK && mode == 0 && n <= fastCapN;
+      bool fast = fastOK && mode == 0 && n <= fastCapN && !Dd.latOn;          // lattice bookkeeping needs every placement in memory: the memory path has them
 
       if (fast) {
         // ======================= register path =======================
@@ -655,6 +663,7 @@ __global__ __launch_bounds__(kThreads) void k_viterbi(GraphDev G, DecDev Dd, con
       int C = 0;
       for (int w = 0; w < nw; w++) C += s_waveTot[w];
       if (C > Dd.maxCand) { status = DSR_E_ALLOCATION; break; }
+      if (Dd.latOn && latOff + C > Dd.latCap) { status = DSR_E_ALLOCATION; break; }
       placements += C;
       const bool useHash = hashN > 0 && C <= (hashN >> 1) + (hashN >> 2);        // load factor <= 0.75 even if every placement is a new state
       // ---------------- phase A2: absolute offsets + owner fill
@@ -808,9 +817,19 @@ __global__ __launch_bounds__(kThreads) void k_viterbi(GraphDev G, DecDev Dd, con
                 else { bp.prev = bw.prevBp; bp.rec = (uint32_t) bw.rec; }
               }
               nxtA[pos] = na; nxtB[pos] = nb; arena[arenaOff + pos] = bp;
+              if (Dd.latOn) Dd.arenaLat[(size_t) u * Dd.arenaCap + arenaOff + pos] = (int) (latOff + w);
             }
           }
         }
+      }
+      if (Dd.latOn) {                                                          // this frame's placements, arrival order
+        uint4* lat = Dd.lat + (size_t) u * Dd.latCap; double* ltt = Dd.latTtl + (size_t) u * Dd.latCap;
+        for (int c = tid; c < C; c += nthr) {
+          const CandA a = cA[c]; const CandB b = cB[c];
+          lat[latOff + c] = make_uint4(__float_as_uint(a.ac), __float_as_uint(a.lm), (unsigned) b.rec, b.prevBp); ltt[latOff + c] = a.ttl;
+        }
+        latOff += C;
+        if (tid == 0) Dd.latFrameOff[(size_t) u * (Tmax + 3) + fr + 1] = latOff;
       }
       }   // memory path
       __syncthreads();
@@ -843,6 +862,11 @@ __global__ __launch_bounds__(kThreads) void k_viterbi(GraphDev G, DecDev Dd, con
         }
         key = wave_min_u64(key);
         if (lane == 0) s_waveKey[wave] = key;
+        if (Dd.latOn) {                                                        // _next after _expandToEnd (or _current when no token is final), list order
+          const TokB* lstB = numNew > 0 ? nxtB : curB; int4* lf = Dd.latFinal + (size_t) u * Dd.maxTok;
+          for (int i = tid; i < cntL; i += nthr) { const TokA t = lst[i]; lf[i] = make_int4(lstB[i].node, (int) t.bp, __float_as_int(t.ac), __float_as_int(t.lm)); }
+          if (tid == 0) { int* li = Dd.latInfo + 4 * (size_t) u; li[0] = cntL; li[1] = numNew > 0 ? 1 : 0; li[2] = (int) (arenaOff + (numNew > 0 ? numNew : 0)); li[3] = T; }
+        }
         __syncthreads();
         // traceback (bestHypo, decoder.h:748-773).  One thread follows the back pointers (one dependent 8-byte load per frame) and
         // leaves the hop records in scratch memory; everything else -- arcs per hop, their places in the list, the word sequence --
@@ -933,6 +957,9 @@ struct DecoderState {
   DevBuf<TokA> d_tokA, d_ctok; DevBuf<TokB> d_tokB; DevBuf<Side> d_side; DevBuf<XRecD> d_xrecD; int fastOK = 0; DevBuf<int> d_tokOff, d_tokCnt, d_owner, d_rank, d_chead; DevBuf<unsigned> d_tags; DevBuf<CandA> d_cA; DevBuf<CandB> d_cB; DevBuf<unsigned> d_first; DevBuf<Bp> d_arena;
   DevBuf<long long> d_prof; DevBuf<dsr_decode_result> d_res; DevBuf<int> d_arcs; DevBuf<unsigned> d_words;
   long arenaCap = 0; int initial = 0; int threads = kThreads; bool twoPerCu = false;
+  // lattice bookkeeping of the last decode (cfg.latticeTokens > 0), per utterance
+  DevBuf<uint4> d_lat; DevBuf<double> d_latTtl; DevBuf<long> d_latFrameOff; DevBuf<int> d_arenaLat; DevBuf<int4> d_latFinal; DevBuf<int> d_latInfo;
+  int latU = 0, latTmax = 0; long latArenaCap = 0; WfstGraph graphCopy;
   PinBuf<dsr_decode_result> h_res; PinBuf<int> h_arcs; PinBuf<unsigned> h_words; hipEvent_t evDone = nullptr;
   int pendingU = 0; size_t pendingPath = 0; int pendingSlots = 0; long long* pendingProf = nullptr;
   // dump
@@ -1001,7 +1028,7 @@ dsr_status dsr_decoder_set(dsr_decoder* d, const dsr_wfst* g)
     if (!d || !g) throw Error(DSR_E_PARAMETER, "null argument");
     if (g->initial < 0) throw Error(DSR_E_CONSISTENCY, "the transducer has no arcs");
     d->csr = g->csr(); d->tab = g->tables(d->csr, (size_t) 1 << 28);
-    d->nNodes = (int) g->nodes.size(); d->initial = g->initial;
+    d->nNodes = (int) g->nodes.size(); d->initial = g->initial; d->graphCopy = *g;
     std::vector<int> nf(d->nNodes); std::vector<float> nc(d->nNodes);
     for (int i = 0; i < d->nNodes; i++) { nf[i] = g->nodes[i].final_; nc[i] = g->nodes[i].cost; }
     d->d_xoff.upload(d->tab.xoff); d->d_eoff.upload(d->tab.eoff); d->d_path.upload(d->tab.path);
@@ -1038,12 +1065,12 @@ dsr_status dsr_decoder_set_beam(dsr_decoder* d, double beam) { return guard([&] 
 
 dsr_status dsr_decoder_enable_dump(dsr_decoder* d, int en) { return guard([&] { if (!d) throw Error(DSR_E_PARAMETER, "null argument"); d->dumpOn = en; }); }
 
-static void ensure_scratch(dsr_decoder* d, int slots, int Tmax)
+static void ensure_scratch(dsr_decoder* d, int slots, int Tmax, int arenas)
 {
   const dsr_decoder_cfg& c = d->cfg;
   long arena = c.arenaTokens > 0 ? (long) c.arenaTokens : (long) 8192 * (long) (Tmax + 2);
   if (arena > 0x7FFFFFF0L) arena = 0x7FFFFFF0L;
-  if (slots <= d->nSlots && arena <= d->arenaCap) return;
+  if (slots <= d->nSlots && arena <= d->arenaCap && (size_t) (arenas > slots ? arenas : slots) * (size_t) arena <= d->d_arena.n) return;
   if (slots < d->nSlots) slots = d->nSlots;
   if (arena < d->arenaCap) arena = d->arenaCap;
   const size_t S = (size_t) slots;
@@ -1053,7 +1080,7 @@ static void ensure_scratch(dsr_decoder* d, int slots, int Tmax)
   d->d_cA.reserve(S * c.maxCandidates); d->d_cB.reserve(S * c.maxCandidates);
   d->d_first.reserve(S * d->nNodes); d->d_tokCnt.reserve(S * (c.maxActive + 1)); d->d_chead.reserve(S * c.maxCandidates);
   d->d_tags.reserve(S); DSR_HIP(hipMemset(d->d_tags.p, 0, S * sizeof(unsigned)));          // tag 0 = wipe the table on first use
-  d->d_arena.reserve(S * (size_t) arena);
+  d->d_arena.reserve((size_t) (arenas > slots ? arenas : slots) * (size_t) arena);
   d->d_queue.reserve(1);
   d->nSlots = slots; d->arenaCap = arena;
 }
@@ -1074,7 +1101,9 @@ dsr_status dsr_decoder_decode_launch(dsr_decoder* d, const float* score, const i
     // every input symbol must name a distribution (decoder.h:985: _dist->find(distX-1))
     for (size_t a = 0; a < d->csr.in.size(); a++) if (d->csr.in[a] > (uint32_t) nDist) throw Error(DSR_E_INDEX, "arc input %u has no distribution (nDist=%d)", d->csr.in[a], nDist);
     int slots = d->cfg.streams; if (slots > U) slots = U; if (d->dumpOn) slots = 1;
-    ensure_scratch(d, slots, Tmax);
+    const bool latOn = d->cfg.latticeTokens > 0;
+    if (latOn && d->dumpOn) throw Error(DSR_E_PARAMETER, "lattice bookkeeping and the token dump are separate debugging aids: enable one");
+    ensure_scratch(d, slots, Tmax, latOn ? U : 0);
     d->d_res.reserve(U);
     if (maxPath < 0) maxPath = 0;
     if (arcs_out || words_out) { d->d_arcs.reserve((size_t) U * (maxPath > 0 ? maxPath : 1)); d->d_words.reserve((size_t) U * (maxPath > 0 ? maxPath : 1)); }
@@ -1096,6 +1125,15 @@ dsr_status dsr_decoder_decode_launch(dsr_decoder* d, const float* score, const i
     if (getenv("DSR_VITERBI_PROF")) { d->d_prof.reserve((size_t) slots * 16); D.prof = d->d_prof.p; }
     D.dumpOn = d->dumpOn; D.dumpCap = d->dumpCap; D.dumpFrameOff = d->d_dumpFrameOff.p; D.dumpNode = d->d_dumpNode.p; D.dumpAc = d->d_dumpAc.p;
     D.dumpLm = d->d_dumpLm.p; D.dumpArc = d->d_dumpArc.p; D.dumpCount = d->d_dumpCount.p;
+    D.latOn = latOn ? 1 : 0; D.latCap = 0; D.lat = nullptr; D.latTtl = nullptr; D.latFrameOff = nullptr; D.arenaLat = nullptr; D.latFinal = nullptr; D.latInfo = nullptr;
+    if (latOn) {
+      const size_t cap = (size_t) d->cfg.latticeTokens;
+      d->d_lat.reserve((size_t) U * cap); d->d_latTtl.reserve((size_t) U * cap); d->d_latFrameOff.reserve((size_t) U * (Tmax + 3));
+      d->d_arenaLat.reserve((size_t) U * (size_t) d->arenaCap); d->d_latFinal.reserve((size_t) U * d->cfg.maxActive); d->d_latInfo.reserve((size_t) 4 * U);
+      DSR_HIP(hipMemsetAsync(d->d_latInfo.p, 0, sizeof(int) * 4 * (size_t) U, st));
+      D.latCap = (long) cap; D.lat = d->d_lat.p; D.latTtl = d->d_latTtl.p; D.latFrameOff = d->d_latFrameOff.p; D.arenaLat = d->d_arenaLat.p; D.latFinal = d->d_latFinal.p; D.latInfo = d->d_latInfo.p;
+      d->latU = U; d->latTmax = Tmax; d->latArenaCap = d->arenaCap;
+    } else d->latU = 0;
     // LDS: [score row][state table: 2 x hashN words][slot offsets of the expanding tokens]; the row stays in global memory
     // when it would push the state table below the size the register path needs
     // Two shapes: one workgroup per CU (16384 buckets, 512 threads) or two per CU (8192 buckets, 256 threads each: two
@@ -1168,6 +1206,75 @@ dsr_status dsr_decoder_decode_batch(dsr_decoder* d, const float* score, const in
   const dsr_status s1 = dsr_decoder_decode_launch(d, score, nframes, U, Tmax, nDist, maxPath, (arcs_out || words_out) ? 1 : 0, stream);
   if (s1 != DSR_OK) return s1;
   return dsr_decoder_decode_collect(d, res, arcs_out, words_out);
+}
+
+// _Decoder::lattice() (decoder.h:805-860) for utterance u of the last decode (cfg.latticeTokens > 0)
+struct dsr_lattice : dsr::LatticeData {};
+dsr_status dsr_decoder_lattice(dsr_decoder* d, int u, uint32_t eosX, dsr_lattice** out)
+{
+  return guard([&] {
+    if (!d || !out) throw Error(DSR_E_PARAMETER, "null argument");
+    if (d->latU <= 0) throw Error(DSR_E_CONSISTENCY, "Must enable lattice generation during decoding.");                 // decoder.h:807-808
+    if (d->pendingU > 0) throw Error(DSR_E_CONSISTENCY, "a decode is in flight: collect it first");
+    if (u < 0 || u >= d->latU) throw Error(DSR_E_INDEX, "utterance %d of %d", u, d->latU);
+    int info[4]; DSR_HIP(hipMemcpy(info, d->d_latInfo.p + 4 * (size_t) u, sizeof(info), hipMemcpyDeviceToHost));
+    const int finN = info[0], haveNext = info[1], T = info[3]; const long arenaN = info[2];
+    if (T <= 0) throw Error(DSR_E_CONSISTENCY, "utterance %d was not decoded to its end (status of its decode result)", u);
+    std::vector<long> frameOff((size_t) T + 2);
+    DSR_HIP(hipMemcpy(frameOff.data(), d->d_latFrameOff.p + (size_t) u * (d->latTmax + 3), sizeof(long) * ((size_t) T + 2), hipMemcpyDeviceToHost));
+    const long nP = frameOff[(size_t) T + 1];
+    std::vector<LatPlace> place((size_t) (nP > 0 ? nP : 1)); std::vector<double> ttl((size_t) (nP > 0 ? nP : 1));
+    std::vector<LatBp> arena((size_t) (arenaN > 0 ? arenaN : 1)); std::vector<int> arenaLat((size_t) (arenaN > 0 ? arenaN : 1)); std::vector<LatFinalTok> fin((size_t) (finN > 0 ? finN : 1));
+    const size_t cap = (size_t) d->cfg.latticeTokens;
+    if (nP > 0) { DSR_HIP(hipMemcpy(place.data(), d->d_lat.p + (size_t) u * cap, sizeof(LatPlace) * (size_t) nP, hipMemcpyDeviceToHost));
+                  DSR_HIP(hipMemcpy(ttl.data(), d->d_latTtl.p + (size_t) u * cap, sizeof(double) * (size_t) nP, hipMemcpyDeviceToHost)); }
+    if (arenaN > 0) { DSR_HIP(hipMemcpy(arena.data(), d->d_arena.p + (size_t) u * (size_t) d->latArenaCap, sizeof(LatBp) * (size_t) arenaN, hipMemcpyDeviceToHost));
+                      DSR_HIP(hipMemcpy(arenaLat.data(), d->d_arenaLat.p + (size_t) u * (size_t) d->latArenaCap, sizeof(int) * (size_t) arenaN, hipMemcpyDeviceToHost)); }
+    if (finN > 0) DSR_HIP(hipMemcpy(fin.data(), d->d_latFinal.p + (size_t) u * d->cfg.maxActive, sizeof(LatFinalTok) * (size_t) finN, hipMemcpyDeviceToHost));
+    LatInput in; in.graph = &d->graphCopy; in.csr = &d->csr; in.tab = &d->tab; in.lmScale = d->cfg.lmScale; in.lmPenalty = d->cfg.lmPenalty; in.silPenalty = d->cfg.silPenalty;
+    in.silenceX = d->cfg.silenceX; in.eosX = eosX; in.T = T; in.place = place.data(); in.ttl = ttl.data(); in.frameOff = frameOff.data();
+    in.arena = arena.data(); in.arenaLat = arenaLat.data(); in.arenaN = arenaN; in.fin = fin.data(); in.finN = finN; in.haveNext = haveNext;
+    dsr_lattice* L = new dsr_lattice();
+    try { build_lattice(in, *L); } catch (...) { delete L; throw; }
+    *out = L;
+  });
+}
+void dsr_lattice_destroy(dsr_lattice* L) { delete L; }
+int dsr_lattice_num_nodes(const dsr_lattice* L) { return L ? (int) L->nodeFinal.size() : 0; }
+int dsr_lattice_num_edges(const dsr_lattice* L) { return L ? (int) L->from.size() : 0; }
+int dsr_lattice_final_states_n(const dsr_lattice* L) { return L ? L->finalStatesN : 0; }
+dsr_status dsr_lattice_get(const dsr_lattice* L, int32_t* nodeFinal, int32_t* from, int32_t* to, uint32_t* in, uint32_t* out, int32_t* start, int32_t* end, double* ac, double* lm)
+{
+  return guard([&] {
+    if (!L) throw Error(DSR_E_PARAMETER, "null argument");
+    const size_t nE = L->from.size();
+    if (nodeFinal) memcpy(nodeFinal, L->nodeFinal.data(), 4 * L->nodeFinal.size());
+    if (from && nE) memcpy(from, L->from.data(), 4 * nE); if (to && nE) memcpy(to, L->to.data(), 4 * nE);
+    if (in && nE) memcpy(in, L->in.data(), 4 * nE); if (out && nE) memcpy(out, L->out.data(), 4 * nE);
+    if (start && nE) memcpy(start, L->start.data(), 4 * nE); if (end && nE) memcpy(end, L->end.data(), 4 * nE);
+    if (ac && nE) memcpy(ac, L->ac.data(), 8 * nE); if (lm && nE) memcpy(lm, L->lm.data(), 8 * nE);
+  });
+}
+dsr_status dsr_lattice_write(const dsr_lattice* L, const char* fileName, int writeData)
+{ return guard([&] { if (!L || !fileName) throw Error(DSR_E_PARAMETER, "null argument"); L->write(fileName, writeData != 0); }); }
+size_t dsr_lattice_pack_size(const dsr_lattice* L) { return L ? 16 + 4 * L->nodeFinal.size() + 40 * L->from.size() : 0; }
+dsr_status dsr_lattice_pack(const dsr_lattice* L, void* buf, size_t bufBytes)
+{
+  return guard([&] {
+    if (!L || !buf) throw Error(DSR_E_PARAMETER, "null argument");
+    const std::vector<unsigned char> b = L->pack();
+    if (b.size() > bufBytes) throw Error(DSR_E_DIMENSION, "buffer holds %zu bytes, the lattice needs %zu", bufBytes, b.size());
+    memcpy(buf, b.data(), b.size());
+  });
+}
+dsr_status dsr_lattice_unpack(const void* buf, size_t bytes, dsr_lattice** out)
+{
+  return guard([&] {
+    if (!buf || !out) throw Error(DSR_E_PARAMETER, "null argument");
+    dsr_lattice* L = new dsr_lattice();
+    try { static_cast<LatticeData&>(*L) = LatticeData::unpack((const unsigned char*) buf, bytes); } catch (...) { delete L; throw; }
+    *out = L;
+  });
 }
 
 dsr_status dsr_decoder_get_dump(dsr_decoder* d, int64_t* nFrames, const int64_t** frameOff, const int32_t** node,

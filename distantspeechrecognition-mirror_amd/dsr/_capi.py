@@ -42,7 +42,7 @@ class MfccCfg(C.Structure):
 
 class DecoderCfg(C.Structure):
     _fields_ = [("beam", f64), ("lmScale", f64), ("lmPenalty", f64), ("silPenalty", f64), ("silenceX", u32),
-                ("maxActive", C.c_int), ("maxCandidates", C.c_int), ("arenaTokens", i64), ("streams", C.c_int)]
+                ("maxActive", C.c_int), ("maxCandidates", C.c_int), ("arenaTokens", i64), ("streams", C.c_int), ("latticeTokens", i64)]
 
 
 class DecodeResult(C.Structure):
@@ -643,10 +643,10 @@ class Decoder:
     """DecoderFlyWeight (asr/decoder/decoder.i:147-199) for batches of score matrices."""
 
     def __init__(self, beam=100.0, lmScale=12.0, lmPenalty=0.0, silPenalty=0.0, silenceX=0xFFFFFFFF, maxActive=0,
-                 maxCandidates=0, arenaTokens=0, streams=0):
+                 maxCandidates=0, arenaTokens=0, streams=0, latticeTokens=0):
         L = load(); c = DecoderCfg(); L.dsr_decoder_default_cfg(C.byref(c))
         c.beam, c.lmScale, c.lmPenalty, c.silPenalty, c.silenceX = beam, lmScale, lmPenalty, silPenalty, silenceX
-        c.maxActive, c.maxCandidates, c.arenaTokens, c.streams = maxActive, maxCandidates, arenaTokens, streams
+        c.maxActive, c.maxCandidates, c.arenaTokens, c.streams, c.latticeTokens = maxActive, maxCandidates, arenaTokens, streams, latticeTokens
         self.h = vp(); check(L.dsr_decoder_create(C.byref(c), C.byref(self.h))); self._g = None
 
     def __del__(self):
@@ -681,6 +681,11 @@ class Decoder:
                             activeHypos=r.activeHypos, maxActive=r.maxActiveSeen, placements=r.placements, registerFrames=r.registerFrames))
         return out
 
+    def lattice(self, u=0, eosX=0):
+        """_Decoder::lattice() (decoder.h:805-860) of utterance u of the last decode (needs latticeTokens > 0)"""
+        h = vp(); check(_lib.dsr_decoder_lattice(self.h, int(u), int(eosX), C.byref(h)))
+        return Lattice(h)
+
     def get_dump(self):
         n = i64(); fo = C.POINTER(i64)(); nd = C.POINTER(i32)(); ac = C.POINTER(f32)(); lm = C.POINTER(f32)(); arc = C.POINTER(i32)()
         check(_lib.dsr_decoder_get_dump(self.h, C.byref(n), C.byref(fo), C.byref(nd), C.byref(ac), C.byref(lm), C.byref(arc)))
@@ -689,6 +694,37 @@ class Decoder:
         N = int(off[-1])
         g = lambda p, dt: np.ctypeslib.as_array(p, (N,)).astype(dt).copy() if N > 0 else np.zeros(0, dt)
         return dict(frameOff=off, node=g(nd, np.int32), ac=g(ac, np.float32), lm=g(lm, np.float32), arc=g(arc, np.int32))
+
+
+class Lattice:
+    """asr/lattice Lattice as the decoder builds it: nodes numbered as the reference numbers them (0 = initial), edges in creation order."""
+
+    def __init__(self, handle):
+        self.h = handle
+        n, e = _lib.dsr_lattice_num_nodes(self.h), _lib.dsr_lattice_num_edges(self.h)
+        d = {"nodeFinal": np.zeros(n, np.int32), "from": np.zeros(e, np.int32), "to": np.zeros(e, np.int32), "in": np.zeros(e, np.uint32),
+             "out": np.zeros(e, np.uint32), "start": np.zeros(e, np.int32), "end": np.zeros(e, np.int32), "ac": np.zeros(e, np.float64), "lm": np.zeros(e, np.float64)}
+        check(_lib.dsr_lattice_get(self.h, *[_ptr(d[k]) for k in ("nodeFinal", "from", "to", "in", "out", "start", "end", "ac", "lm")]))
+        self.data = d; self.finalStatesN = _lib.dsr_lattice_final_states_n(self.h)
+
+    def __del__(self):
+        if _lib is not None and getattr(self, "h", None):
+            _lib.dsr_lattice_destroy(self.h)
+
+    def write(self, fileName, useSymbols=False, writeData=False):
+        """Lattice::write (lattice.cc:715-757); useSymbols needs the lexica and is not offered here"""
+        if useSymbols:
+            raise DsrError(13, "useSymbols: write the numeric form and map the symbols with the lexica")
+        check(_lib.dsr_lattice_write(self.h, fileName.encode(), int(writeData)))
+
+    def pack(self):
+        n = _lib.dsr_lattice_pack_size(self.h); b = np.zeros(n, np.uint8)
+        check(_lib.dsr_lattice_pack(self.h, _ptr(b), n)); return b
+
+    @staticmethod
+    def unpack(buf):
+        load(); b = np.ascontiguousarray(buf, np.uint8); h = vp()
+        check(_lib.dsr_lattice_unpack(_ptr(b), b.size, C.byref(h))); return Lattice(h)
 
 
 class Pipe:

@@ -256,6 +256,8 @@ typedef struct {
   int maxCandidates;        /* placements per frame      (0 = default 8*maxActive) */
   int64_t arenaTokens;      /* back-pointer records per utterance (0 = default 64 * frames * 1024) */
   int streams;              /* concurrent utterance slots (0 = default 2 per CU) */
+  int64_t latticeTokens;    /* generateLattice (decoder.i:199): > 0 keeps every placement of every frame, at most this many per utterance, for
+                               dsr_decoder_lattice(); 0 (default here; the reference always builds its 'worse' chains, decoder.h:1113-1114) = 1-best only */
 } dsr_decoder_cfg;
 void dsr_decoder_default_cfg(dsr_decoder_cfg*);
 typedef struct dsr_decoder dsr_decoder;
@@ -287,6 +289,27 @@ dsr_status dsr_decoder_decode_batch(dsr_decoder*, const float* score_dev, const 
 dsr_status dsr_decoder_decode_launch(dsr_decoder*, const float* score_dev, const int32_t* nframes_dev, int U,
                                      int Tmax, int nDist, int maxPath, int want_paths, void* stream);
 dsr_status dsr_decoder_decode_collect(dsr_decoder*, dsr_decode_result* res, int32_t* arcs_out, uint32_t* words_out);
+/* Lattice generation: _Decoder::lattice(), _majorTrace, _minorTrace, _findLNode (asr/decoder/decoder.h:805-953) over the 'worse' chains of
+ * _placeOnList (:531-541), for utterance u of the last decode of a decoder created with cfg.latticeTokens > 0 (DSR_E_CONSISTENCY otherwise: the
+ * reference's "Must enable lattice generation during decoding.").  eosX: output-lexicon index of eosSymbol (decoder.h:740-745), used when no token
+ * reached a final state (:843-851).  Nodes are numbered as the reference numbers them (0 = the initial node, then creation order); edges come in
+ * creation order: from, to, input, output, first and last frame, acoustic score and LM score with the penalties and the LM scale taken out
+ * (:921-923).  The lattice object is host memory, independent of the decoder afterwards. */
+typedef struct dsr_lattice dsr_lattice;
+dsr_status dsr_decoder_lattice(dsr_decoder*, int u, uint32_t eosX, dsr_lattice** out);
+void       dsr_lattice_destroy(dsr_lattice*);
+int        dsr_lattice_num_nodes(const dsr_lattice*);
+int        dsr_lattice_num_edges(const dsr_lattice*);
+int        dsr_lattice_final_states_n(const dsr_lattice*);      /* finalStatesN() (decoder.h:598-608) */
+dsr_status dsr_lattice_get(const dsr_lattice*, int32_t* nodeFinal, int32_t* from, int32_t* to, uint32_t* in, uint32_t* out, int32_t* start,
+                           int32_t* end, double* ac, double* lm);   /* any pointer may be NULL */
+/* Lattice::write(fileName, useSymbols = false, writeData) (asr/lattice/lattice.cc:715-757); a cyclic lattice is DSR_E_CONSISTENCY (:862-864) */
+dsr_status dsr_lattice_write(const dsr_lattice*, const char* fileName, int writeData);
+/* flat image of a lattice for the gather across ranks (north star: "gather decoded lattices/1-best") */
+size_t     dsr_lattice_pack_size(const dsr_lattice*);
+dsr_status dsr_lattice_pack(const dsr_lattice*, void* buf, size_t bufBytes);
+dsr_status dsr_lattice_unpack(const void* buf, size_t bytes, dsr_lattice** out);
+
 /* debug/parity: per-frame token list (list order) of utterance 0 of the last decode with
    cfg.streams == 1 and dumpFrames enabled through dsr_decoder_enable_dump(). */
 dsr_status dsr_decoder_enable_dump(dsr_decoder*, int enable);

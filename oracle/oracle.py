@@ -79,7 +79,14 @@ class DecResult(C.Structure):
                 ("topScore", C.POINTER(c_dbl)), ("dumpOff", C.POINTER(C.c_long)),
                 ("dumpNode", C.POINTER(c_int)), ("dumpAc", C.POINTER(c_flt)),
                 ("dumpLm", C.POINTER(c_flt)), ("dumpArc", C.POINTER(c_int)),
-                ("dumpN", C.c_long), ("dumpCap", C.c_long)]
+                ("dumpN", C.c_long), ("dumpCap", C.c_long), ("finalStatesN", c_int)]
+
+
+class Lattice(C.Structure):
+    _fields_ = [("nNodes", c_int), ("capNodes", c_int), ("nodeFinal", C.POINTER(c_int)), ("nodeFirstEdge", C.POINTER(c_int)),
+                ("nEdges", c_int), ("capEdges", c_int), ("from_", C.POINTER(c_int)), ("to", C.POINTER(c_int)), ("in_", C.POINTER(C.c_uint)),
+                ("out", C.POINTER(C.c_uint)), ("start", C.POINTER(c_int)), ("end", C.POINTER(c_int)), ("ac", C.POINTER(c_dbl)),
+                ("lm", C.POINTER(c_dbl)), ("nextEdge", C.POINTER(c_int))]
 
 
 def _bind(L):
@@ -570,18 +577,37 @@ class Wfst:
             d[k] = d[k][:a]
         return d
 
-    def decode(self, scores, beam=100.0, lmScale=12.0, lmPenalty=0.0, silPenalty=0.0, silenceX=0xFFFFFFFF, dump=False):
+    def decode(self, scores, beam=100.0, lmScale=12.0, lmPenalty=0.0, silPenalty=0.0, silenceX=0xFFFFFFFF, dump=False, lattice=False, eosX=0,
+               latticeFile=None, writeData=True):
+        """lattice=True: also _Decoder::lattice() (decoder.h:805-953) -> out["lattice"] = dict(nodeFinal, from, to, in, out, start, end, ac, lm), edges
+        in creation order; latticeFile: Lattice::write(file, useSymbols=False, writeData) (lattice.cc:715-757)"""
         sc = _f32(scores); T, nDist = sc.shape
         cfg = DecCfg(beam, lmScale, lmPenalty, silPenalty, silenceX, int(dump))
-        res = DecResult()
-        rc = lib().orc_decode(self.h, C.byref(cfg), _p(sc), T, nDist, C.byref(res))
+        res = DecResult(); lat = Lattice()
+        L = lib(); L.orc_decode_lat.argtypes = [c_vp, C.POINTER(DecCfg), c_vp, c_int, c_int, C.POINTER(DecResult), C.POINTER(Lattice), C.c_uint]
+        rc = L.orc_decode_lat(self.h, C.byref(cfg), _p(sc), T, nDist, C.byref(res), C.byref(lat) if lattice else None, int(eosX))
         if rc != 0:
             return dict(rc=rc)
+        latd = None
+        if lattice:
+            n, e = lat.nNodes, lat.nEdges
+            g = lambda ptr, dt, k: np.array(ptr[:k], dt) if k > 0 else np.zeros(0, dt)
+            latd = {"nodeFinal": g(lat.nodeFinal, np.int32, n), "from": g(lat.from_, np.int32, e), "to": g(lat.to, np.int32, e), "in": g(lat.in_, np.uint32, e),
+                    "out": g(lat.out, np.uint32, e), "start": g(lat.start, np.int32, e), "end": g(lat.end, np.int32, e), "ac": g(lat.ac, np.float64, e),
+                    "lm": g(lat.lm, np.float64, e)}
+            if latticeFile is not None:
+                L.orc_lattice_write.argtypes = [C.POINTER(Lattice), C.c_char_p, c_int]
+                rcw = L.orc_lattice_write(C.byref(lat), latticeFile.encode(), int(writeData))
+                if rcw != 0:
+                    raise ValueError("lattice write failed (%d)" % rcw)
+            L.orc_lattice_free.argtypes = [C.POINTER(Lattice)]; L.orc_lattice_free(C.byref(lat))
         out = dict(rc=0, score=res.score, ac=res.ac, lm=res.lm, frames=res.frames, reachedFinal=bool(res.reachedFinal),
                    arcs=np.array(res.arcs[:res.nArcs], np.int32), arcFrames=np.array(res.arcFrames[:res.nArcs], np.int32),
                    words=np.array(res.words[:res.nWords], np.uint32), activeHypos=res.activeHypos,
                    activeCount=np.array(res.activeCount[:res.nActive], np.int32),
-                   topScore=np.array(res.topScore[:res.nActive], np.float64))
+                   topScore=np.array(res.topScore[:res.nActive], np.float64), finalStatesN=res.finalStatesN)
+        if latd is not None:
+            out["lattice"] = latd
         if dump:
             n = res.nActive
             off = np.array(res.dumpOff[: n + 1], np.int64)

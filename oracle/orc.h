@@ -181,7 +181,17 @@ typedef struct {
   double* topScore; /* per frame */
   /* optional per-frame dump of _next in list order (front first) */
   long* dumpOff; int* dumpNode; float* dumpAc; float* dumpLm; int* dumpArc; long dumpN, dumpCap;
+  int finalStatesN;  /* decoder.h:598-608 */
 } orc_dec_result;
+/* _Decoder::lattice() (decoder.h:805-953): nodes are numbered in creation order (0 = the initial node), nodeFinal[i] 1 final / 0 not / -1 unused
+   index; edges in creation order with per-node lists in the reference's iteration order (last added first) */
+typedef struct {
+  int nNodes, capNodes; int* nodeFinal; int* nodeFirstEdge;
+  int nEdges, capEdges; int* from; int* to; unsigned* in; unsigned* out; int* start; int* end; double* ac; double* lm; int* nextEdge;
+} orc_lattice;
+int  orc_decode_lat(const orc_wfst* g, const orc_dec_cfg* cfg, const float* scores, int T, int nDist, orc_dec_result* res, orc_lattice* lat, unsigned eosX);
+int  orc_lattice_write(const orc_lattice* L, const char* file, int writeData);   /* Lattice::write(file, false, writeData) (lattice.cc:715-757) */
+void orc_lattice_free(orc_lattice* L);
 /* scores: [T][nDist] (cost of distribution d at frame t) */
 int  orc_decode(const orc_wfst* g, const orc_dec_cfg* cfg, const float* scores, int T, int nDist,
                 orc_dec_result* res);

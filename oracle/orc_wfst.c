@@ -13,6 +13,11 @@
  *   asr/decoder/decoder.h:639-737          _bestToken, decode
  *   asr/decoder/decoder.h:748-773          bestHypo
  *   asr/decoder/decoder.h:956-1015         _expandNode, _expandNodeToEnd
+ *   asr/decoder/decoder.h:517-545          _placeOnList incl. the lattice 'worse' chains (built always: decoder.h:1113-1114,1133-1135)
+ *   asr/decoder/decoder.h:598-608,805-953  finalStatesN, lattice, _majorTrace, _minorTrace, _findLNode
+ *   asr/lattice/lattice.cc:64-69,715-757,858-887  Lattice ctor (initial node 0), write, _topoSort/_visitNode
+ *   asr/fsm/fsm.cc:122-138,153-178,541-545,1171-1178,553-559  _addFinal, _find, _addEdgeForce (prepend), Edge::write, Node::write
+ *   asr/lattice/lattice.h:151-154          LatticeEdgeData::write
  * Token scores are stored as float and compared as the reference does (double candidate
  * against the incumbent's float sum).  Compile with -ffp-contract=off.
  */
@@ -191,7 +196,7 @@ void orc_wfst_export(const orc_wfst* g, unsigned* nodeState, int* nodeFinal, flo
 }
 
 /* ------------------------------ decoder ------------------------------ */
-typedef struct { float ac, lm; int frame; int arc; int prev; } tok_t;       /* lattice.h:73-78 */
+typedef struct { float ac, lm; int frame; int arc; int prev; int worse; } tok_t;       /* lattice.h:73-78 */
 typedef struct { int tok; int state; int next; } holder_t;                    /* decoder.h:58-76 */
 typedef struct {
   holder_t* h; int nH, capH; int head; int* ofState; int* stamp; int gen; int active;
@@ -215,21 +220,28 @@ static void tl_insert(tlist_t* l, int node, int tok)
 static int new_tok(dec_t* d, double ac, double lm, int frame, int arc, int prev)
 {
   if (d->nTok == d->capTok) { d->capTok = d->capTok ? 2 * d->capTok : (1 << 16); d->tok = (tok_t*) realloc(d->tok, sizeof(tok_t) * (size_t) d->capTok); }
-  tok_t* t = &d->tok[d->nTok]; t->ac = (float) ac; t->lm = (float) lm; t->frame = frame; t->arc = arc; t->prev = prev;
+  tok_t* t = &d->tok[d->nTok]; t->ac = (float) ac; t->lm = (float) lm; t->frame = frame; t->arc = arc; t->prev = prev; t->worse = -1;
   return d->nTok++;
 }
 static inline float tok_score(const tok_t* t) { return t->ac + t->lm; }       /* float sum, lattice.h:53 */
 
 static void place_on_list(dec_t* d, int arc, double acScore, double lmScore, int thisToken)
 {
-  /* decoder.h:517-545 (lattice 'worse' chains do not influence the 1-best and are omitted) */
+  /* decoder.h:517-545.  The 'worse' chains of lattice generation: a better arrival takes the place on the list and hangs the
+     incumbent (with its own chain) behind itself; a worse one is hung directly behind the incumbent, in front of its chain. */
   double ttlScore = acScore + lmScore;
   const arc_t* e = &d->g->arcs[arc];
   if (ttlScore < d->topScore && e->in != 0) d->topScore = ttlScore;
   int h = tl_find(d->nxt, e->dst);
   if (h >= 0) {
-    const tok_t* nt = &d->tok[d->nxt->h[h].tok];
-    if (ttlScore < tok_score(nt)) d->nxt->h[h].tok = new_tok(d, acScore, lmScore, d->frameX, arc, thisToken);
+    const int inc = d->nxt->h[h].tok;
+    if (ttlScore < tok_score(&d->tok[inc])) {
+      const int nt = new_tok(d, acScore, lmScore, d->frameX, arc, thisToken);
+      d->tok[nt].worse = inc; d->nxt->h[h].tok = nt;
+    } else {
+      const int wt = new_tok(d, acScore, lmScore, d->frameX, arc, thisToken);
+      d->tok[wt].worse = d->tok[inc].worse; d->tok[inc].worse = wt;
+    }
   } else tl_insert(d->nxt, e->dst, new_tok(d, acScore, lmScore, d->frameX, arc, thisToken));
 }
 
@@ -308,7 +320,134 @@ static void dump_list(orc_dec_result* res, const dec_t* d, const int* csrOf, int
   res->dumpOff[frame + 1] = res->dumpN;
 }
 
+/* ------------------------------ lattice (decoder.h:805-953) ------------------------------ */
+typedef struct { long long key; int node; } lnode_t;            /* (state index, frame) -> lattice node index */
+typedef struct {
+  const dec_t* d; orc_lattice* L;
+  lnode_t* map; int nMap, capMap;
+  int lnStateIndices;
+} lat_t;
+static void lat_add_node(orc_lattice* L, int idx, int final)
+{
+  if (idx >= L->capNodes) { int nc = L->capNodes ? L->capNodes : 64; while (nc <= idx) nc *= 2; L->nodeFinal = (int*) realloc(L->nodeFinal, sizeof(int) * (size_t) nc); L->nodeFirstEdge = (int*) realloc(L->nodeFirstEdge, sizeof(int) * (size_t) nc);
+    for (int i = L->capNodes; i < nc; i++) { L->nodeFinal[i] = -1; L->nodeFirstEdge[i] = -1; } L->capNodes = nc; }
+  if (idx >= L->nNodes) L->nNodes = idx + 1;
+  L->nodeFinal[idx] = final;
+}
+static int lat_map_find(lat_t* t, long long key) { for (int i = t->nMap - 1; i >= 0; i--) if (t->map[i].key == key) return t->map[i].node; return -1; }
+static void lat_map_put(lat_t* t, long long key, int node)
+{ if (t->nMap == t->capMap) { t->capMap = t->capMap ? 2 * t->capMap : 256; t->map = (lnode_t*) realloc(t->map, sizeof(lnode_t) * (size_t) t->capMap); } t->map[t->nMap].key = key; t->map[t->nMap].node = node; t->nMap++; }
+static long long lkey(unsigned state, int frame) { return ((long long) state << 32) | (unsigned) frame; }
+static void lat_add_edge(orc_lattice* L, int from, int to, unsigned in, unsigned out, int start, int end, double ac, double lm)
+{
+  if (L->nEdges == L->capEdges) {
+    L->capEdges = L->capEdges ? 2 * L->capEdges : 256; size_t n = (size_t) L->capEdges;
+    L->from = (int*) realloc(L->from, sizeof(int) * n); L->to = (int*) realloc(L->to, sizeof(int) * n); L->in = (unsigned*) realloc(L->in, sizeof(unsigned) * n);
+    L->out = (unsigned*) realloc(L->out, sizeof(unsigned) * n); L->start = (int*) realloc(L->start, sizeof(int) * n); L->end = (int*) realloc(L->end, sizeof(int) * n);
+    L->ac = (double*) realloc(L->ac, sizeof(double) * n); L->lm = (double*) realloc(L->lm, sizeof(double) * n); L->nextEdge = (int*) realloc(L->nextEdge, sizeof(int) * n);
+  }
+  const int e = L->nEdges++;
+  L->from[e] = from; L->to[e] = to; L->in[e] = in; L->out[e] = out; L->start[e] = start; L->end[e] = end; L->ac[e] = ac; L->lm[e] = lm;
+  L->nextEdge[e] = L->nodeFirstEdge[from]; L->nodeFirstEdge[from] = e;          /* addEdgeForce: prepend (fsm.cc:541-545) */
+}
+static void major_trace(lat_t* t, int start, long long prev);
+static void minor_trace(lat_t* t, int endTok, long long prev)
+{
+  /* decoder.h:873-931 */
+  const dec_t* d = t->d; const orc_wfst* g = d->g;
+  int tok = endTok; const int endFrame = d->tok[endTok].frame;
+  unsigned currentInput = g->arcs[d->tok[tok].arc].in, currentOutput = g->arcs[d->tok[tok].arc].out;
+  while (d->tok[tok].prev >= 0) {
+    const arc_t* pe = &g->arcs[d->tok[d->tok[tok].prev].arc];
+    if (pe->out != 0 && currentOutput != 0) break;
+    if (pe->in != 0) { if (currentInput != 0 && pe->in != currentInput) break; currentInput = pe->in; }
+    if (pe->out != 0) { if (currentOutput != 0) break; currentOutput = pe->out; }
+    tok = d->tok[tok].prev;
+  }
+  const int begFrame = d->tok[tok].frame; const int prevTok = d->tok[tok].prev;
+  const int endNode = lat_map_find(t, prev);                   /* _findLNode(lattice, prev): exists by construction */
+  long long lnode = 0; int begNode; int create = 1;
+  double acScore = d->tok[endTok].ac, lmScore = d->tok[endTok].lm;
+  if (prevTok < 0) begNode = 0;                               /* lattice->initial() */
+  else {
+    acScore -= d->tok[prevTok].ac; lmScore -= d->tok[prevTok].lm;
+    lnode = lkey(g->nodes[g->arcs[d->tok[tok].arc].src].state, begFrame);
+    begNode = lat_map_find(t, lnode);
+    if (begNode >= 0) create = 0;
+    else { begNode = ++t->lnStateIndices; lat_add_node(t->L, begNode, 0); lat_map_put(t, lnode, begNode); }
+  }
+  if (currentInput == d->cfg->silenceX) lmScore -= (d->cfg->lmScale * d->cfg->silPenalty);
+  if (currentOutput != 0) lmScore -= (d->cfg->lmScale * d->cfg->lmPenalty);
+  lmScore /= d->cfg->lmScale;
+  lat_add_edge(t->L, begNode, endNode, currentInput, currentOutput, begFrame, endFrame, acScore, lmScore);
+  if (prevTok >= 0 && create) major_trace(t, prevTok, lnode);
+}
+static void major_trace(lat_t* t, int start, long long prev)
+{ for (int tok = start; tok >= 0; tok = t->d->tok[tok].worse) minor_trace(t, tok, prev); }
+
+static void build_lattice(const dec_t* d, orc_lattice* L, unsigned eosX)
+{
+  lat_t t; memset(&t, 0, sizeof(t)); t.d = d; t.L = L;
+  const orc_wfst* g = d->g;
+  lat_add_node(L, 0, 0);                                       /* Lattice ctor: _initial = _newNode(0) (lattice.cc:64-69) */
+  int nFinal = 0;
+  for (int h = d->nxt->head; h >= 0; h = d->nxt->h[h].next) if (g->nodes[g->arcs[d->tok[d->nxt->h[h].tok].arc].dst].final) nFinal++;
+  if (nFinal > 0) {
+    for (int h = d->nxt->head; h >= 0; h = d->nxt->h[h].next) {
+      const int tk = d->nxt->h[h].tok; const int nd = g->arcs[d->tok[tk].arc].dst;
+      if (!g->nodes[nd].final) continue;
+      const long long init = lkey(g->nodes[nd].state, d->frameX + 1);
+      const int ln = ++t.lnStateIndices; lat_add_node(L, ln, 1); lat_map_put(&t, init, ln);
+      major_trace(&t, tk, init);
+    }
+  } else {
+    int reached = 0; const int best = best_token(d, &reached);
+    if (best >= 0) {
+      const long long init = lkey(g->nodes[g->arcs[d->tok[best].arc].dst].state, d->frameX + 1);
+      const int ln = ++t.lnStateIndices; lat_add_node(L, ln, 0); lat_map_put(&t, init, ln);
+      const int en = ++t.lnStateIndices; lat_add_node(L, en, 1);
+      lat_add_edge(L, ln, en, 0, eosX, d->frameX + 1, d->frameX + 1, 0.0, 0.0);
+      major_trace(&t, best, init);
+    }
+  }
+  free(t.map);
+}
+void orc_lattice_free(orc_lattice* L)
+{ if (!L) return; free(L->nodeFinal); free(L->nodeFirstEdge); free(L->from); free(L->to); free(L->in); free(L->out); free(L->start); free(L->end); free(L->ac); free(L->lm); free(L->nextEdge); memset(L, 0, sizeof(*L)); }
+
+/* Lattice::write(fileName, useSymbols = false, writeData) (lattice.cc:715-757): depth-first topological order from the initial node
+   (finished nodes go to the front of the list), edges of the non-final nodes, then per final node (index order) its edges and its node line */
+static void lat_visit(const orc_lattice* L, int node, int* color, int* order, int* nOrder, int* err)
+{
+  if (color[node] == 2) return;
+  if (color[node] == 1) { *err = 1; return; }                  /* "graph is not acyclic" */
+  color[node] = 1;
+  for (int e = L->nodeFirstEdge[node]; e >= 0 && !*err; e = L->nextEdge[e]) lat_visit(L, L->to[e], color, order, nOrder, err);
+  color[node] = 2; order[(*nOrder)++] = node;                  /* reversed below = push_front */
+}
+static void lat_write_edge(FILE* fp, const orc_lattice* L, int e, int writeData)
+{
+  fprintf(fp, "%10d  %10d  %10d  %10d", L->from[e], L->to[e], (int) L->in[e], (int) L->out[e]);
+  fprintf(fp, "\n");                                           /* edge cost is ZeroWeight */
+  if (writeData) fprintf(fp, "%4d  %4d  %8.4f  %8.4f  %8.4f\n", L->start[e], L->end[e], L->ac[e], L->lm[e], 0.0);
+}
+int orc_lattice_write(const orc_lattice* L, const char* file, int writeData)
+{
+  FILE* fp = fopen(file, "w"); if (!fp) return -7;
+  int* color = (int*) calloc((size_t) L->nNodes + 1, sizeof(int)); int* order = (int*) malloc(sizeof(int) * ((size_t) L->nNodes + 1)); int nOrder = 0, err = 0;
+  lat_visit(L, 0, color, order, &nOrder, &err);
+  if (!err) {
+    for (int i = nOrder - 1; i >= 0; i--) { const int nd = order[i]; if (L->nodeFinal[nd] == 1) continue; for (int e = L->nodeFirstEdge[nd]; e >= 0; e = L->nextEdge[e]) lat_write_edge(fp, L, e, writeData); }
+    for (int nd = 0; nd < L->nNodes; nd++) if (L->nodeFinal[nd] == 1) { for (int e = L->nodeFirstEdge[nd]; e >= 0; e = L->nextEdge[e]) lat_write_edge(fp, L, e, writeData); fprintf(fp, "%10d\n", nd); }
+  }
+  free(color); free(order); fclose(fp);
+  return err ? -3 : 0;
+}
+
+int orc_decode_lat(const orc_wfst* g, const orc_dec_cfg* cfg, const float* scores, int T, int nDist, orc_dec_result* res, orc_lattice* lat, unsigned eosX);
 int orc_decode(const orc_wfst* g, const orc_dec_cfg* cfg, const float* scores, int T, int nDist, orc_dec_result* res)
+{ return orc_decode_lat(g, cfg, scores, T, nDist, res, NULL, 0); }
+int orc_decode_lat(const orc_wfst* g, const orc_dec_cfg* cfg, const float* scores, int T, int nDist, orc_dec_result* res, orc_lattice* lat, unsigned eosX)
 {
   memset(res, 0, sizeof(*res));
   if (g->initial < 0) return -3;
@@ -378,6 +517,9 @@ int orc_decode(const orc_wfst* g, const orc_dec_cfg* cfg, const float* scores, i
       for (k = 0; k < n; k++) if (tmpw[k] != 0) res->words[res->nWords++] = tmpw[k];
       free(tmpw); }
   }
+  res->finalStatesN = 0;
+  for (int h = d.nxt->head; h >= 0; h = d.nxt->h[h].next) if (g->nodes[g->arcs[d.tok[d.nxt->h[h].tok].arc].dst].final) res->finalStatesN++;
+  if (lat) { memset(lat, 0, sizeof(*lat)); build_lattice(&d, lat, eosX); }
   tl_free(&A); tl_free(&B); free(d.tok); free(arcOff); free(csrOf);
   return 0;
 }

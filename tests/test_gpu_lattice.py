@@ -1,0 +1,128 @@
+"""Lattice generation and its gather (row f2) against the oracle's restatement of _Decoder::lattice / _majorTrace /
+_minorTrace (asr/decoder/decoder.h:805-953) over the 'worse' chains of _placeOnList (:531-541): node numbering, edge list (creation order),
+frames, ac/lm doubles -- all bit for bit -- and the bytes of Lattice::write (asr/lattice/lattice.cc:715-757)."""
+import numpy as np
+import pytest
+
+from tests import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _graphs(dsr, oracle, arcs, fin):
+    go, gd = oracle.Wfst(), dsr.Wfst()
+    for a in arcs:
+        go.add_arc(*a); gd.add_arc(*a)
+    for s, c in fin:
+        go.add_final(s, c); gd.add_final(s, c)
+    return go, gd
+
+
+def _same_lattice(Lo, Ld):
+    for k in ("nodeFinal", "from", "to", "in", "out", "start", "end"):
+        assert np.array_equal(Lo[k], Ld[k]), k
+    for k in ("ac", "lm"):
+        assert np.array_equal(Lo[k].view(np.int64), Ld[k].view(np.int64)), k         # doubles, bit for bit
+
+
+@pytest.mark.parametrize("seed,S,nDist,T,beam,kw", [
+    (1, 300, 16, 40, 1e9, dict()),
+    (2, 1000, 64, 80, 30.0, dict()),
+    (3, 2000, 128, 60, 12.0, dict(lmPenalty=0.7)),
+    (4, 2000, 128, 60, 8.0, dict(silPenalty=1.5, silenceX=3)),
+    (5, 500, 32, 40, 50.0, dict(ties=True)),
+    (6, 300, 8, 40, 25.0, dict(eps_frac=0.35, out_frac=0.3)),
+    (7, 400, 16, 30, 40.0, dict(nFinal=0)),
+    (8, 300, 8, 30, 30.0, dict(eps_frac=0.2, silPenalty=0.9, silenceX=0, lmPenalty=0.3)),     # the silence symbol on the epsilon arcs (decoder.h:975-977)
+])
+def test_lattice_matches_oracle(dsr, oracle, cuda, tmp_path, seed, S, nDist, T, beam, kw):
+    import torch
+    gkw = {k: kw[k] for k in ("ties", "eps_frac", "nFinal", "out_frac") if k in kw}
+    dkw = {k: kw[k] for k in ("lmPenalty", "silPenalty", "silenceX") if k in kw}
+    arcs, fin = synth.random_wfst(S, nDist, seed=seed, nWords=200, **gkw)
+    go, gd = _graphs(dsr, oracle, arcs, fin)
+    rng = np.random.default_rng(200 + seed)
+    sc = rng.uniform(0, 10, (3, T, nDist)).astype(np.float32)
+    if kw.get("ties"):
+        sc = np.round(sc)
+    nfr = [T, T - 7, 2]
+    dec = dsr.Decoder(beam=beam, lmScale=12.0, maxActive=8192, streams=2, latticeTokens=400000, **dkw)
+    dec.set(gd)
+    out = dec.decode_batch(torch.from_numpy(sc).to(cuda), torch.tensor(nfr, dtype=torch.int32, device=cuda))
+    plain = dsr.Decoder(beam=beam, lmScale=12.0, maxActive=8192, streams=2, **dkw); plain.set(gd)
+    out0 = plain.decode_batch(torch.from_numpy(sc).to(cuda), torch.tensor(nfr, dtype=torch.int32, device=cuda))
+    with pytest.raises(dsr.DsrError) as e:
+        plain.lattice(0)
+    assert e.value.status == 4                                            # jconsistency_error "Must enable lattice generation during decoding."
+    for u in range(3):
+        assert out[u]["status"] == 0 and out[u]["score"] == out0[u]["score"] and np.array_equal(out[u]["arcs"], out0[u]["arcs"])     # the bookkeeping does not move the 1-best
+        fo = str(tmp_path / ("o%d.lat" % u))
+        try:
+            ro = go.decode(sc[u, :nfr[u]], beam=beam, lmScale=12.0, lattice=True, eosX=7, latticeFile=fo, writeData=True, **dkw); cyclic = False
+        except ValueError:
+            ro = go.decode(sc[u, :nfr[u]], beam=beam, lmScale=12.0, lattice=True, eosX=7, **dkw); cyclic = True
+        assert ro["rc"] == 0 and ro["score"] == out[u]["score"]
+        L = dec.lattice(u, eosX=7)
+        assert L.finalStatesN == ro["finalStatesN"]
+        _same_lattice(ro["lattice"], L.data)
+        assert len(L.data["from"]) >= nfr[u] - 1
+        fd = str(tmp_path / ("d%d.lat" % u))
+        if cyclic:                                                        # (a self loop taken in the last frame + an epsilon arc into a final state:
+            with pytest.raises(dsr.DsrError) as e2:                       #  the reference's (state, frame) keys collide and its _topoSort throws)
+                L.write(fd, writeData=True)
+            assert e2.value.status == 4
+        else:
+            L.write(fd, writeData=True)
+            assert open(fd, "rb").read() == open(fo, "rb").read()         # Lattice::write, byte for byte
+        # the flat image used by the gather
+        L2 = dsr.Lattice.unpack(L.pack())
+        _same_lattice(L.data, L2.data)
+
+
+def test_lattice_epsilon_free_contains_the_best_path(dsr, oracle, cuda):
+    """without epsilon arcs the lattice is exact: its best path has the decode score (property, no oracle needed)"""
+    import torch
+    arcs, fin = synth.random_wfst(800, 32, seed=31, eps_frac=0.0, out_frac=0.2, nWords=100)
+    gd = dsr.Wfst()
+    for a in arcs:
+        gd.add_arc(*a)
+    for s, c in fin:
+        gd.add_final(s, c)
+    rng = np.random.default_rng(31)
+    T, lmS, pen = 50, 3.0, 0.4
+    sc = rng.uniform(0, 10, (2, T, 32)).astype(np.float32)
+    dec = dsr.Decoder(beam=25.0, lmScale=lmS, lmPenalty=pen, maxActive=8192, streams=2, latticeTokens=600000); dec.set(gd)
+    out = dec.decode_batch(torch.from_numpy(sc).to(cuda))
+    for u in range(2):
+        L = dec.lattice(u).data
+        n = len(L["nodeFinal"]); best = np.full(n, np.inf); best[0] = 0.0
+        order = np.argsort(L["start"], kind="stable")
+        w = L["ac"] + lmS * (L["lm"] + np.where(L["out"] != 0, pen, 0.0))
+        for _ in range(T + 2):
+            ch = False
+            for e in order:
+                v = best[L["from"][e]] + w[e]
+                if v < best[L["to"][e]] - 1e-12:
+                    best[L["to"][e]] = v; ch = True
+            if not ch:
+                break
+        fb = min(best[i] for i in range(n) if L["nodeFinal"][i] == 1)
+        assert abs(fb - out[u]["score"]) <= 1e-4 * abs(out[u]["score"])
+
+
+def test_lattice_capacity_and_errors(dsr, cuda):
+    import torch
+    arcs, fin = synth.random_wfst(300, 16, seed=3)
+    gd = dsr.Wfst()
+    for a in arcs:
+        gd.add_arc(*a)
+    for s, c in fin:
+        gd.add_final(s, c)
+    sc = np.random.default_rng(0).uniform(0, 10, (1, 30, 16)).astype(np.float32)
+    dec = dsr.Decoder(beam=1e9, lmScale=12.0, maxActive=8192, streams=1, latticeTokens=500); dec.set(gd)     # too small on purpose
+    out = dec.decode_batch(torch.from_numpy(sc).to(cuda))
+    assert out[0]["status"] == 2                                          # JALLOCATION: the placement log is full -- reported, never silent
+    with pytest.raises(dsr.DsrError):
+        dec.lattice(0)
+    with pytest.raises(dsr.DsrError):
+        dec.lattice(5)
