@@ -281,6 +281,17 @@ dsr_status dsr_gmm_save(const dsr_gmm* m, const char* cbFile, const char* dsFile
 void dsr_gmm_destroy(dsr_gmm* m) { delete m; }
 int dsr_gmm_num_dists(const dsr_gmm* m) { return m->K; }
 int dsr_gmm_dim(const dsr_gmm* m) { return m->D; }
+// DistribSet::find(name) / index(key) (asr/gaussian/distribBasic.h:183-190: List lookup, jkey_error when absent) and the names of the set
+const char* dsr_gmm_dist_name(const dsr_gmm* g, int distX) { return (g && distX >= 0 && distX < g->K) ? g->dsNames[distX].c_str() : ""; }
+const char* dsr_gmm_codebook_name(const dsr_gmm* g, int cbX) { return (g && cbX >= 0 && cbX < g->K) ? g->cbNames[cbX].c_str() : ""; }
+dsr_status dsr_gmm_find_dist(const dsr_gmm* g, const char* name, int* distX)
+{
+  return guard([&] {
+    if (!g || !name || !distX) throw Error(DSR_E_PARAMETER, "null argument");
+    for (int k = 0; k < g->K; k++) if (g->dsNames[k] == name) { *distX = k; return; }
+    throw Error(DSR_E_KEY, "Could not find key %s in list Distribution Set", name);
+  });
+}
 
 dsr_status dsr_gmm_score(dsr_gmm* m, const float* x, int64_t N, int mode, float* score, uint8_t* argmin, void* stream)
 {

@@ -25,6 +25,8 @@
 #include "common.h"
 #include "wfst_graph.h"
 #include "lattice.h"
+#include "lexicon.h"
+#include <algorithm>
 #include <cmath>
 #include <type_traits>
 
@@ -76,6 +78,8 @@ struct DecDev {
   // {ac, lm, record, parent back pointer} + its unrounded total (the reference's 'worse' chains are an order-dependent function of exactly
   // these; the host replays them, lattice.cpp) -- plus, per back-pointer record, the placement that won its state, and the final token list.
   int latOn; long latCap; uint4* lat; double* latTtl; long* latFrameOff; int* arenaLat; int4* latFinal; int* latInfo;
+  // topN > 0 (decoder.h:571-581): a frame expands the topN best tokens of the list in order of their scores and applies no beam; third token buffer
+  int topN; TokA* tokA3; TokB* tokB3;
 };
 
 __device__ __forceinline__ unsigned ld_u32(const unsigned* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
@@ -187,6 +191,7 @@ __global__ __launch_bounds__(kThreads) void k_viterbi(GraphDev G, DecDev Dd, con
     if (T <= 0) status = DSR_E_ITERATOR;         // no frame at all: the exception escapes decode() (decoder.h:691)
 
     TokA* curA = tokA0; TokA* nxtA = tokA1; TokB* curB = tokB0; TokB* nxtB = tokB1;
+    TokA* sprA = Dd.topN > 0 ? Dd.tokA3 + (size_t) slot * Dd.maxTok : nullptr; TokB* sprB = Dd.topN > 0 ? Dd.tokB3 + (size_t) slot * Dd.maxTok : nullptr;
     int n = 1; long arenaOff = 0; long activeHypos = 0; long placements = 0; int maxActive = 0; long regFrames = 0;
     double thresh = HUGE_VAL, topScore = HUGE_VAL;
     for (int i = tid; i < 2 * hashN; i += nthr) hkey[i] = (i < hashN) ? 0u : 0xFFFFFFFFu;
@@ -210,7 +215,7 @@ __global__ __launch_bounds__(kThreads) void k_viterbi(GraphDev G, DecDev Dd, con
       const float* rowG = sc + (size_t) fr * nDist;                            // the frame's score row in memory
       int numNew = 0, numStat = -1;                                           // tokens written to the new list / tokens the reference's list would hold
       if (Dd.prof && tid == 0) s_tlast = (long long) wall_clock64();
-      bool fast = fastOK && mode == 0 && n <= fastCapN && !Dd.latOn;          // lattice bookkeeping needs every placement in memory: the memory path has them
+      bool fast = fastOK && mode == 0 && n <= fastCapN && !Dd.latOn && Dd.topN <= 0;          // lattice bookkeeping needs every placement in memory: the memory path has them
 
       if (fast) {
         // ======================= register path =======================
@@ -639,6 +644,23 @@ __global__ __launch_bounds__(kThreads) void k_viterbi(GraphDev G, DecDev Dd, con
       unsigned* first = Dd.first + (size_t) slot * G.nNodes;
       if (tag <= 1u) { for (int i = tid; i < G.nNodes; i += nthr) first[i] = 0xFFFFFFFFu; tag = 255u; __syncthreads(); } else tag--;
       const unsigned tagw = tag << 24;
+      const bool sorted = Dd.topN > 0 && mode == 0 && fr > 0;
+      if (sorted) {
+        // SortedIterator (decoder.h:298-320): the list sorted by the tokens' float scores (ties: list order -- std::sort leaves them unspecified),
+        // of which _processFrame expands the first topN (:571-581).  Rank by counting: the lists of this mode are short (topN tokens' expansions).
+        unsigned long long* keys = reinterpret_cast<unsigned long long*>(cA);
+        for (int i = tid; i < n; i += nthr) { const TokA t = curA[i]; keys[i] = ((unsigned long long) f2ord(__fadd_rn(t.ac, t.lm)) << 32) | (unsigned) i; }
+        __syncthreads();
+        for (int i = tid; i < n; i += nthr) {
+          const unsigned long long ki = keys[i]; int rk = 0;
+          for (int j = 0; j < n; j++) rk += (keys[j] < ki) ? 1 : 0;
+          if (rk < Dd.topN) { sprA[rk] = curA[i]; sprB[rk] = curB[i]; }
+        }
+        __syncthreads();
+        { TokA* ta = curA; curA = sprA; sprA = ta; TokB* tb = curB; curB = sprB; sprB = tb; }
+        n = n < Dd.topN ? n : Dd.topN;
+      }
+      const double threshM = (Dd.topN > 0) ? HUGE_VAL : thresh;                // topN mode: no beam
       // ---------------- phase A: per-token placement counts, wave-local exclusive scan
       const int chunkT = ((n + nw * 64 - 1) / (nw * 64)) * 64;
       {
@@ -650,7 +672,7 @@ __global__ __launch_bounds__(kThreads) void k_viterbi(GraphDev G, DecDev Dd, con
             const TokA ta = curA[i]; const TokB tb = curB[i];
             if (mode == 0) {
               const float s = __fadd_rn(ta.ac, ta.lm);
-              if (!((double) s > thresh)) cnt = tb.cnt;                        // beam (decoder.h:586-588)
+              if (!((double) s > threshM)) cnt = tb.cnt;                       // beam (decoder.h:586-588)
             } else cnt = (G.nodeFinal[tb.node] ? 1 : 0) + (G.eoff[tb.node + 1] - G.eoff[tb.node]);
           }
           const int incl = wave_incl_scan(cnt, lane);
@@ -759,7 +781,7 @@ __global__ __launch_bounds__(kThreads) void k_viterbi(GraphDev G, DecDev Dd, con
       const int chunkC = ((C + nw * 64 - 1) / (nw * 64)) * 64;
       // (as on the register path: tokens above this frame's best emitting total + beam are counted but not written)
       const double threshNextM = __dadd_rn(topScore, Dd.beam);
-      const bool pruneM = !dump && mode == 0 && (fr + 1 < T);
+      const bool pruneM = !dump && mode == 0 && (fr + 1 < T) && Dd.topN <= 0;
       {
         int running = 0, runAll = 0;
         const int b0 = wave * chunkC, b1 = (b0 + chunkC < C) ? b0 + chunkC : C;
@@ -875,7 +897,7 @@ __global__ __launch_bounds__(kThreads) void k_viterbi(GraphDev G, DecDev Dd, con
         dsr_decode_result r; memset(&r, 0, sizeof(r));
         if (tid == 0) {
           unsigned long long k = ~0ull; for (int w = 0; w < nw; w++) if (s_waveKey[w] < k) k = s_waveKey[w];
-          r.frames = T - 1; r.reachedFinal = numNew > 0 ? 1 : 0; r.activeHypos = activeHypos; r.placements = placements; r.registerFrames = regFrames; r.maxActiveSeen = maxActive; r.status = DSR_OK;
+          r.frames = T - 1; r.reachedFinal = numNew > 0 ? 1 : 0; r.finalStatesN = numNew; /* every token of _next after _expandToEnd sits in a final state */ r.activeHypos = activeHypos; r.placements = placements; r.registerFrames = regFrames; r.maxActiveSeen = maxActive; r.status = DSR_OK;
           int nH = 0;
           if (k != ~0ull) {
             const TokA bt = lst[(unsigned) (k & 0xFFFFFFFFu)];
@@ -959,7 +981,11 @@ struct DecoderState {
   long arenaCap = 0; int initial = 0; int threads = kThreads; bool twoPerCu = false;
   // lattice bookkeeping of the last decode (cfg.latticeTokens > 0), per utterance
   DevBuf<uint4> d_lat; DevBuf<double> d_latTtl; DevBuf<long> d_latFrameOff; DevBuf<int> d_arenaLat; DevBuf<int4> d_latFinal; DevBuf<int> d_latInfo;
-  int latU = 0, latTmax = 0; long latArenaCap = 0; WfstGraph graphCopy;
+  int latU = 0, latTmax = 0; long latArenaCap = 0; WfstGraph graphCopy; DevBuf<TokA> d_tokA3; DevBuf<TokB> d_tokB3;
+  // symbol tables of the transducer set last (borrowed) and the resolved silSymbol / eosSymbol (decoder.h:740-745)
+  const dsr_lexicon* lexIn = nullptr; const dsr_lexicon* lexOut = nullptr; uint32_t eosX = 0;
+  // what the last collected decode left: per-utterance results and best paths (pinned staging memory), for bestHypo / bestPath / finalStatesN
+  int lastU = 0; size_t lastMaxPath = 0; bool lastPaths = false;
   PinBuf<dsr_decode_result> h_res; PinBuf<int> h_arcs; PinBuf<unsigned> h_words; hipEvent_t evDone = nullptr;
   int pendingU = 0; size_t pendingPath = 0; int pendingSlots = 0; long long* pendingProf = nullptr;
   // dump
@@ -970,7 +996,7 @@ struct DecoderState {
 }  // namespace dsr
 
 using namespace dsr;
-struct dsr_wfst : WfstGraph {};
+struct dsr_wfst : WfstGraph { dsr_lexicon* lexState = nullptr; dsr_lexicon* lexIn = nullptr; dsr_lexicon* lexOut = nullptr; };
 struct dsr_decoder : DecoderState {};
 
 extern "C" {
@@ -996,6 +1022,25 @@ dsr_status dsr_wfst_export(const dsr_wfst* g, uint32_t* nodeState, int32_t* node
     for (size_t a = 0; a < c.dst.size(); a++) { if (arcDst) arcDst[a] = c.dst[a]; if (arcIn) arcIn[a] = c.in[a]; if (arcOut) arcOut[a] = c.out[a]; if (arcCost) arcCost[a] = c.cost[a]; }
   });
 }
+
+// WFSTFlyWeight(statelex, inlex, outlex) (decoder.i:52-70): the lexica are borrowed (the reference holds reference-counted pointers); the text reader
+// looks non-numeric fields up in them (wfstFlyWeight.cc:311-347)
+dsr_status dsr_wfst_set_lexicons(dsr_wfst* g, dsr_lexicon* stateLex, dsr_lexicon* inputLex, dsr_lexicon* outputLex)
+{
+  return guard([&] {
+    if (!g) throw Error(DSR_E_PARAMETER, "null argument");
+    g->lexState = stateLex; g->lexIn = inputLex; g->lexOut = outputLex;
+    g->symbolOf = [g](int which, const char* t) -> uint32_t {
+      dsr_lexicon* l = which == 0 ? g->lexState : which == 1 ? g->lexIn : g->lexOut;
+      if (!l) throw Error(DSR_E_KEY, "field '%s' is not a number and the transducer has no %s lexicon", t, which == 0 ? "state" : which == 1 ? "input" : "output");
+      return l->index(t);
+    };
+  });
+}
+dsr_lexicon* dsr_wfst_state_lexicon(const dsr_wfst* g) { return g ? g->lexState : nullptr; }
+dsr_lexicon* dsr_wfst_input_lexicon(const dsr_wfst* g) { return g ? g->lexIn : nullptr; }
+dsr_lexicon* dsr_wfst_output_lexicon(const dsr_wfst* g) { return g ? g->lexOut : nullptr; }
+int dsr_wfst_has_final_state(const dsr_wfst* g) { if (!g) return 0; for (size_t i = 0; i < g->nodes.size(); i++) if (g->nodes[i].final_) return 1; return 0; }
 
 void dsr_decoder_default_cfg(dsr_decoder_cfg* c)
 { memset(c, 0, sizeof(*c)); c->beam = 100.0; c->lmScale = 12.0; c->lmPenalty = 0.0; c->silPenalty = 0.0; c->silenceX = 0xFFFFFFFFu; }
@@ -1061,6 +1106,89 @@ dsr_status dsr_decoder_set(dsr_decoder* d, const dsr_wfst* g)
     d->haveGraph = true; d->nSlots = 0;    // scratch is (re)allocated by the first decode
   });
 }
+// DecoderFlyWeight::set(wfst) = _Decoder::_set (decoder.h:740-745): the network and, through its lexica, the indices of silSymbol (input
+// lexicon) and eosSymbol (output lexicon); a missing symbol is the reference's jkey_error (mlist.h:109-114).  Symbols may be NULL when the
+// transducer carries no lexica (then cfg.silenceX stays as configured).
+dsr_status dsr_decoder_set_symbols(dsr_decoder* d, const dsr_wfst* g, const char* silSymbol, const char* eosSymbol)
+{
+  return guard([&] {
+    if (!d || !g) throw Error(DSR_E_PARAMETER, "null argument");
+    uint32_t silX = d->cfg.silenceX, eosX = 0;
+    if (silSymbol) { if (!g->lexIn) throw Error(DSR_E_KEY, "the transducer has no input lexicon to look '%s' up in", silSymbol); silX = g->lexIn->index(silSymbol); }
+    if (eosSymbol) { if (!g->lexOut) throw Error(DSR_E_KEY, "the transducer has no output lexicon to look '%s' up in", eosSymbol); eosX = g->lexOut->index(eosSymbol); }
+    const dsr_status s = dsr_decoder_set(d, g);
+    if (s != DSR_OK) throw Error(s, "%s", dsr_last_error());
+    d->cfg.silenceX = silX; d->eosX = eosX; d->lexIn = g->lexIn; d->lexOut = g->lexOut;
+  });
+}
+uint32_t dsr_decoder_eos_index(const dsr_decoder* d) { return d ? d->eosX : 0; }
+
+// Results of the last collected decode, utterance u.  bestHypo(useInputSymbols) (decoder.h:748-773): the output symbols != 0 along the best path, or
+// the input symbols != 0 with immediate repetitions dropped ("inX != 0 && inX != lastX", walking the path from its END, so a repetition is judged
+// against the symbol after it), each followed by a blank.  bestPath() (:775-797): the names of the distributions along the path = the input
+// symbols != 0, one per line.  Strings need the lexica (DSR_E_KEY without); the id variants do not.
+static void need_last(const dsr_decoder* d, int u, bool paths)
+{
+  if (!d) throw Error(DSR_E_PARAMETER, "null argument");
+  if (d->lastU <= 0) throw Error(DSR_E_CONSISTENCY, "no decode has been collected yet");
+  if (u < 0 || u >= d->lastU) throw Error(DSR_E_INDEX, "utterance %d of %d", u, d->lastU);
+  if (paths && !d->lastPaths) throw Error(DSR_E_CONSISTENCY, "the last decode was collected without its paths");
+  if (d->h_res.p[u].status != DSR_OK) throw Error(d->h_res.p[u].status, "utterance %d was not decoded (status %d)", u, d->h_res.p[u].status);
+}
+// ids: the path's symbol ids in time order (which: 0 outputs != 0; 1 inputs != 0 with repetitions dropped as bestHypo(true); 2 inputs != 0 as bestPath)
+static std::vector<uint32_t> path_ids(const dsr_decoder* d, int u, int which)
+{
+  need_last(d, u, true);
+  const dsr_decode_result& r = d->h_res.p[u];
+  const int n = r.nArcs < (int) d->lastMaxPath ? r.nArcs : (int) d->lastMaxPath;
+  const int* arcs = d->h_arcs.p + (size_t) u * d->lastMaxPath;
+  std::vector<uint32_t> ids;
+  if (which == 1) {                                              // from the end, as the reference walks prev(): keep inX when it differs from the LAST KEPT one
+    uint32_t lastX = 0;
+    for (int i = n - 1; i >= 0; i--) { const uint32_t inX = d->csr.in[arcs[i]]; if (inX != 0 && inX != lastX) { ids.push_back(inX); lastX = inX; } }
+    std::reverse(ids.begin(), ids.end());
+  } else for (int i = 0; i < n; i++) { const uint32_t v = which == 0 ? d->csr.out[arcs[i]] : d->csr.in[arcs[i]]; if (v != 0) ids.push_back(v); }
+  return ids;
+}
+dsr_status dsr_decoder_path_ids(const dsr_decoder* d, int u, int which, uint32_t* ids, int cap, int* n)
+{
+  return guard([&] {
+    if (!n || which < 0 || which > 2) throw Error(DSR_E_PARAMETER, "bad argument");
+    const std::vector<uint32_t> v = path_ids(d, u, which);
+    *n = (int) v.size();
+    if (ids) { if ((int) v.size() > cap) throw Error(DSR_E_DIMENSION, "buffer holds %d ids, the path has %zu", cap, v.size()); if (!v.empty()) memcpy(ids, v.data(), 4 * v.size()); }
+  });
+}
+static void put_string(const std::string& s, char* buf, size_t cap, size_t* need)
+{
+  if (need) *need = s.size() + 1;
+  if (buf) { if (s.size() + 1 > cap) throw Error(DSR_E_DIMENSION, "buffer holds %zu bytes, the string needs %zu", cap, s.size() + 1); memcpy(buf, s.c_str(), s.size() + 1); }
+}
+dsr_status dsr_decoder_best_hypo(const dsr_decoder* d, int u, int useInputSymbols, char* buf, size_t cap, size_t* need)
+{
+  return guard([&] {
+    const std::vector<uint32_t> v = path_ids(d, u, useInputSymbols ? 1 : 0);
+    const dsr_lexicon* lex = useInputSymbols ? d->lexIn : d->lexOut;
+    if (!lex) throw Error(DSR_E_KEY, "the transducer set on this decoder has no %s lexicon", useInputSymbols ? "input" : "output");
+    std::string s; for (size_t i = 0; i < v.size(); i++) { s += lex->symbol(v[i]); s += " "; }
+    put_string(s, buf, cap, need);
+  });
+}
+dsr_status dsr_decoder_best_path(const dsr_decoder* d, int u, char* buf, size_t cap, size_t* need, int* count)
+{
+  return guard([&] {
+    const std::vector<uint32_t> v = path_ids(d, u, 2);
+    if (!d->lexIn) throw Error(DSR_E_KEY, "the transducer set on this decoder has no input lexicon");
+    std::string s; for (size_t i = 0; i < v.size(); i++) { s += d->lexIn->symbol(v[i]); s += "\n"; }
+    if (count) *count = (int) v.size();
+    put_string(s, buf, cap, need);
+  });
+}
+dsr_status dsr_decoder_final_states_n(const dsr_decoder* d, int u, int* n)
+{ return guard([&] { if (!n) throw Error(DSR_E_PARAMETER, "null argument"); need_last(d, u, false); *n = d->h_res.p[u].finalStatesN; }); }
+dsr_status dsr_decoder_trace_back_succeeded(const dsr_decoder* d, int u, int* ok)
+{ return guard([&] { if (!ok) throw Error(DSR_E_PARAMETER, "null argument"); need_last(d, u, false); *ok = d->h_res.p[u].reachedFinal; }); }
+
 dsr_status dsr_decoder_set_beam(dsr_decoder* d, double beam) { return guard([&] { if (!d) throw Error(DSR_E_PARAMETER, "null argument"); d->cfg.beam = beam; }); }
 
 dsr_status dsr_decoder_enable_dump(dsr_decoder* d, int en) { return guard([&] { if (!d) throw Error(DSR_E_PARAMETER, "null argument"); d->dumpOn = en; }); }
@@ -1125,6 +1253,8 @@ dsr_status dsr_decoder_decode_launch(dsr_decoder* d, const float* score, const i
     if (getenv("DSR_VITERBI_PROF")) { d->d_prof.reserve((size_t) slots * 16); D.prof = d->d_prof.p; }
     D.dumpOn = d->dumpOn; D.dumpCap = d->dumpCap; D.dumpFrameOff = d->d_dumpFrameOff.p; D.dumpNode = d->d_dumpNode.p; D.dumpAc = d->d_dumpAc.p;
     D.dumpLm = d->d_dumpLm.p; D.dumpArc = d->d_dumpArc.p; D.dumpCount = d->d_dumpCount.p;
+    D.topN = d->cfg.topN > 0 ? d->cfg.topN : 0; D.tokA3 = nullptr; D.tokB3 = nullptr;
+    if (D.topN > 0) { d->d_tokA3.reserve((size_t) slots * d->cfg.maxActive); d->d_tokB3.reserve((size_t) slots * d->cfg.maxActive); D.tokA3 = d->d_tokA3.p; D.tokB3 = d->d_tokB3.p; }
     D.latOn = latOn ? 1 : 0; D.latCap = 0; D.lat = nullptr; D.latTtl = nullptr; D.latFrameOff = nullptr; D.arenaLat = nullptr; D.latFinal = nullptr; D.latInfo = nullptr;
     if (latOn) {
       const size_t cap = (size_t) d->cfg.latticeTokens;
@@ -1170,7 +1300,7 @@ dsr_status dsr_decoder_decode_collect(dsr_decoder* d, dsr_decode_result* res, in
     if (!d || !res) throw Error(DSR_E_PARAMETER, "null argument");
     if (d->pendingU <= 0) throw Error(DSR_E_CONSISTENCY, "no decode in flight");
     const int U = d->pendingU; const size_t nPath = d->pendingPath; const int slots = d->pendingSlots; long long* prof = d->pendingProf;
-    d->pendingU = 0;
+    d->pendingU = 0; d->lastU = U; d->lastPaths = nPath > 0; d->lastMaxPath = nPath > 0 ? nPath / (size_t) U : 0;
     DSR_HIP(hipEventSynchronize(d->evDone));
     memcpy(res, d->h_res.p, sizeof(dsr_decode_result) * U);
     if (arcs_out && nPath) memcpy(arcs_out, d->h_arcs.p, sizeof(int) * nPath);

@@ -14,7 +14,7 @@
 
 using namespace dsr;
 
-struct dsr_fb; struct dsr_bf; struct dsr_lpc; struct dsr_stft; struct dsr_prfb; struct dsr_zelinski;
+struct dsr_fb; struct dsr_bf; struct dsr_lpc; struct dsr_stft; struct dsr_prfb; struct dsr_zelinski; struct dsr_gmm; struct dsr_decoder;
 
 struct dsr_stream {
   int refs = 1; std::string name; int size_ = 0; int type = DSR_T_FLOAT; int frameX = -1; bool endOfSamples = false;
@@ -611,6 +611,68 @@ dsr_status dsr_linear_transform_set(dsr_stream* s, const float* matrix)
   return guard([&] {
     GemvOp* q = dynamic_cast<GemvOp*>(s); if (!q || !matrix) throw Error(DSR_E_PARAMETER, "not a linear transform");
     q->hA.assign(matrix, matrix + q->hA.size()); q->A.upload(q->hA); q->ready = false;
+  });
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// ASR side of the boundary: the distribution set as the decoder sees it.  The reference decoder asks _dist->find(distX-1)->score(_frameX)
+// (asr/decoder/decoder.h:985); Distrib::score -> CodebookBasic::score pulls frame frameX of the feature stream and caches the codebook's
+// score for that frame (asr/gaussian/distribBasic.h:48-50,110-114, codebookBasic.cc:431-465).  Here a distribution set is a GMM model bound to
+// a feature stream handle: score(distX, frameX) scores ALL distributions of that frame on the device at the first request and serves the rest
+// of the frame's requests from the host copy; decode_stream() keeps everything on the device (features -> scores -> token passing), no host
+// round trip.
+struct dsr_distribset { dsr_gmm* gmm = nullptr; dsr_stream* feat = nullptr; int mode = 0; int cachedFrame = -1; std::vector<float> row; DevBuf<float> d_row, d_scores; DevBuf<int> d_T; };
+
+dsr_status dsr_distribset_create(dsr_gmm* gmm, dsr_stream* feature, int gmmMode, dsr_distribset** out)
+{
+  return guard([&] {
+    if (!gmm || !feature || !out) throw Error(DSR_E_PARAMETER, "null argument");
+    if (feature->type != DSR_T_FLOAT) throw Error(DSR_E_TYPE, "the feature stream of a codebook set delivers float vectors");
+    if (feature->size_ != dsr_gmm_dim(gmm)) throw Error(DSR_E_DIMENSION, "Feature and codebook dimensions (%d vs. %d) do not match.", feature->size_, dsr_gmm_dim(gmm));
+    if (gmmMode < 0 || gmmMode > 2) throw Error(DSR_E_PARAMETER, "bad scoring mode %d", gmmMode);
+    dsr_distribset* d = new dsr_distribset(); d->gmm = gmm; d->feat = feature; d->mode = gmmMode; dsr_stream_retain(feature); *out = d;
+  });
+}
+void dsr_distribset_destroy(dsr_distribset* d) { if (d) { dsr_stream_release(d->feat); delete d; } }
+int dsr_distribset_ndists(const dsr_distribset* d) { return d ? dsr_gmm_num_dists(d->gmm) : 0; }
+dsr_status dsr_distribset_find(const dsr_distribset* d, const char* name, int* distX)
+{ if (!d) return guard([&] { throw Error(DSR_E_PARAMETER, "null argument"); }); return dsr_gmm_find_dist(d->gmm, name, distX); }
+const char* dsr_distribset_name(const dsr_distribset* d, int distX) { return d ? dsr_gmm_dist_name(d->gmm, distX) : ""; }
+dsr_status dsr_distribset_reset_cache(dsr_distribset* d) { return guard([&] { if (!d) throw Error(DSR_E_PARAMETER, "null argument"); d->cachedFrame = -1; }); }      // codebookBasic.cc:414-420
+dsr_status dsr_distribset_reset_feature(dsr_distribset* d) { return guard([&] { if (!d) throw Error(DSR_E_PARAMETER, "null argument"); d->feat->reset(); d->cachedFrame = -1; }); }
+dsr_status dsr_distribset_score(dsr_distribset* d, int distX, int frameX, float* score)
+{
+  return guard([&] {
+    if (!d || !score) throw Error(DSR_E_PARAMETER, "null argument");
+    const int K = dsr_gmm_num_dists(d->gmm);
+    if (distX < 0 || distX >= K) throw Error(DSR_E_INDEX, "distribution %d of %d", distX, K);
+    if (frameX != d->cachedFrame || frameX < 0) {
+      (void) d->feat->next(frameX);                                       // jiterator_error at the end of the stream, jindex_error out of order
+      const int t = d->feat->frameX;
+      d->d_row.reserve((size_t) K); d->row.resize((size_t) K);
+      const float* x = reinterpret_cast<const float*>(d->feat->dev.p) + (size_t) t * d->feat->size_;
+      const dsr_status s = dsr_gmm_score(d->gmm, x, 1, d->mode, d->d_row.p, nullptr, S0); if (s) throw Error(s, "%s", dsr_last_error());
+      DSR_HIP(hipMemcpy(d->row.data(), d->d_row.p, sizeof(float) * (size_t) K, hipMemcpyDeviceToHost));
+      d->cachedFrame = t;
+    }
+    *score = d->row[(size_t) distX];
+  });
+}
+// _Decoder::decode() (decoder.h:688-737) for the utterance the feature stream currently holds: _newUtterance resets the cache and the feature
+// (decoder.h:488-492), every frame is scored and decoded on the device.  An empty stream is DSR_E_ITERATOR (the exception escapes decode(), :691).
+dsr_status dsr_decoder_decode_stream(dsr_decoder* dec, dsr_distribset* d, dsr_decode_result* res, int32_t* arcs_out, uint32_t* words_out, int maxPath)
+{
+  return guard([&] {
+    if (!dec || !d || !res) throw Error(DSR_E_PARAMETER, "null argument");
+    d->cachedFrame = -1; d->feat->reset();
+    d->feat->materialize();
+    const int T = d->feat->nFrames, K = dsr_gmm_num_dists(d->gmm);
+    if (T <= 0) { d->feat->endOfSamples = true; throw Error(DSR_E_ITERATOR, "end of samples!"); }
+    d->d_scores.reserve((size_t) T * K); d->d_T.upload(&T, 1);
+    dsr_status s = dsr_gmm_score(d->gmm, reinterpret_cast<const float*>(d->feat->dev.p), (int64_t) T, d->mode, d->d_scores.p, nullptr, S0); if (s) throw Error(s, "%s", dsr_last_error());
+    s = dsr_decoder_decode_batch(dec, d->d_scores.p, d->d_T.p, 1, T, K, res, arcs_out, words_out, maxPath, S0); if (s) throw Error(s, "%s", dsr_last_error());
+    d->feat->frameX = T - 1; d->feat->endOfSamples = true;                   // the reference has pulled the stream to its end
+    if (res->status != DSR_OK) throw Error(res->status, "decode failed (status %d)", res->status);
   });
 }
 

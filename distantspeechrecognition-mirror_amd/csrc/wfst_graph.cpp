@@ -74,11 +74,17 @@ void WfstGraph::readEx(const char* file, bool binary, bool noSelfLoops)
         char* tok[6]; int i = 0;
         tok[0] = strtok(line, " \t\n"); if (!tok[0]) continue;
         while ((i < 5) && ((tok[++i] = strtok(nullptr, " \t\n")) != nullptr));
-        const uint32_t s1 = (uint32_t) strtoul(tok[0], nullptr, 0);
+        auto field = [&](int which, const char* t) -> uint32_t {      // strtoul first, the lexicon when no digits were consumed (:311-313,332-347)
+          char* p = nullptr; const unsigned long v = strtoul(t, &p, 0);
+          if (p != t) return (uint32_t) v;
+          if (!symbolOf) throw Error(DSR_E_KEY, "field '%s' is not a number and the transducer has no %s lexicon", t, which == 0 ? "state" : which == 1 ? "input" : "output");
+          return symbolOf(which, t);
+        };
+        const uint32_t s1 = field(0, tok[0]);
         if (i == 1) addFinal(s1, 0.0f);
         else if (i == 2) { float c = 0.f; sscanf(tok[1], "%f", &c); addFinal(s1, c); }
         else if (i == 4 || i == 5) {
-          const uint32_t s2 = (uint32_t) strtoul(tok[1], nullptr, 0), in = (uint32_t) strtoul(tok[2], nullptr, 0), out = (uint32_t) strtoul(tok[3], nullptr, 0);
+          const uint32_t s2 = field(0, tok[1]), in = field(1, tok[2]), out = field(2, tok[3]);
           if (s1 == s2 && noSelfLoops) continue;
           float c = 0.f; if (i == 5) sscanf(tok[4], "%f", &c);
           addArc(s1, s2, in, out, c, true);

@@ -11,6 +11,7 @@
 // depth-first through epsilon arcs, which the reference expands recursively without recombination.
 #pragma once
 #include "common.h"
+#include <functional>
 #include <string>
 
 namespace dsr {
@@ -24,6 +25,9 @@ struct WfstGraph {
   std::vector<Node> nodes; std::vector<Arc> arcs;
   std::vector<int> nodeOf;             // state -> node id in _nodes/_final, -1 if none
   int initial = -1;
+  // text files may name states and symbols instead of numbering them: a field that does not start with a number is looked up in the state (0),
+  // input (1) or output (2) lexicon (wfstFlyWeight.cc:311-347); unset: such a field is an error
+  std::function<uint32_t(int, const char*)> symbolOf;
 
   int  findNode(uint32_t state, bool create);
   void addFinal(uint32_t state, float cost);

@@ -42,12 +42,12 @@ class MfccCfg(C.Structure):
 
 class DecoderCfg(C.Structure):
     _fields_ = [("beam", f64), ("lmScale", f64), ("lmPenalty", f64), ("silPenalty", f64), ("silenceX", u32),
-                ("maxActive", C.c_int), ("maxCandidates", C.c_int), ("arenaTokens", i64), ("streams", C.c_int), ("latticeTokens", i64)]
+                ("maxActive", C.c_int), ("maxCandidates", C.c_int), ("arenaTokens", i64), ("streams", C.c_int), ("topN", C.c_int), ("latticeTokens", i64)]
 
 
 class DecodeResult(C.Structure):
     _fields_ = [("score", f64), ("ac", f32), ("lm", f32), ("frames", i32), ("reachedFinal", i32), ("nArcs", i32),
-                ("nWords", i32), ("status", i32), ("maxActiveSeen", i32), ("activeHypos", i64), ("placements", i64), ("registerFrames", i64)]
+                ("nWords", i32), ("status", i32), ("maxActiveSeen", i32), ("activeHypos", i64), ("placements", i64), ("registerFrames", i64), ("finalStatesN", i32), ("reserved_", i32)]
 
 
 _HEADER = os.path.join(os.path.dirname(os.path.dirname(_HERE)), "include", "dsr.h")
@@ -643,10 +643,10 @@ class Decoder:
     """DecoderFlyWeight (asr/decoder/decoder.i:147-199) for batches of score matrices."""
 
     def __init__(self, beam=100.0, lmScale=12.0, lmPenalty=0.0, silPenalty=0.0, silenceX=0xFFFFFFFF, maxActive=0,
-                 maxCandidates=0, arenaTokens=0, streams=0, latticeTokens=0):
+                 maxCandidates=0, arenaTokens=0, streams=0, latticeTokens=0, topN=0):
         L = load(); c = DecoderCfg(); L.dsr_decoder_default_cfg(C.byref(c))
         c.beam, c.lmScale, c.lmPenalty, c.silPenalty, c.silenceX = beam, lmScale, lmPenalty, silPenalty, silenceX
-        c.maxActive, c.maxCandidates, c.arenaTokens, c.streams, c.latticeTokens = maxActive, maxCandidates, arenaTokens, streams, latticeTokens
+        c.maxActive, c.maxCandidates, c.arenaTokens, c.streams, c.latticeTokens, c.topN = maxActive, maxCandidates, arenaTokens, streams, latticeTokens, topN
         self.h = vp(); check(L.dsr_decoder_create(C.byref(c), C.byref(self.h))); self._g = None
 
     def __del__(self):

@@ -1,4 +1,6 @@
-"""asr.decoder: WFSTFlyWeightPtr / DecoderFlyWeightPtr (decoder.i:52-70,147-199)."""
+"""asr.decoder: WFSTFlyWeightPtr / DecoderFlyWeightPtr / DecoderPtr (decoder.i:52-70,147-199) over the C-ABI (include/dsr.h sections 5 and 8)."""
+import ctypes as C
+
 import numpy as np
 
 from .. import _capi as K
@@ -7,6 +9,8 @@ from .. import _capi as K
 class WFSTFlyWeightPtr(object):
     def __init__(self, statelex=None, inlex=None, outlex=None, name="WFSTFlyWeight"):
         self._g = K.Wfst(); self._state, self._in, self._out = statelex, inlex, outlex
+        h = lambda l: l._h if l is not None else None
+        K.check(K.load().dsr_wfst_set_lexicons(self._g.h, h(statelex), h(inlex), h(outlex)))
 
     def read(self, fileName, binary=False):
         self._g.read(fileName, binary)
@@ -15,7 +19,10 @@ class WFSTFlyWeightPtr(object):
         self._g.write(fileName, binary)
 
     def hasFinalState(self):
-        return bool(self._g.export()["nodeFinal"].any())
+        return bool(K.load().dsr_wfst_has_final_state(self._g.h))
+
+    def stateLexicon(self):
+        return self._state
 
     def inputLexicon(self):
         return self._in
@@ -35,21 +42,26 @@ class WFSTransducerPtr(WFSTFlyWeightPtr):
         self._g.read_dynamic(fileName, noSelfLoops)
 
 
+class DistribPath(list):
+    """asr/path/distribPath.h:34-60: the names of the distributions along the best path"""
+
+
 class DecoderFlyWeightPtr(object):
-    """decode() pulls every frame of the distribution set's feature stream, scores all distributions on the GPU and runs
-    the token-passing kernel; bestHypo() maps the output ids through the output lexicon (decoder.h:748-773)."""
+    """DecoderFlyWeight (decoder.h:1127-1139; ctor argument order of decoder.i:191-199).  decode() = dsr_decoder_decode_stream: the feature stream
+    of the distribution set is scored and decoded on the device without a host round trip.  heapSize is the bucket count of the reference's token
+    hash (decoder.h:48-76) and has no counterpart here (accepted, unused); generateLattice=True keeps the placement log lattice() needs."""
 
     def __init__(self, dist, beam=100.0, lmScale=12.0, lmPenalty=0.0, silPenalty=0.0, silSymbol="SIL-m", eosSymbol="</s>",
-                 heapSize=5000, topN=0, generateLattice=True):
-        if topN:
-            raise K.DsrError(13, "topN > 0 (sorted expansion with per-hypothesis printing) is not supported")
-        self._dist = dist; self._cfg = dict(beam=beam, lmScale=lmScale, lmPenalty=lmPenalty, silPenalty=silPenalty)
-        self._sil, self._eos = silSymbol, eosSymbol; self._dec = None; self._wfst = None; self._last = None
+                 heapSize=5000, topN=0, generateLattice=True, latticeTokens=1 << 22, maxActive=0):
+        self._dist = dist; self._cfg = dict(beam=beam, lmScale=lmScale, lmPenalty=lmPenalty, silPenalty=silPenalty, topN=int(topN), maxActive=maxActive,
+                                            latticeTokens=int(latticeTokens) if generateLattice else 0, streams=1)
+        self._sil, self._eos = silSymbol, eosSymbol; self._dec = None; self._wfst = None; self._last = None; self._maxPath = 0
 
     def set(self, wfst):
         # _set(): both symbols must exist (decoder.h:740-745 -> jkey_error from List::index)
-        silenceX = wfst.inputLexicon().index(self._sil); wfst.outputLexicon().index(self._eos)
-        self._dec = K.Decoder(silenceX=silenceX, **self._cfg); self._dec.set(wfst._g); self._wfst = wfst
+        self._dec = K.Decoder(**self._cfg)
+        K.check(K.load().dsr_decoder_set_symbols(self._dec.h, wfst._g.h, self._sil.encode(), self._eos.encode()))
+        self._dec._g = wfst._g; self._wfst = wfst
 
     def setBeam(self, beam):
         self._cfg["beam"] = beam
@@ -57,24 +69,45 @@ class DecoderFlyWeightPtr(object):
             self._dec.setBeam(beam)
 
     def decode(self, verbose=False):
-        import torch
-        feat = self._dist._cbs.feature()
-        rows = [np.array(v, dtype=np.float32) for v in feat]           # __iter__ = reset() + next() until the end
-        if not rows:
-            raise StopIteration                                         # the exception escapes decode() (decoder.h:691)
-        x = torch.from_numpy(np.stack(rows)).cuda()
-        sc = self._dist.score_all_frames(x)
-        self._last = self._dec.decode_batch(sc[None].contiguous())[0]
-        if self._last["status"] != 0:
-            raise K.DsrError(self._last["status"], "decode failed")
-        return self._last["score"]
+        if self._dec is None:
+            raise K.DsrError(7, "call set() with a transducer first")
+        res = K.DecodeResult(); maxPath = 1 << 16
+        arcs = np.zeros(maxPath, np.int32); words = np.zeros(maxPath, np.uint32)
+        st = K.load().dsr_decoder_decode_stream(self._dec.h, self._dist._ds, C.byref(res), K._ptr(arcs), K._ptr(words), maxPath)
+        if st == K.E_ITERATOR:
+            raise StopIteration                                         # an empty stream: the exception escapes decode() (decoder.h:691)
+        K.check(st)
+        self._last = dict(score=res.score, ac=res.ac, lm=res.lm, frames=res.frames, reachedFinal=bool(res.reachedFinal), arcs=arcs[:res.nArcs].copy(),
+                          words=words[:res.nWords].copy(), finalStatesN=res.finalStatesN, activeHypos=res.activeHypos)
+        if verbose:
+            print("Decoded %d frames: score %g, %g active hypotheses per frame" % (res.frames + 1, res.score, res.activeHypos / max(1, res.frames + 1)))
+        return res.score
+
+    def _string(self, fn, *a):
+        need = C.c_size_t()
+        K.check(fn(self._dec.h, 0, *a, None, 0, C.byref(need)))
+        buf = C.create_string_buffer(need.value)
+        K.check(fn(self._dec.h, 0, *a, buf, need.value, C.byref(need)))
+        return buf.value.decode()
 
     def bestHypo(self, useInputSymbols=False):
-        lex = self._wfst.outputLexicon()
-        return "".join(lex.symbol(int(w)) + " " for w in self._last["words"])
+        return self._string(K.load().dsr_decoder_best_hypo, int(bool(useInputSymbols)))
+
+    def bestPath(self):
+        need = C.c_size_t(); cnt = C.c_int(); L = K.load()
+        K.check(L.dsr_decoder_best_path(self._dec.h, 0, None, 0, C.byref(need), C.byref(cnt)))
+        buf = C.create_string_buffer(need.value)
+        K.check(L.dsr_decoder_best_path(self._dec.h, 0, buf, need.value, C.byref(need), C.byref(cnt)))
+        return DistribPath(buf.value.decode().split("\n")[:cnt.value])
+
+    def finalStatesN(self):
+        n = C.c_int(); K.check(K.load().dsr_decoder_final_states_n(self._dec.h, 0, C.byref(n))); return n.value
 
     def traceBackSucceeded(self):
-        return bool(self._last and self._last["reachedFinal"])
+        ok = C.c_int(); K.check(K.load().dsr_decoder_trace_back_succeeded(self._dec.h, 0, C.byref(ok))); return bool(ok.value)
+
+    def lattice(self):
+        return self._dec.lattice(0, K.load().dsr_decoder_eos_index(self._dec.h))
 
     def bestArcs(self):
         return self._last["arcs"]

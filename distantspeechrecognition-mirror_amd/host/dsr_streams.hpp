@@ -319,3 +319,184 @@ class SubbandMVDR : public SubbandDS {
   bool calcMVDRWeights(double sampleRate, double dThreshold = 1.0E-8, bool calcInverseMatrix = true) { (void) calcInverseMatrix; dsr_throw(dsr_bf_calc_mvdr_weights(weights(), sampleRate, dThreshold)); return true; }
 };
 #undef DSR_OP
+
+// ======================================================================================================================
+// ASR side (asr/dictionary, asr/gaussian, asr/decoder): the classes decoder.i:52-199 and gaussian.i:281-283,465-467 wrap, with
+// their constructor argument order, over include/dsr.h sections 4, 5 and 8.
+// ======================================================================================================================
+#include <fstream>
+#include <map>
+#include <sstream>
+
+// ---- btk/feature/feature.h:1486-1501
+class FeatureSet {
+ public:
+  explicit FeatureSet(const String& nm = "FeatureSet") : _name(nm) {}
+  const String& name() const { return _name; }
+  void add(VectorFloatFeatureStreamPtr& feat) { _list[feat->name()] = feat; }
+  VectorFloatFeatureStreamPtr& feature(const String& nm) {
+    std::map<String, VectorFloatFeatureStreamPtr>::iterator it = _list.find(nm);
+    if (it == _list.end()) throw jkey_error("Could not find key " + nm + " in list " + _name);          // List::operator[] (mlist.h:109-114)
+    return it->second;
+  }
+ private:
+  String _name; std::map<String, VectorFloatFeatureStreamPtr> _list;
+};
+typedef std::shared_ptr<FeatureSet> FeatureSetPtr;
+
+// ---- asr/dictionary/distribTree.h:40-65
+class Lexicon {
+ public:
+  explicit Lexicon(const String& nm, const String& fileName = "") : _h(0) { dsr_throw(dsr_lexicon_create(nm.c_str(), fileName.c_str(), &_h)); }
+  ~Lexicon() { dsr_lexicon_destroy(_h); }
+  void clear() { dsr_throw(dsr_lexicon_clear(_h)); }
+  String name() const { return dsr_lexicon_name(_h); }
+  unsigned size() const { return (unsigned) dsr_lexicon_size(_h); }
+  void read(const String& fileName) { dsr_throw(dsr_lexicon_read(_h, fileName.c_str())); }
+  void write(const String& fileName, bool writeHeader = false) const { dsr_throw(dsr_lexicon_write(_h, fileName.c_str(), writeHeader)); }
+  unsigned index(const String& symbol, bool create = false) { unsigned i = 0; dsr_throw(dsr_lexicon_index(_h, symbol.c_str(), create, &i)); return i; }
+  String symbol(unsigned idx) const { const char* p = 0; dsr_throw(dsr_lexicon_symbol(_h, idx, &p)); return p; }
+  bool isPresent(const String& symbol) const { return dsr_lexicon_is_present(_h, symbol.c_str()) != 0; }
+  dsr_lexicon* handle() const { return _h; }
+ private:
+  Lexicon(const Lexicon&); Lexicon& operator=(const Lexicon&);
+  dsr_lexicon* _h;
+};
+typedef std::shared_ptr<Lexicon> LexiconPtr;
+
+// ---- asr/gaussian: CodebookSetBasic(descFile, fs, cbkFile) (gaussian.i:281-283; description lines "name featureName refN dimN covType",
+// ';' comments, codebookBasic.cc:804-828) and DistribSetBasic(cbs, descFile, distFile) (gaussian.i:465-467; lines "name codebookName",
+// distribBasic.cc:218-232).  The big-endian set files are read by dsr_gmm_load.
+inline std::vector<std::vector<String> > dsr_desc_rows(const String& path)
+{
+  std::vector<std::vector<String> > rows; if (path.empty()) return rows;
+  std::ifstream f(path.c_str()); if (!f) throw jio_error("Could not open file " + path);
+  String line;
+  while (std::getline(f, line)) { if (!line.empty() && line[0] == ';') continue; std::istringstream is(line); std::vector<String> t; String w; while (is >> w) t.push_back(w); if (!t.empty()) rows.push_back(t); }
+  return rows;
+}
+class CodebookSetBasic {
+ public:
+  CodebookSetBasic(const String& descFile = "", FeatureSetPtr fs = FeatureSetPtr(), const String& cbkFile = "") : _fs(fs), _cbkFile(cbkFile), _desc(dsr_desc_rows(descFile)) {}
+  unsigned ncbks() const { return (unsigned) _desc.size(); }
+  const String& cbkFile() const { return _cbkFile; }
+  VectorFloatFeatureStreamPtr& feature() {
+    if (_desc.empty() || _desc[0].size() < 2 || !_fs) throw jconsistency_error("the codebook description names no feature");
+    return _fs->feature(_desc[0][1]);
+  }
+ private:
+  FeatureSetPtr _fs; String _cbkFile; std::vector<std::vector<String> > _desc;
+};
+typedef std::shared_ptr<CodebookSetBasic> CodebookSetBasicPtr;
+
+class DistribSetBasic;
+class DistribBasic {                                          // Distrib::score(frameX), name() (distribBasic.h:40-60)
+ public:
+  DistribBasic(dsr_distribset* ds, int x) : _ds(ds), _x(x) {}
+  float score(int frameX) { float s = 0.f; dsr_throw(dsr_distribset_score(_ds, _x, frameX, &s)); return s; }
+  String name() const { return dsr_distribset_name(_ds, _x); }
+ private:
+  dsr_distribset* _ds; int _x;
+};
+class DistribSetBasic {
+ public:
+  DistribSetBasic(CodebookSetBasicPtr& cbs, const String& descFile = "", const String& distFile = "") : _cbs(cbs), _gmm(0), _ds(0) {
+    const std::vector<std::vector<String> > d = dsr_desc_rows(descFile);
+    dsr_throw(dsr_gmm_load(cbs->cbkFile().c_str(), distFile.c_str(), &_gmm));
+    if (!d.empty() && (int) d.size() != dsr_gmm_num_dists(_gmm)) { dsr_gmm_destroy(_gmm); throw jconsistency_error("the description and the file hold different numbers of distributions"); }
+    _feat = cbs->feature();
+    const dsr_status s = dsr_distribset_create(_gmm, _feat->handle(), 0, &_ds);
+    if (s != DSR_OK) { dsr_gmm_destroy(_gmm); dsr_throw(s); }
+  }
+  ~DistribSetBasic() { dsr_distribset_destroy(_ds); dsr_gmm_destroy(_gmm); }
+  unsigned ndists() const { return (unsigned) dsr_distribset_ndists(_ds); }
+  unsigned index(const String& key) const { int x = 0; dsr_throw(dsr_distribset_find(_ds, key.c_str(), &x)); return (unsigned) x; }
+  DistribBasic find(const String& key) { return DistribBasic(_ds, (int) index(key)); }
+  DistribBasic find(unsigned dsX) { if (dsX >= ndists()) throw jindex_error("distribution index out of range"); return DistribBasic(_ds, (int) dsX); }
+  void resetCache() { dsr_throw(dsr_distribset_reset_cache(_ds)); }
+  void resetFeature() { dsr_throw(dsr_distribset_reset_feature(_ds)); }
+  dsr_distribset* handle() const { return _ds; }
+ private:
+  DistribSetBasic(const DistribSetBasic&); DistribSetBasic& operator=(const DistribSetBasic&);
+  CodebookSetBasicPtr _cbs; VectorFloatFeatureStreamPtr _feat; dsr_gmm* _gmm; dsr_distribset* _ds;
+};
+typedef std::shared_ptr<DistribSetBasic> DistribSetBasicPtr;
+typedef DistribSetBasicPtr DistribSetPtr;
+
+// ---- asr/decoder: WFSTFlyWeight(statelex, inlex, outlex, name) (decoder.i:52-70)
+class WFSTFlyWeight {
+ public:
+  WFSTFlyWeight(LexiconPtr& statelex, LexiconPtr& inlex, LexiconPtr& outlex, const String& name = "WFSTFlyWeight")
+    : _stateLexicon(statelex), _inputLexicon(inlex), _outputLexicon(outlex), _name(name), _h(0) {
+    dsr_throw(dsr_wfst_create(&_h));
+    dsr_throw(dsr_wfst_set_lexicons(_h, statelex ? statelex->handle() : 0, inlex ? inlex->handle() : 0, outlex ? outlex->handle() : 0));
+  }
+  ~WFSTFlyWeight() { dsr_wfst_destroy(_h); }
+  void read(const String& fileName, bool binary = false) { dsr_throw(dsr_wfst_read(_h, fileName.c_str(), binary)); }
+  void write(const String& fileName, bool binary = true, bool useSymbols = false) { (void) useSymbols; dsr_throw(dsr_wfst_write(_h, fileName.c_str(), binary)); }
+  bool hasFinalState() const { return dsr_wfst_has_final_state(_h) != 0; }
+  LexiconPtr& stateLexicon() { return _stateLexicon; }
+  LexiconPtr& inputLexicon() { return _inputLexicon; }
+  LexiconPtr& outputLexicon() { return _outputLexicon; }
+  dsr_wfst* handle() const { return _h; }
+ private:
+  WFSTFlyWeight(const WFSTFlyWeight&); WFSTFlyWeight& operator=(const WFSTFlyWeight&);
+  LexiconPtr _stateLexicon, _inputLexicon, _outputLexicon; String _name; dsr_wfst* _h;
+};
+typedef std::shared_ptr<WFSTFlyWeight> WFSTFlyWeightPtr;
+
+typedef std::vector<String> DistribPath;                       // asr/path/distribPath.h:34-60: the distribution names along a path
+class Lattice {                                                // what _Decoder::lattice() returns (asr/lattice/lattice.h:188-330): write() and the raw arrays
+ public:
+  explicit Lattice(dsr_lattice* h) : _h(h) {}
+  ~Lattice() { dsr_lattice_destroy(_h); }
+  void write(const String& fileName = "", bool useSymbols = false, bool writeData = false) { (void) useSymbols; dsr_throw(dsr_lattice_write(_h, fileName.c_str(), writeData)); }
+  unsigned nodesN() const { return (unsigned) dsr_lattice_num_nodes(_h); }
+  unsigned edgesN() const { return (unsigned) dsr_lattice_num_edges(_h); }
+  dsr_lattice* handle() const { return _h; }
+ private:
+  Lattice(const Lattice&); Lattice& operator=(const Lattice&);
+  dsr_lattice* _h;
+};
+typedef std::shared_ptr<Lattice> LatticePtr;
+
+// DecoderFlyWeight(dist, beam, lmScale, lmPenalty, silPenalty, silSymbol, eosSymbol, heapSize, topN, generateLattice) (decoder.i:147-199).
+// heapSize sizes the reference's token hash (decoder.h:48-76) and has no counterpart here.
+class DecoderFlyWeight {
+ public:
+  DecoderFlyWeight(DistribSetPtr& dist, double beam = 100.0, double lmScale = 12.0, double lmPenalty = 0.0, double silPenalty = 0.0,
+                   const String& silSymbol = "SIL-m", const String& eosSymbol = "</s>", unsigned heapSize = 5000, unsigned topN = 0, bool generateLattice = true)
+    : _dist(dist), _sil(silSymbol), _eos(eosSymbol), _h(0), _score(0.0) {
+    (void) heapSize;
+    dsr_decoder_cfg c; dsr_decoder_default_cfg(&c);
+    c.beam = beam; c.lmScale = lmScale; c.lmPenalty = lmPenalty; c.silPenalty = silPenalty; c.topN = (int) topN; c.streams = 1;
+    c.latticeTokens = generateLattice ? ((int64_t) 1 << 22) : 0;
+    dsr_throw(dsr_decoder_create(&c, &_h));
+  }
+  ~DecoderFlyWeight() { dsr_decoder_destroy(_h); }
+  void set(WFSTFlyWeightPtr& wfst) { dsr_throw(dsr_decoder_set_symbols(_h, wfst->handle(), _sil.c_str(), _eos.c_str())); _wfst = wfst; }
+  double decode(bool verbose = false) {
+    (void) verbose;
+    dsr_decode_result r; std::vector<int32_t> arcs((size_t) 1 << 16); std::vector<uint32_t> words((size_t) 1 << 16);
+    dsr_throw(dsr_decoder_decode_stream(_h, _dist->handle(), &r, arcs.data(), words.data(), (int) arcs.size()));
+    _score = r.score; return _score;
+  }
+  String bestHypo(bool useInputSymbols = false) {
+    size_t need = 0; dsr_throw(dsr_decoder_best_hypo(_h, 0, useInputSymbols, 0, 0, &need));
+    std::vector<char> b(need); dsr_throw(dsr_decoder_best_hypo(_h, 0, useInputSymbols, b.data(), b.size(), &need)); return String(b.data());
+  }
+  DistribPath bestPath() {
+    size_t need = 0; int n = 0; dsr_throw(dsr_decoder_best_path(_h, 0, 0, 0, &need, &n));
+    std::vector<char> b(need); dsr_throw(dsr_decoder_best_path(_h, 0, b.data(), b.size(), &need, &n));
+    DistribPath p; std::istringstream is(String(b.data())); String w; while (std::getline(is, w)) p.push_back(w); return p;
+  }
+  unsigned finalStatesN() const { int n = 0; dsr_throw(dsr_decoder_final_states_n(_h, 0, &n)); return (unsigned) n; }
+  bool traceBackSucceeded() const { int ok = 0; dsr_throw(dsr_decoder_trace_back_succeeded(_h, 0, &ok)); return ok != 0; }
+  LatticePtr lattice() { dsr_lattice* l = 0; dsr_throw(dsr_decoder_lattice(_h, 0, dsr_decoder_eos_index(_h), &l)); return LatticePtr(new Lattice(l)); }
+  void setBeam(double beam) { dsr_throw(dsr_decoder_set_beam(_h, beam)); }
+  dsr_decoder* handle() const { return _h; }
+ private:
+  DecoderFlyWeight(const DecoderFlyWeight&); DecoderFlyWeight& operator=(const DecoderFlyWeight&);
+  DistribSetPtr _dist; WFSTFlyWeightPtr _wfst; String _sil, _eos; dsr_decoder* _h; double _score;
+};
+typedef std::shared_ptr<DecoderFlyWeight> DecoderFlyWeightPtr;

@@ -222,6 +222,10 @@ dsr_status dsr_gmm_save(const dsr_gmm*, const char* codebookFile, const char* di
 void       dsr_gmm_destroy(dsr_gmm*);
 int dsr_gmm_num_dists(const dsr_gmm*);
 int dsr_gmm_dim(const dsr_gmm*);
+/* names of the set (file order) and DistribSet::find(name) / index(key) (asr/gaussian/distribBasic.h:183-190): DSR_E_KEY when absent */
+const char* dsr_gmm_dist_name(const dsr_gmm*, int distX);
+const char* dsr_gmm_codebook_name(const dsr_gmm*, int cbX);
+dsr_status dsr_gmm_find_dist(const dsr_gmm*, const char* name, int* distX);
 /* x_dev [N][dimN] fp32 -> score_dev [N][K] fp32 (cost), argmin_dev [N][K] u8 or NULL.
    mode 0: _scoreOpt nearest Gaussian, bit-exact reference order; mode 1: _scoreAll log-sum;
    mode 2: _scoreOpt through the fp32-MFMA candidate search + exact re-score (same bits as mode 0) */
@@ -233,8 +237,30 @@ dsr_status dsr_gmm_score(dsr_gmm*, const float* x_dev, int64_t N, int mode, floa
  *    replaces WFSTFlyWeight (asr/decoder/wfstFlyWeight.h:47-252, .cc:63-139,299-463) and
  *    DecoderFlyWeight / _Decoder (asr/decoder/decoder.h:325-1102,1127-1139; decoder.i:147-199)
  * ===================================================================================== */
+/* Lexicon (asr/dictionary/distribTree.h:40-65, distribTree.cc:36-133): symbol <-> index, indices = line order of the file (its index column is
+   ignored), ';' comment lines, a repeated symbol is skipped; index() of an unknown symbol is DSR_E_KEY (List::index, btk/common/mlist.h:109-114)
+   unless create != 0 */
+typedef struct dsr_lexicon dsr_lexicon;
+dsr_status dsr_lexicon_create(const char* name, const char* fileName /* "" or NULL: empty */, dsr_lexicon** out);
+void       dsr_lexicon_destroy(dsr_lexicon*);
+dsr_status dsr_lexicon_read(dsr_lexicon*, const char* fileName);
+dsr_status dsr_lexicon_write(const dsr_lexicon*, const char* fileName, int writeHeader);
+dsr_status dsr_lexicon_clear(dsr_lexicon*);
+int        dsr_lexicon_size(const dsr_lexicon*);
+const char* dsr_lexicon_name(const dsr_lexicon*);
+int        dsr_lexicon_is_present(const dsr_lexicon*, const char* symbol);
+dsr_status dsr_lexicon_index(dsr_lexicon*, const char* symbol, int create, unsigned* index);
+dsr_status dsr_lexicon_symbol(const dsr_lexicon*, unsigned index, const char** symbol /* borrowed */);
+
 typedef struct dsr_wfst dsr_wfst;
 dsr_status dsr_wfst_create(dsr_wfst** out);
+/* WFSTFlyWeight(statelex, inlex, outlex) (decoder.i:52-70): borrowed lexica; the text reader looks fields that are not numbers up in them
+   (wfstFlyWeight.cc:311-347); inputLexicon() / outputLexicon() / stateLexicon(); hasFinalState() */
+dsr_status dsr_wfst_set_lexicons(dsr_wfst*, dsr_lexicon* stateLex, dsr_lexicon* inputLex, dsr_lexicon* outputLex);
+dsr_lexicon* dsr_wfst_state_lexicon(const dsr_wfst*);
+dsr_lexicon* dsr_wfst_input_lexicon(const dsr_wfst*);
+dsr_lexicon* dsr_wfst_output_lexicon(const dsr_wfst*);
+int        dsr_wfst_has_final_state(const dsr_wfst*);
 void       dsr_wfst_destroy(dsr_wfst*);
 dsr_status dsr_wfst_read(dsr_wfst*, const char* fileName, int binary);    /* WFSTFlyWeight::read */
 /* the dynamic container's text reader, WFSTransducer::read(fileName, noSelfLoops) (asr/fsm/fsm.cc:901-986): same node/arc
@@ -256,6 +282,8 @@ typedef struct {
   int maxCandidates;        /* placements per frame      (0 = default 8*maxActive) */
   int64_t arenaTokens;      /* back-pointer records per utterance (0 = default 64 * frames * 1024) */
   int streams;              /* concurrent utterance slots (0 = default 2 per CU) */
+  int topN;                 /* decoder.i:198 (default 0).  > 0: _processFrame expands the topN best tokens of the list, in the order of their scores
+                               (SortedIterator, decoder.h:298-320; ties in list order, which std::sort leaves open) and applies no beam (:571-581) */
   int64_t latticeTokens;    /* generateLattice (decoder.i:199): > 0 keeps every placement of every frame, at most this many per utterance, for
                                dsr_decoder_lattice(); 0 (default here; the reference always builds its 'worse' chains, decoder.h:1113-1114) = 1-best only */
 } dsr_decoder_cfg;
@@ -265,6 +293,23 @@ dsr_status dsr_decoder_create(const dsr_decoder_cfg*, dsr_decoder** out);
 void       dsr_decoder_destroy(dsr_decoder*);
 dsr_status dsr_decoder_set(dsr_decoder*, const dsr_wfst*);               /* DecoderFlyWeight::set */
 dsr_status dsr_decoder_set_beam(dsr_decoder*, double beam);
+/* DecoderFlyWeight::set(wfst) with the symbol look-ups of _Decoder::_set (decoder.h:740-745): silSymbol in the input lexicon (-> cfg.silenceX),
+   eosSymbol in the output lexicon; a missing symbol is DSR_E_KEY as in the reference.  NULL symbols are not looked up. */
+dsr_status dsr_decoder_set_symbols(dsr_decoder*, const dsr_wfst*, const char* silSymbol, const char* eosSymbol);
+uint32_t   dsr_decoder_eos_index(const dsr_decoder*);
+/* Results of the last collected decode, utterance u of its batch (the decode must have been collected with paths):
+ *   best_hypo  bestHypo(useInputSymbols) (decoder.h:748-773): output symbols != 0 along the best path, or the input symbols != 0 with repetitions
+ *              dropped as the reference drops them (walking from the path's end: a symbol is kept when it differs from the one kept after it),
+ *              every symbol followed by one blank;
+ *   best_path  bestPath() (decoder.h:775-797): the names of the distributions along the path = input symbols != 0, one per line; *count = how many;
+ *   path_ids   the same sequences as ids (which 0 outputs, 1 inputs as bestHypo(true), 2 inputs as bestPath) -- no lexicon needed;
+ *   final_states_n  finalStatesN() (:598-608);   trace_back_succeeded  traceBackSucceeded() (:611-637).
+ * buf may be NULL to ask for the size (*need, including the terminating NUL). */
+dsr_status dsr_decoder_best_hypo(const dsr_decoder*, int u, int useInputSymbols, char* buf, size_t cap, size_t* need);
+dsr_status dsr_decoder_best_path(const dsr_decoder*, int u, char* buf, size_t cap, size_t* need, int* count);
+dsr_status dsr_decoder_path_ids(const dsr_decoder*, int u, int which, uint32_t* ids, int cap, int* n);
+dsr_status dsr_decoder_final_states_n(const dsr_decoder*, int u, int* n);
+dsr_status dsr_decoder_trace_back_succeeded(const dsr_decoder*, int u, int* ok);
 typedef struct {
   double  score;        /* decode() return value: double(ac)+double(lm) of the best token */
   float   ac, lm;
@@ -277,6 +322,8 @@ typedef struct {
   int64_t activeHypos;  /* sum over frames of |_next| (decoder.h:413) */
   int64_t placements;   /* calls of _placeOnList over the utterance (expanded arcs incl. the end expansion) */
   int64_t registerFrames; /* diagnostics: frames that ran on the decoder kernel's register path (rest: memory path) */
+  int32_t finalStatesN; /* finalStatesN() (decoder.h:598-608): tokens of _next in a final state after _expandToEnd */
+  int32_t reserved_;
 } dsr_decode_result;
 /* Batched decode.  score_dev [U][Tmax][nDist] fp32 costs (row t = Distrib::score(t)), nframes_dev [U].
  * Host outputs: res[U]; arcs_out [U][maxPath] (export arc ids, first..last), words_out [U][maxPath]
@@ -513,6 +560,25 @@ dsr_status dsr_mean_subtraction_create(dsr_stream* src, double devNormFactor, in
 dsr_status dsr_adjacent_create(dsr_stream* single, int delta, const char* name, dsr_stream** out);
 dsr_status dsr_linear_transform_create(dsr_stream* src, int sz, const char* name, dsr_stream** out);
 dsr_status dsr_linear_transform_set(dsr_stream*, const float* matrix /*[sz][srcSize]*/);
+
+/* =====================================================================================
+ * 8. The distribution set as the decoder sees it
+ *    replaces Distrib::score(frameX) (asr/gaussian/distribBasic.h:48-50), DistribSet::find (:183-190), resetCache / resetFeature (:177-178) and
+ *    the pull chain decoder -> distribution -> codebook -> feature stream (decoder.h:985, codebookBasic.cc:431-465): a GMM model bound to a
+ *    feature-stream handle.  score() pulls frame frameX through the stream protocol (DSR_E_ITERATOR at the end, DSR_E_INDEX out of order), scores
+ *    every distribution of that frame on the device once and serves the frame's other requests from that (the reference caches per codebook and
+ *    frame).  decode_stream() = _Decoder::decode() for the utterance the stream holds: features, scores and token passing stay on the device.
+ * ===================================================================================== */
+typedef struct dsr_distribset dsr_distribset;
+dsr_status dsr_distribset_create(dsr_gmm*, dsr_stream* feature, int gmmMode /* as dsr_gmm_score */, dsr_distribset** out);
+void       dsr_distribset_destroy(dsr_distribset*);
+int        dsr_distribset_ndists(const dsr_distribset*);
+dsr_status dsr_distribset_find(const dsr_distribset*, const char* name, int* distX);
+const char* dsr_distribset_name(const dsr_distribset*, int distX);
+dsr_status dsr_distribset_score(dsr_distribset*, int distX, int frameX, float* score);
+dsr_status dsr_distribset_reset_cache(dsr_distribset*);
+dsr_status dsr_distribset_reset_feature(dsr_distribset*);
+dsr_status dsr_decoder_decode_stream(dsr_decoder*, dsr_distribset*, dsr_decode_result* res, int32_t* arcs_out, uint32_t* words_out, int maxPath);
 
 #ifdef __cplusplus
 }

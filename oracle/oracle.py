@@ -68,7 +68,7 @@ class CbSet(C.Structure):
 
 class DecCfg(C.Structure):
     _fields_ = [("beam", c_dbl), ("lmScale", c_dbl), ("lmPenalty", c_dbl), ("silPenalty", c_dbl),
-                ("silenceX", C.c_uint), ("dumpTokens", c_int)]
+                ("silenceX", C.c_uint), ("dumpTokens", c_int), ("topN", c_int)]
 
 
 class DecResult(C.Structure):
@@ -578,11 +578,11 @@ class Wfst:
         return d
 
     def decode(self, scores, beam=100.0, lmScale=12.0, lmPenalty=0.0, silPenalty=0.0, silenceX=0xFFFFFFFF, dump=False, lattice=False, eosX=0,
-               latticeFile=None, writeData=True):
+               latticeFile=None, writeData=True, topN=0):
         """lattice=True: also _Decoder::lattice() (decoder.h:805-953) -> out["lattice"] = dict(nodeFinal, from, to, in, out, start, end, ac, lm), edges
         in creation order; latticeFile: Lattice::write(file, useSymbols=False, writeData) (lattice.cc:715-757)"""
         sc = _f32(scores); T, nDist = sc.shape
-        cfg = DecCfg(beam, lmScale, lmPenalty, silPenalty, silenceX, int(dump))
+        cfg = DecCfg(beam, lmScale, lmPenalty, silPenalty, silenceX, int(dump), int(topN))
         res = DecResult(); lat = Lattice()
         L = lib(); L.orc_decode_lat.argtypes = [c_vp, C.POINTER(DecCfg), c_vp, c_int, c_int, C.POINTER(DecResult), C.POINTER(Lattice), C.c_uint]
         rc = L.orc_decode_lat(self.h, C.byref(cfg), _p(sc), T, nDist, C.byref(res), C.byref(lat) if lattice else None, int(eosX))

@@ -170,6 +170,7 @@ void orc_wfst_export(const orc_wfst*, unsigned* nodeState, int* nodeFinal, float
 typedef struct {
   double beam, lmScale, lmPenalty, silPenalty; unsigned silenceX;
   int dumpTokens;   /* record every frame's token list (list order) in the result */
+  int topN;         /* > 0: expand the topN best tokens in score order, no beam (decoder.h:571-581) */
 } orc_dec_cfg;
 typedef struct {
   double score; float ac, lm; int frames; int reachedFinal; int nArcs;

@@ -476,6 +476,19 @@ int orc_decode_lat(const orc_wfst* g, const orc_dec_cfg* cfg, const float* score
     double thresh = d.topScore + cfg->beam;
     d.topScore = HUGE_VAL;
     int any = 0;
+    if (cfg->topN > 0) {
+      /* SortedIterator (decoder.h:298-320): holders in list order, sorted by the float score (insertion sort = stable: ties keep list order,
+         which the reference's std::sort leaves open), the first topN are expanded, no beam (:571-581) */
+      int cnt = 0; for (int h = d.cur->head; h >= 0; h = d.cur->h[h].next) cnt++;
+      int* ord = (int*) malloc(sizeof(int) * (size_t) (cnt > 0 ? cnt : 1)); int k = 0;
+      for (int h = d.cur->head; h >= 0; h = d.cur->h[h].next) {
+        int tk = d.cur->h[h].tok; float sc_ = tok_score(&d.tok[tk]); int j = k++;
+        while (j > 0 && tok_score(&d.tok[ord[j - 1]]) > sc_) { ord[j] = ord[j - 1]; j--; }
+        ord[j] = tk;
+      }
+      for (int i = 0; i < cnt && i < cfg->topN && !d.ended; i++) { any = 1; expand_node(&d, g->arcs[d.tok[ord[i]].arc].dst, ord[i]); }
+      free(ord);
+    } else
     for (int h = d.cur->head; h >= 0 && !d.ended; h = d.cur->h[h].next) {
       int tk = d.cur->h[h].tok;
       double score = tok_score(&d.tok[tk]);

@@ -195,3 +195,57 @@ def test_cpp_facade_compiles_and_maps_errors(tmp_path):
     # without a GPU the first device touch raises JINITIALIZATION (6); with one, an empty source ends with JITERATOR (8)
     assert lines[0] in ("320 Preemphasis -1",) or lines[0].startswith("init")
     assert any(l in ("init 6", "iter 8") for l in lines)
+
+
+def test_cpp_facade_asr_classes(tmp_path):
+    """Lexicon / FeatureSet / CodebookSetBasic / DistribSetBasic / WFSTFlyWeight / DecoderFlyWeight in host/dsr_streams.hpp with
+    the constructor order of decoder.i:52-70,147-199 and gaussian.i:281-283,465-467: compile with plain g++ and run the host-side parts."""
+    src = tmp_path / "a.cpp"
+    src.write_text(r"""
+#include "dsr_streams.hpp"
+#include <cstdio>
+int main(int argc, char** argv) {
+  LexiconPtr st(new Lexicon("state")), in(new Lexicon("in", argv[1])), out(new Lexicon("out", argv[1]));
+  printf("lex %u %s %u %d\n", in->size(), in->symbol(3).c_str(), in->index("eps"), (int) in->isPresent("nope"));
+  try { in->index("nope"); } catch (jkey_error& e) { printf("key %d\n", (int) e.getCode()); }
+  WFSTFlyWeightPtr w(new WFSTFlyWeight(st, in, out));
+  w->read(argv[2], false);
+  printf("final %d\n", (int) w->hasFinalState());
+  try {
+    VectorFloatFeatureStreamPtr s(new SampleFeature("", 320, 160));
+    FeatureSetPtr fs(new FeatureSet()); fs->add(s);
+    CodebookSetBasicPtr cbs(new CodebookSetBasic("", fs, "/nonexistent.cb"));
+    DistribSetBasicPtr dss(new DistribSetBasic(cbs, "", "/nonexistent.ds"));
+    DecoderFlyWeightPtr d(new DecoderFlyWeight(dss, 100.0, 12.0, 0.0, 0.0, "SIL-m", "</s>", 5000, 0, true));
+    d->set(w); d->decode(); d->bestHypo(true); d->bestPath(); d->finalStatesN(); d->lattice();
+  } catch (j_error& e) { printf("err %d\n", (int) e.getCode()); }
+  return 0;
+}
+""")
+    g = tmp_path / "g.fsm"
+    g.write_text("0 1 eps # 0.5\n1 2 3 0\n2 1.5\n")                    # symbols ('eps', '#') and numbers mixed (wfstFlyWeight.cc:311-347)
+    exe = tmp_path / "a"
+    subprocess.check_call(["g++", "-std=c++11", "-Wall", "-I", os.path.join(PKG, "host"), str(src), "-o", str(exe), "-L", os.path.join(PKG, "lib"),
+                           "-ldsr_hip", "-Wl,-rpath," + os.path.join(PKG, "lib"), "-Wl,-rpath,/opt/rocm/lib"])
+    out = subprocess.run([str(exe), os.path.join(ROOT, "tests", "golden", "Lexicon.txt"), str(g)], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout + out.stderr
+    lines = out.stdout.strip().split("\n")
+    assert lines[0] == "lex 4 # 0 0" and lines[1] == "key 10" and lines[2] == "final 1"
+    assert lines[3] in ("err 7", "err 6")                                # the model files do not exist (JIO) / no device (JINITIALIZATION)
+
+
+def test_lexicon_container_through_the_boundary(tmp_path):
+    import dsr._capi as K
+    from dsr.asr.dictionary import LexiconPtr
+    f = tmp_path / "l.txt"
+    f.write_text("; comment\neps 0\nA 7\nB\nA 3\n\nC 1\n")
+    lx = LexiconPtr("t", str(f))
+    assert lx.size() == 4 and [lx.symbol(i) for i in range(4)] == ["eps", "A", "B", "C"]     # line order; the index column is ignored; the repeat skipped
+    assert lx.index("Z", create=True) == 4 and lx.isPresent("Z") and not lx.isPresent("Q")
+    with pytest.raises(K.DsrError) as e:
+        lx.symbol(99)
+    assert e.value.status == 6
+    lx.write(str(tmp_path / "o.txt"))
+    assert open(tmp_path / "o.txt").read().splitlines()[1] == "%30s %10d" % ("A", 1)         # distribTree.cc:118
+    l2 = LexiconPtr("u", str(tmp_path / "o.txt"))
+    assert list(l2) == list(lx)

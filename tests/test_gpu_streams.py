@@ -186,6 +186,54 @@ def test_decode_like_decodeTest(dsr, oracle, cuda, headset, tmp_path):
     with pytest.raises(dsr.DsrError) as e:
         bad.set(wfst)
     assert e.value.status == 11                                  # jkey_error
+    # ---- the rest of the ASR boundary: bestPath, finalStatesN, bestHypo(useInputSymbols), traceBackSucceeded
+    ex = go.export(); ain = ex["arcIn"][ro["arcs"]]
+    assert list(d.bestPath()) == [inlex[i] for i in ain if i != 0]                                   # decoder.h:775-797: names along the path
+    kept, lastX = [], 0
+    for i in ain[::-1]:                                                                             # decoder.h:754-760, walking prev() from the end
+        if i != 0 and i != lastX:
+            kept.append(int(i)); lastX = int(i)
+    assert d.bestHypo(useInputSymbols=True) == "".join(inlex[i] + " " for i in kept[::-1])
+    assert d.finalStatesN() == ro["finalStatesN"] and d.traceBackSucceeded() == ro["reachedFinal"]
+    # ---- Distrib::score(frameX) / DistribSet::find (distribBasic.h:48-50,183-190) through the feature-stream protocol
+    assert dss.ndists() == K and dss.index("ds7") == 7 and dss.find("ds7").name() == "ds7"
+    with pytest.raises(dsr.DsrError) as e:
+        dss.find("nope")
+    assert e.value.status == 11
+    dss.resetFeature(); dss.resetCache()
+    for t in (0, 1, 2):
+        for k in (0, 7, K - 1):
+            assert dss.find(k).score(t) == so[t, k]                                                  # the same bits the decoder consumed
+    with pytest.raises(dsr.DsrError) as e:
+        dss.find(0).score(9)                                                                         # out of order: jindex_error (feature.cc:1222-1223)
+    assert e.value.status == 6
+    # ---- lattice() behind the same face, against the oracle
+    ro2 = go.decode(so, beam=80.0, lmScale=12.0, silPenalty=0.5, silenceX=4, lattice=True, eosX=1)
+    Ld = d.lattice().data
+    for k in ("nodeFinal", "from", "to", "in", "out", "start", "end"):
+        assert np.array_equal(Ld[k], ro2["lattice"][k]), k
+    assert np.array_equal(Ld["ac"].view(np.int64), ro2["lattice"]["ac"].view(np.int64)) and np.array_equal(Ld["lm"].view(np.int64), ro2["lattice"]["lm"].view(np.int64))
+    # ---- topN (decoder.h:571-581): the 6 best tokens of every list expanded in score order, no beam
+    dn = DecoderFlyWeightPtr(dss, beam=80.0, lmScale=12.0, silPenalty=0.5, topN=6, generateLattice=False); dn.set(wfst)
+    sn = dn.decode()
+    rn = go.decode(so, beam=80.0, lmScale=12.0, silPenalty=0.5, silenceX=4, topN=6)
+    assert rn["rc"] == 0 and sn == rn["score"] and np.array_equal(dn.bestArcs(), rn["arcs"]) and sn != score
+    # ---- the same transducer written with symbols instead of numbers (wfstFlyWeight.cc:311-347) reads to the same graph
+    with open(tmp_path / "gsym.fsm", "w") as f:
+        for a in arcs:
+            f.write("%d %d %s %s %.9g\n" % (a[0], a[1], inlex[a[2]], outlex[a[3]], a[4]))
+        for s_, c in fin:
+            f.write("%d %.9g\n" % (s_, c))
+    w2 = WFSTFlyWeightPtr(LexiconPtr("state"), LexiconPtr("in", str(tmp_path / "in.lex")), LexiconPtr("out", str(tmp_path / "out.lex")))
+    w2.read(str(tmp_path / "gsym.fsm"), binary=False)
+    e1, e2 = wfst._g.export(), w2._g.export()
+    for k in e1:
+        assert np.array_equal(e1[k], e2[k]), k
+    assert w2.hasFinalState() and w2.inputLexicon().symbol(4) == "SIL-m"
+    # an empty utterance: the exception escapes decode() (decoder.h:691)
+    samp.setSamples(np.zeros(10, np.float32), 16000)
+    with pytest.raises(StopIteration):
+        d.decode()
 
 
 def test_python_source_is_refilled_when_a_downstream_operator_resets(dsr, cuda, headset):
