@@ -94,36 +94,78 @@ def tune_beam(dsr, torch, mdl, scores, nfr, target=5000.0):
     return best
 
 
-def cpu_baseline(mdl, x_host, nsamp, beam, max_seconds=25.0):
-    """The oracle (plain C restatement of the reference, 1 thread, -O3 -march=native build when gcc is there) on a
-    bounded sample of the same workload: whole utterances through the same pipe."""
+def cpu_baseline(mdl, x_host, nsamp, beam, max_seconds=12.0, threads=1):
+    """The oracle (plain C restatement of the reference, -O3 -march=native build when gcc is there) on a bounded sample of the same
+    workload: whole utterances through the same pipe.  threads == 1: the reference's own shape (it is single threaded).  threads > 1:
+    utterance-parallel over the host cores -- worker threads inside this process (the oracle is C called through ctypes, which releases
+    the GIL; it keeps no static state), so nothing is forked or exec'ed from a process that holds the GPU."""
+    from concurrent.futures import ThreadPoolExecutor
     from oracle import oracle as O
     try:
         O.lib(native=True); nat = True
     except Exception:
         nat = False
-    L = O.lib(native=nat)
-    go = O.Wfst()
-    for a in mdl["arcs"]:
-        go.add_arc(*a)
-    for s, c in mdl["fin"]:
-        go.add_final(s, c)
+    O.lib(native=nat)
     cb = O.Codebooks(mdl["gm_m"]["refN"], mdl["gm_m"]["mean"], mdl["gm_m"]["ivar"], mdl["gm_m"]["det"])
     W = mdl["bf"].get(4); cfg = O.mfcc_cfg(lda=mdl["lda"])
     h, g, M, m, r, Cn = mdl["h"], mdl["g"], mdl["M"], mdl["m"], mdl["r"], mdl["C"]
-    done, t0, words = 0, time.time(), []
-    for u in range(x_host.shape[0]):
+
+    def graph():
+        go = O.Wfst()
+        for a in mdl["arcs"]:
+            go.add_arc(*a)
+        for s, c in mdl["fin"]:
+            go.add_final(s, c)
+        return go
+    go = graph()                                               # read-only in orc_decode: shared by the worker threads
+    t0 = time.time()
+
+    def one(args):
+        u, k = args
+        if time.time() - t0 > max_seconds:
+            return None
         Xc = np.stack([O.analysis_bank(x_host[u, c, :nsamp], h, M, m, r, 0) for c in range(Cn)])
         y = O.synthesis_bank(O.beamform_apply(Xc, W), g, M, m, r, 0)
         f = O.mfcc_chain(y, cfg)
         sc, _ = O.gmm_score_opt(cb, mdl["gm_m"]["val"], f, native=nat)
-        ro = go.decode(sc, beam=beam, lmScale=12.0)
-        words.append(ro.get("words"))
-        done += 1
-        if time.time() - t0 > max_seconds:
-            break
+        return go.decode(sc, beam=beam, lmScale=12.0).get("words")
+    n = x_host.shape[0]
+    if threads == 1:
+        words = []
+        for u in range(n):
+            w = one((u, 0))
+            if w is None:
+                break
+            words.append(w)
+    else:
+        # thread k takes utterances k, k + threads, ...
+        def lane(k):
+            return [(u, one((u, k))) for u in range(k, n, threads)]
+        with ThreadPoolExecutor(threads) as ex:
+            got = sorted(sum(ex.map(lane, range(threads)), []))
+        words = [w for _, w in got if w is not None]
     dt = time.time() - t0
-    return done, dt, words, nat
+    return len(words), dt, words, nat
+
+
+def cpu_config1():
+    """BASELINE configs[0] (the reference's own CPU-runnable case): the 1-channel recording shipped with the reference (its samples are the
+    committed fixture tests/golden/Headset1_16k_s16.npy) through the MFCC chain of SURVEY.md Appendix C.3 on one host core, oracle build."""
+    from oracle import oracle as O
+    try:
+        O.lib(native=True)
+    except Exception:
+        pass
+    x = np.load(os.path.join(ROOT, "tests", "golden", "Headset1_16k_s16.npy")).astype(np.float32)
+    lda = (np.random.default_rng(1234).standard_normal((39, 195)) / np.sqrt(195)).astype(np.float32)
+    cfg = O.mfcc_cfg(lda=lda)
+    O.mfcc_chain(x, cfg)                                       # warm (page in, tables)
+    reps, t0 = 0, time.time()
+    while time.time() - t0 < 1.5:
+        f = O.mfcc_chain(x, cfg); reps += 1
+    dt = (time.time() - t0) / reps
+    return dict(workload="Headset1.wav (134823 samples, 16 kHz, 1 ch) -> pre-emphasis .. LDA (39-d), 1 core", frames=int(f.shape[0]),
+                frames_per_sec=f.shape[0] / dt, xRT=(len(x) / 16000.0) / dt, ms=1000.0 * dt)
 
 
 def main():
@@ -131,7 +173,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--utts", type=int, default=1000, help="utterances per GPU per step")
+    ap.add_argument("--utts", type=int, default=1000, help="utterances per GPU per step (weak scaling, the default)")
+    ap.add_argument("--total-utts", type=int, default=0, help="strong scaling: this many utterances in all, sharded u -> rank u mod world "
+                    "(BASELINE configs[3]: --total-utts 1000); 0 = weak scaling with --utts per GPU")
+    ap.add_argument("--cpu-threads", type=int, default=0, help="host cores of the N-core CPU baseline leg (0 = all the process may use, at most 16)")
     ap.add_argument("--secs", type=float, default=10.0, help="seconds of audio per utterance")
     ap.add_argument("--states", type=int, default=50000)
     ap.add_argument("--dists", type=int, default=1024)
@@ -155,7 +200,13 @@ def main():
     from tests import synth
     dsr.load()
 
-    U, Cn, nsamp = args.utts, 8, int(args.secs * 16000)
+    from dsr.dist import shard_utterances
+    strong = args.total_utts > 0
+    my_ids = shard_utterances(args.total_utts, world, rank) if strong else list(range(args.utts))
+    U, Cn, nsamp = len(my_ids), 8, int(args.secs * 16000)
+    if U < 1:
+        raise SystemExit("rank %d has no utterance: --total-utts must be at least the number of GPUs" % rank)
+    total_utts = args.total_utts if strong else world * U
     mdl = build_models(dsr, synth, args.dists, args.states)
     x = make_input(torch, dev, U, Cn, nsamp, seed=7 + rank)
     ns_host = np.full(U, nsamp, np.int32); ns_dev = torch.from_numpy(ns_host).to(dev)
@@ -248,7 +299,7 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
     ms_per_step = 1000.0 * dt / args.steps
-    audio_s = world * U * args.secs
+    audio_s = total_utts * args.secs
     hours_per_s = audio_s / 3600.0 / (dt / args.steps)
 
     if rank == 0:
@@ -274,11 +325,14 @@ def main():
         # HBM bytes per launch from the counter passes of this round (profiles/r01_traffic.json: FETCH_SIZE and WRITE_SIZE, separate
         # rocprofv3 --pmc runs of this same workload); only quoted when the workload is the one they were collected on
         try:
-            tj = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
+            tj_path = os.path.join(ROOT, "profiles", "r02_traffic.json")
+            if not os.path.exists(tj_path):
+                tj_path = os.path.join(ROOT, "profiles", "r01_traffic.json")
+            tj = json.load(open(tj_path))
             key = {"viterbi": "k_viterbi", "analysis": "k_analysis_q256", "beamform": "k_bf_apply"}.get(dn)
             if key in tj["kernels"] and U == 1000 and args.secs == 10.0 and args.states == 50000 and abs(beam - 53.787) < 0.01:
                 roof["traffic"] = tj["kernels"][key]["bytes_per_launch"]
-                roof["traffic_note"] = "bytes per launch, PMC FETCH_SIZE + WRITE_SIZE (profiles/r01_traffic.json)"
+                roof["traffic_note"] = "bytes per launch, PMC FETCH_SIZE + WRITE_SIZE (profiles/%s)" % os.path.basename(tj_path)
         except (OSError, ValueError, KeyError):
             pass
         roof["launch_ms"] = stage_ms[dom]
@@ -291,8 +345,14 @@ def main():
                               unit="GB/s" if k == "hbm" else "TFLOP/s")
         cpu = None
         if not args.no_cpu:
-            ncpu = min(6, U)
-            done, cdt, cwords, nat = cpu_baseline(mdl, x[:ncpu].cpu().numpy(), nsamp, beam)
+            try:
+                ncores = len(os.sched_getaffinity(0))
+            except AttributeError:
+                ncores = os.cpu_count() or 1
+            nthr = args.cpu_threads if args.cpu_threads > 0 else min(16, ncores)
+            ncpu = min(24, U)                                           # ~0.35 s per utterance and core: about 8 s single-threaded
+            xh = x[:min(U, max(ncpu, 4 * nthr))].cpu().numpy()         # N-core leg: four utterances per core
+            done, cdt, cwords, nat = cpu_baseline(mdl, xh[:ncpu], nsamp, beam, max_seconds=12.0, threads=1)
             cpu = dict(value=done * args.secs / 3600.0 / cdt, unit="audio_hours_per_sec", cores=1, kind="port",
                        sample="%d whole utterances (%.0f s x 8 ch) through the same pipe, oracle C restatement%s, %.1f s of CPU time"
                               % (done, args.secs, " -O3 -march=native" if nat else "", cdt),
@@ -300,13 +360,22 @@ def main():
             # the same utterances decoded on the GPU give the same word sequences? (front end differs by fp32 rounding)
             agree = sum(1 for u in range(done) if cwords[u] is not None and np.array_equal(cwords[u], words[u, :res[u].nWords]))
             cpu["one_best_agree"] = "%d/%d" % (agree, done)
+            # N-core leg: utterance-parallel over the host cores this process may use, one utterance per core
+            if nthr > 1 and xh.shape[0] >= 2:
+                nd, ndt, _, _ = cpu_baseline(mdl, xh, nsamp, beam, max_seconds=12.0, threads=min(nthr, xh.shape[0]))
+                cpu["n_core"] = dict(value=nd * args.secs / 3600.0 / ndt, unit="audio_hours_per_sec", cores=min(nthr, xh.shape[0]), host_cores=ncores,
+                                     xRT=nd * args.secs / ndt, sample="%d utterances over %d worker threads (oracle C code, GIL released), %.1f s wall" % (nd, min(nthr, xh.shape[0]), ndt))
+            cpu["config1"] = cpu_config1()
         line = dict(metric="decoded_audio_hours_per_sec", value=hours_per_s, unit="audio_hours/s", n_gpus=world, steps=args.steps,
-                    warmup=args.warmup, ms_per_step=ms_per_step, higher_is_better=True, scaling="weak", vs_baseline=None,
+                    warmup=args.warmup, ms_per_step=ms_per_step, higher_is_better=True, scaling="strong" if strong else "weak", vs_baseline=None,
                     dtype="f32", data="synthetic",
                     config=dict(workload="full pipe: %d utt/GPU x %.0f s x 8 ch, analysis M=256 m=4 r=1 -> MVDR -> synthesis -> MFCC(39) -> "
                                          "GMM %d dists x %d Gaussians -> WFST %d states/%d arcs, lmScale 12, beam %.1f"
                                          % (U, args.secs, args.dists, 4096 // args.dists, args.states, mdl["nArcs"], beam),
-                                utts_per_gpu=U, xRT=audio_s / (dt / args.steps), beam=beam,
+                                utts_per_gpu=U, total_utts=total_utts,
+                                scaling_mode=("strong: --total-utts %d sharded u -> rank u mod %d (BASELINE configs[3])" % (total_utts, world)) if strong
+                                else "weak: %d utterances per GPU (at 1 GPU this is BASELINE configs[3]'s 1k-utterance batch)" % U,
+                                xRT=audio_s / (dt / args.steps), beam=beam,
                                 mean_active_tokens=active / max(1, frames), failed_utts=bad, gmm_mode=args.gmm_mode,
                                 parallelism="utterance-sharded x%d, RCCL gather of 1-best" % world,
                                 step_overlap="two pipes on two streams (decode tail of a step under the next step's front end)" if npipes > 1 else "none"),
