@@ -211,9 +211,31 @@ dsr_status dsr_gmm_load(const char* cbFile, const char* dsFile, dsr_gmm** out)
     FILE* fp = fopen(cbFile, "rb"); if (!fp) { delete m; throw Error(DSR_E_IO, "Could not open codebook file %s.", cbFile); }
     try {
       BE r{fp};
-      if (r.i32() != 64207531) throw Error(DSR_E_IO, "codebook file %s: only the CodebookMagic format is supported", cbFile);   // codebookBasic.cc:921-933
-      const int cb0 = r.i32(), cbN = r.i32(); m->K = cbN - cb0;
-      for (int k = 0; k < m->K; k++) {
+      const int first = r.i32();
+      if (first != 64207531) {
+        // the older (Janus) set format (CodebookSetBasic::load :934-957, CodebookBasic::loadOld :311-350; written by save(fp, janusFormat = true)
+        // :352-383,962-983): codebook count, then per codebook name, refN, dimN, covariance type -- -1 = a count and a type per Gaussian -- and per
+        // Gaussian [count] mean [type] inverse variances + determinant; no marker.  A negative count is the compressed mode the reference refuses.
+        int cbN = first;
+        if (cbN < 0) throw Error(DSR_E_IO, "Mode not supported.");
+        m->K = cbN;
+        for (int k = 0; k < m->K; k++) {
+          m->cbNames.push_back(r.str());
+          const int refN = r.i32(), dimN = r.i32(), lcov = r.i32();
+          if (k == 0) m->D = dimN; else if (dimN != m->D) throw Error(DSR_E_DIMENSION, "codebooks of different dimension (%d vs %d)", dimN, m->D);
+          m->refN.push_back(refN);
+          for (int i = 0; i < refN; i++) {
+            m->count.push_back(lcov == -1 ? r.f32() : 0.0f);
+            for (int d = 0; d < dimN; d++) m->mean.push_back(r.f32());
+            const int thisCov = lcov == -1 ? r.i32() : lcov;
+            if (thisCov != 2 /*COV_DIAGONAL*/) throw Error(DSR_E_IO, "Wrong covariance type.");
+            for (int d = 0; d < dimN; d++) m->ivar.push_back(r.f32());
+            m->det.push_back(r.f32());
+          }
+        }
+      }
+      const int cb0 = first == 64207531 ? r.i32() : 0, cbN = first == 64207531 ? r.i32() : 0; if (first == 64207531) m->K = cbN - cb0;
+      for (int k = 0; first == 64207531 && k < m->K; k++) {
         m->cbNames.push_back(r.str());                               // CodebookBasic::load :258-309
         const int refN = r.i32(), dimN = r.i32(), orgDimN = r.i32(), nSub = r.i32(); (void) r.i32();
         const int regP = r.i32(), descP = r.i32();
@@ -249,6 +271,28 @@ dsr_status dsr_gmm_load(const char* cbFile, const char* dsFile, dsr_gmm** out)
   });
 }
 
+// CodebookSetBasic::save(filename, janusFormat = true) (codebookBasic.cc:352-383,962-983): count, then name, refN, dimN, covariance type and per
+// Gaussian mean, inverse variances, determinant -- no magic, no counts, no marker; the distribution file is the same in both formats
+dsr_status dsr_gmm_save(const dsr_gmm* m, const char* cbFile, const char* dsFile);
+dsr_status dsr_gmm_save_janus(const dsr_gmm* m, const char* cbFile, const char* dsFile)
+{
+  return guard([&] {
+    if (!m || !cbFile) throw Error(DSR_E_PARAMETER, "null argument");
+    FILE* fp = fopen(cbFile, "wb"); if (!fp) throw Error(DSR_E_IO, "Could not open codebook file %s.", cbFile);
+    BE w{fp};
+    w.w32(m->K);
+    for (int k = 0; k < m->K; k++) {
+      w.wstr(m->cbNames[k]); w.w32(m->refN[k]); w.w32(m->D); w.w32(2 /*COV_DIAGONAL*/);
+      for (int g = m->off[k]; g < m->off[k + 1]; g++) {
+        for (int d = 0; d < m->D; d++) w.wf(m->mean[(size_t) g * m->D + d]);
+        for (int d = 0; d < m->D; d++) w.wf(m->ivar[(size_t) g * m->D + d]);
+        w.wf(m->det[g]);
+      }
+    }
+    fclose(fp);
+    if (dsFile && *dsFile) { const dsr_status s = dsr_gmm_save(m, "/dev/null", dsFile); if (s) throw Error(s, "%s", dsr_last_error()); }
+  });
+}
 dsr_status dsr_gmm_save(const dsr_gmm* m, const char* cbFile, const char* dsFile)
 {
   return guard([&] {

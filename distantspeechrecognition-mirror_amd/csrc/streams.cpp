@@ -614,6 +614,59 @@ dsr_status dsr_linear_transform_set(dsr_stream* s, const float* matrix)
   });
 }
 
+// LinearTransformFeature::load(fileName, old) (feature.cc:2972-2976): gsl_matrix_float_load into the operator's (size x srcSize) matrix, then the
+// crop to (size x srcSize) -- which only ever shrinks (gslmatrix.cc:6-15), so a Janus file must carry exactly that shape.
+dsr_status dsr_linear_transform_load(dsr_stream* s, const char* fileName, int old)
+{
+  return guard([&] {
+    GemvOp* q = dynamic_cast<GemvOp*>(s); if (!q || !fileName) throw Error(DSR_E_PARAMETER, "not a linear transform");
+    const int rows = q->size_, cols = q->ups[0]->size_;
+    std::vector<float> m((size_t) rows * cols, 0.0f); int r2 = 0, c2 = 0;
+    const dsr_status st = dsr_fmat_load(fileName, old, rows, cols, m.data(), &r2, &c2); if (st) throw Error(st, "%s", dsr_last_error());
+    if (r2 < rows) throw Error(DSR_E_DIMENSION, "Cannot resize from %d to %d", r2, rows);           // the crop back to (size x srcSize)
+    if (c2 < cols) throw Error(DSR_E_DIMENSION, "Cannot resize from %d to %d", c2, cols);
+    q->hA = m; q->A.upload(q->hA); q->ready = false;
+  });
+}
+// StorageFeature::write(fileName, plainText) / read(fileName) (feature.cc:3025-3067), quirks kept: the count that is written is _frameX -- the
+// index of the last frame, one less than the number of frames that follow it; read() takes that number for _frameX and reads that many frames,
+// i.e. one fewer than the file holds.  Binary: big-endian ints (write_int) and native-endian float blocks (gsl_vector_float_fwrite).
+dsr_status dsr_storage_write(dsr_stream* s, const char* fileName, int plainText)
+{
+  return guard([&] {
+    StorageOp* q = dynamic_cast<StorageOp*>(s); if (!q || !fileName) throw Error(DSR_E_PARAMETER, "not a StorageFeature");
+    if (q->frameX <= 0) throw Error(DSR_E_IO, "Frame count must be > 0.\n");
+    FILE* fp = fopen(fileName, "w"); if (!fp) throw Error(DSR_E_IO, "Could not open file %s", fileName);
+    const int sz = q->size_;
+    auto wbe = [&](int v) { const unsigned u = (unsigned) v; const unsigned char b[4] = { (unsigned char) (u >> 24), (unsigned char) (u >> 16), (unsigned char) (u >> 8), (unsigned char) u }; fwrite(b, 1, 4, fp); };
+    if (plainText) {
+      fprintf(fp, "%d %d\n", q->frameX, sz);
+      for (int i = 0; i <= q->frameX; i++) { const float* r = (const float*) q->row(i); for (int j = 0; j < sz; j++) { fprintf(fp, "%g", (double) r[j]); if (j < sz - 1) fprintf(fp, " "); } fprintf(fp, "\n"); }
+    } else {
+      wbe(q->frameX); wbe(sz);
+      for (int i = 0; i <= q->frameX; i++) fwrite(q->row(i), sizeof(float), (size_t) sz, fp);
+    }
+    fclose(fp);
+  });
+}
+dsr_status dsr_storage_read(dsr_stream* s, const char* fileName)
+{
+  return guard([&] {
+    StorageOp* q = dynamic_cast<StorageOp*>(s); if (!q || !fileName) throw Error(DSR_E_PARAMETER, "not a StorageFeature");
+    FILE* fp = fopen(fileName, "r"); if (!fp) throw Error(DSR_E_IO, "Could not open file %s", fileName);
+    auto rbe = [&](int& v) { unsigned char b[4]; if (fread(b, 1, 4, fp) != 4) { fclose(fp); throw Error(DSR_E_IO, "premature end of %s", fileName); } v = (int) ((unsigned) b[0] << 24 | (unsigned) b[1] << 16 | (unsigned) b[2] << 8 | (unsigned) b[3]); };
+    int fx = 0, sz = 0; rbe(fx); rbe(sz);
+    if (sz != q->size_) { fclose(fp); throw Error(DSR_E_DIMENSION, "Feature dimensions (%d vs. %d) do not match.\n", sz, q->size_); }
+    if (fx < 0 || fx >= 100000) { fclose(fp); throw Error(DSR_E_DIMENSION, "Frame %d is greater than maximum number %d.", fx, 100000); }
+    // the operator now serves frames 0.._frameX from its own store: frames 0.._frameX-1 from the file, frame _frameX as the store had it (zero)
+    q->nFrames = fx + 1; q->host.assign((size_t) q->nFrames * q->rowBytes() + 16, 0);
+    for (int i = 0; i < fx; i++) if (fread(q->host.data() + (size_t) i * q->rowBytes(), sizeof(float), (size_t) sz, fp) != (size_t) sz) { fclose(fp); throw Error(DSR_E_IO, "premature end of %s", fileName); }
+    fclose(fp);
+    require_device(); q->dev.reserve(q->host.size()); DSR_HIP(hipMemcpy(q->dev.p, q->host.data(), (size_t) q->nFrames * q->rowBytes(), hipMemcpyHostToDevice));
+    q->ready = true; q->frameX = fx; q->endOfSamples = false;
+  });
+}
+
 // ---------------------------------------------------------------------------------------------------------------------------------
 // ASR side of the boundary: the distribution set as the decoder sees it.  The reference decoder asks _dist->find(distX-1)->score(_frameX)
 // (asr/decoder/decoder.h:985); Distrib::score -> CodebookBasic::score pulls frame frameX of the feature stream and caches the codebook's

@@ -134,6 +134,14 @@ class StorageFeaturePtr(_unary(lambda *a: lib().dsr_storage_create(*a), "Storage
             pass
         return n - 1
 
+    def write(self, fileName, plainText=False):
+        """StorageFeature::write (feature.cc:3025-3050)"""
+        K.check(lib().dsr_storage_write(self._h, fileName.encode(), int(bool(plainText))))
+
+    def read(self, fileName):
+        """StorageFeature::read (feature.cc:3052-3066)"""
+        K.check(lib().dsr_storage_read(self._h, fileName.encode()))
+
 
 class MeanSubtractionFeaturePtr(_unary(lambda *a: lib().dsr_mean_subtraction_create(*a), "Mean Subtraction")):
     def _args(self, src, weight=None, devNormFactor=0.0, runon=False):
@@ -163,15 +171,9 @@ class LinearTransformFeaturePtr(_unary(lambda *a: lib().dsr_linear_transform_cre
         self.setMatrix(np.eye(self._shape[0], dtype=np.float32))
 
     def load(self, fileName, old=False):
-        """GSL raw float matrix (native endian) or Janus 'FMAT' big-endian file (btk/matrix/gslmatrix.cc:27-96)."""
-        raw = open(fileName, "rb").read()
-        if raw[:4] == b"FMAT":
-            rows, cols = int.from_bytes(raw[4:8], "big"), int.from_bytes(raw[8:12], "big")
-            a = np.frombuffer(raw[16:16 + 4 * rows * cols], dtype=">f4").reshape(rows, cols).astype(np.float32)
-        else:
-            a = np.frombuffer(raw, dtype=np.float32)
-            a = a[: (a.size // self._shape[1]) * self._shape[1]].reshape(-1, self._shape[1])
-        self.setMatrix(a[: self._shape[0], : self._shape[1]])
+        """LinearTransformFeature::load(fileName, old) (feature.cc:2972-2976): GSL raw float block or Janus 'FMAT' file (gslmatrix.cc:27-96),
+        with the reference's error branches (dsr_linear_transform_load)"""
+        K.check(lib().dsr_linear_transform_load(self._h, fileName.encode(), int(bool(old))))
 
 
 class FeatureSetPtr(object):

@@ -219,6 +219,10 @@ dsr_status dsr_gmm_create(int K, int dimN, const int32_t* refN, const float* mea
 /* big-endian model files written by CodebookSetBasic::save / DistribSetBasic::save */
 dsr_status dsr_gmm_load(const char* codebookFile, const char* distribFile, dsr_gmm** out);
 dsr_status dsr_gmm_save(const dsr_gmm*, const char* codebookFile, const char* distribFile);
+/* the older (Janus) codebook-set format: dsr_gmm_load reads it when the file does not start with CodebookMagic (CodebookSetBasic::load
+   :934-957 -> CodebookBasic::loadOld :311-350; a uniform covariance type or, with -1, a count and a type per Gaussian; "Wrong covariance type."
+   for anything but diagonal; the compressed mode is refused as in the reference).  save_janus = save(filename, janusFormat = true) (:352-383,962-983). */
+dsr_status dsr_gmm_save_janus(const dsr_gmm*, const char* codebookFile, const char* distribFile /* may be NULL */);
 void       dsr_gmm_destroy(dsr_gmm*);
 int dsr_gmm_num_dists(const dsr_gmm*);
 int dsr_gmm_dim(const dsr_gmm*);
@@ -560,6 +564,29 @@ dsr_status dsr_mean_subtraction_create(dsr_stream* src, double devNormFactor, in
 dsr_status dsr_adjacent_create(dsr_stream* single, int delta, const char* name, dsr_stream** out);
 dsr_status dsr_linear_transform_create(dsr_stream* src, int sz, const char* name, dsr_stream** out);
 dsr_status dsr_linear_transform_set(dsr_stream*, const float* matrix /*[sz][srcSize]*/);
+/* LinearTransformFeature::load(fileName, old) (feature.cc:2972-2976): gsl_matrix_float_load + the crop to (size x srcSize) */
+dsr_status dsr_linear_transform_load(dsr_stream*, const char* fileName, int old);
+/* StorageFeature::write(fileName, plainText) / read(fileName) (feature.cc:3025-3067), quirks kept (the count written is the index of the last
+   frame; read() loads that many frames, one fewer than the file holds) */
+dsr_status dsr_storage_write(dsr_stream*, const char* fileName, int plainText);
+dsr_status dsr_storage_read(dsr_stream*, const char* fileName);
+
+/* On-disk formats either side of the path, host side.
+ * gsl_matrix_float_load / gsl_vector_float_load(m, fileName, old) (btk/matrix/gslmatrix.cc:27-96,133-240) into a caller matrix of rows x cols:
+ *   old == 0: the GSL raw block (rows*cols native-endian floats); old != 0: Janus "FMAT"/"FVEC" (magic, big-endian sizes, a count that is
+ *   skipped, big-endian floats; rows < 0 = derived from the file length).  Errors as the reference raises them: DSR_E_IO "Couldn't find magic
+ *   number", "File empty", "Number of bytes in file = don't match matrix dimension"; DSR_E_DIMENSION "Cannot resize" when the file's matrix is
+ *   larger than the caller's.  *rowsOut x *colsOut: the matrix size after the load (the file's, for old != 0). */
+dsr_status dsr_fmat_load(const char* fileName, int old, int rows, int cols, float* data, int* rowsOut, int* colsOut);
+dsr_status dsr_fmat_save(const char* fileName, int old, int rows, int cols, const float* data, int rowsUnset);
+dsr_status dsr_fvec_load(const char* fileName, int old, int n, float* data, int* nOut);
+dsr_status dsr_fvec_save(const char* fileName, int old, int n, const float* data);
+/* HTK parameter files (btk/feature/feature.cc:4025-4318: ReadHTKHeader / WriteHTKHeader / ReadFloatBinary / WriteFloatBinary,
+ * WriteHTKFeatureFile, HTKFeature): 12-byte header + float vectors of sampSize bytes.  isBigEndian is the reference's flag ("the machine is big
+ * endian"): when 0 every field is byte-swapped, which gives the big-endian files HTK expects.  Compressed (_C) and CRC (_K) kinds: DSR_E_IO. */
+dsr_status dsr_htk_write(const char* fileName, int nSamples, int sampPeriod, int sampSize, int parmKind, int isBigEndian, const float* data);
+dsr_status dsr_htk_read_header(const char* fileName, int isBigEndian, int* nSamples, int* sampPeriod, int* sampSize, int* parmKind);
+dsr_status dsr_htk_read(const char* fileName, int isBigEndian, float* data, size_t nFloats);
 
 /* =====================================================================================
  * 8. The distribution set as the decoder sees it

@@ -283,3 +283,79 @@ def test_python_source_is_refilled_when_a_downstream_operator_resets(dsr, cuda, 
     ham2.reset()
     with pytest.raises((RuntimeError, dsr.DsrError)):           # JPYTHON surfaces (jexception.i:181-183), never stale frames
         ham2.next()
+
+
+def test_legacy_formats_behind_the_operators(dsr, oracle, cuda, headset, tmp_path):
+    """SURVEY.md 8f rank 4 / row a22: StorageFeature::write/read (feature.cc:3025-3067, quirks kept), LinearTransformFeature::load with GSL and Janus FMAT
+    files (feature.cc:2972-2976, gslmatrix.cc:27-96), the older Janus codebook-set format (codebookBasic.cc:311-350,934-957)."""
+    import struct
+    import torch
+    from dsr.btk.feature import (SampleFeaturePtr, HammingFeaturePtr, FFTFeaturePtr, SpectralPowerFeaturePtr, MelFeaturePtr, LogFeaturePtr,
+                                 CepstralFeaturePtr, StorageFeaturePtr, LinearTransformFeaturePtr)
+    samp = SampleFeaturePtr(blockLen=320, shiftLen=160)
+    cep = CepstralFeaturePtr(LogFeaturePtr(MelFeaturePtr(SpectralPowerFeaturePtr(FFTFeaturePtr(HammingFeaturePtr(samp), fftLen=512), powN=257),
+                                                        powN=257, filterN=30)), ncep=13)
+    st = StorageFeaturePtr(cep)
+    samp.setSamples(headset[9000:9000 + 160 * 30], 16000)
+    last = st.evaluate(); assert last == st.frameX() and last >= 20
+    rows = np.stack([np.array(st.next(t)) for t in range(last + 1)])
+    # binary: big-endian _frameX (the LAST INDEX, not the count) and size, then the frames 0.._frameX as native float blocks
+    st.write(str(tmp_path / "s.bin"))
+    assert open(tmp_path / "s.bin", "rb").read() == struct.pack(">ii", last, 13) + rows.tobytes()
+    st.write(str(tmp_path / "s.txt"), plainText=True)
+    txt = open(tmp_path / "s.txt").read().splitlines()
+    assert txt[0] == "%d %d" % (last, 13) and len(txt) == last + 2 and txt[1] == " ".join("%g" % v for v in rows[0])
+    # read(): _frameX = the number in the file; that many frames are read (one fewer than were written); the rest of the store is as it was
+    st2 = StorageFeaturePtr(CepstralFeaturePtr(LogFeaturePtr(MelFeaturePtr(SpectralPowerFeaturePtr(FFTFeaturePtr(HammingFeaturePtr(SampleFeaturePtr(blockLen=320, shiftLen=160)), fftLen=512),
+                                                                                              powN=257), powN=257, filterN=30)), ncep=13))
+    st2.read(str(tmp_path / "s.bin"))
+    assert st2.frameX() == last
+    got = np.stack([np.array(st2.next(t)) for t in range(last + 1)])
+    assert np.array_equal(got[:last], rows[:last]) and np.all(got[last] == 0)
+    open(tmp_path / "bad.bin", "wb").write(struct.pack(">ii", 3, 12) + b"\0" * 200)
+    with pytest.raises(dsr.DsrError) as e:
+        st2.read(str(tmp_path / "bad.bin"))
+    assert e.value.status == 5                                            # "Feature dimensions (12 vs. 13) do not match."
+    # LinearTransformFeature::load
+    lt = LinearTransformFeaturePtr(st, 5)
+    A = np.random.default_rng(3).standard_normal((5, 13)).astype(np.float32)
+    open(tmp_path / "a.gsl", "wb").write(A.tobytes())
+    open(tmp_path / "a.fmat", "wb").write(b"FMAT" + struct.pack(">ii", -1, 13) + struct.pack(">f", 0.0) + A.astype(">f4").tobytes())
+    for fn, old in (("a.gsl", False), ("a.fmat", True)):
+        lt.load(str(tmp_path / fn), old); lt.reset()
+        y = np.stack([np.array(v) for v in lt])
+        assert np.abs(y - oracle.sgemv_rows(A, rows)).max() < 1e-4
+    open(tmp_path / "small.fmat", "wb").write(b"FMAT" + struct.pack(">ii", 4, 13) + struct.pack(">f", 0.0) + A[:4].astype(">f4").tobytes())
+    with pytest.raises(dsr.DsrError) as e:
+        lt.load(str(tmp_path / "small.fmat"), True)                       # the crop back to 5 x 13 cannot grow the matrix (gslmatrix.cc:6-15)
+    assert e.value.status == 5
+    # the older Janus codebook-set format: written by save(janusFormat = true), read when the file does not start with CodebookMagic
+    import ctypes as C
+    m = synth.gmm_model(6, 4, 13, seed=9); g = dsr.Gmm(**m)
+    cbj, dsf, cbn = str(tmp_path / "cb.janus"), str(tmp_path / "ds.bin"), str(tmp_path / "cb.new")
+    dsr.check(dsr.load().dsr_gmm_save_janus(g.h, cbj.encode(), dsf.encode())); g.save(cbn, dsf)
+    be = lambda a: np.asarray(a, np.float32).astype(">f4").tobytes()
+    exp = struct.pack(">i", 6)
+    for k in range(6):
+        nm = ("cb%d" % k).encode()
+        exp += struct.pack(">h", len(nm)) + nm + b"\0" + struct.pack(">iii", 4, 13, 2)
+        for j in range(4 * k, 4 * k + 4):
+            exp += be(m["mean"][j]) + be(m["ivar"][j]) + be(m["det"][j])
+    assert open(cbj, "rb").read() == exp
+    g2 = dsr.Gmm(files=(cbj, dsf)); g3 = dsr.Gmm(files=(cbn, dsf))
+    x = torch.from_numpy(np.random.default_rng(4).standard_normal((50, 13)).astype(np.float32)).to(cuda)
+    assert torch.equal(g2.score(x)[0], g3.score(x)[0]) and torch.equal(g2.score(x)[0], g.score(x)[0])
+    # per-Gaussian counts and types (uniform type -1), and the reference's refusals
+    var = struct.pack(">i", 1) + struct.pack(">h", 3) + b"cb0\0" + struct.pack(">iii", 4, 13, -1)
+    for j in range(4):
+        var += be([7.0]) + be(m["mean"][j]) + struct.pack(">i", 2) + be(m["ivar"][j]) + be(m["det"][j])
+    open(tmp_path / "cb.var", "wb").write(var)
+    one = dsr.Gmm(refN=[4], mean=m["mean"][:4], ivar=m["ivar"][:4], det=m["det"][:4], val=m["val"][:4]); one.save(str(tmp_path / "x.cb"), str(tmp_path / "one.ds"))
+    g4 = dsr.Gmm(files=(str(tmp_path / "cb.var"), str(tmp_path / "one.ds")))
+    assert torch.equal(g4.score(x)[0], one.score(x)[0])
+    open(tmp_path / "cb.full", "wb").write(var.replace(struct.pack(">i", 2), struct.pack(">i", 3), 1))      # a full covariance: "Wrong covariance type."
+    open(tmp_path / "cb.comp", "wb").write(struct.pack(">i", -1) + var[4:])                                 # compressed mode: "Mode not supported."
+    for fn in ("cb.full", "cb.comp"):
+        with pytest.raises(dsr.DsrError) as e:
+            dsr.Gmm(files=(str(tmp_path / fn), str(tmp_path / "one.ds")))
+        assert e.value.status == 8
