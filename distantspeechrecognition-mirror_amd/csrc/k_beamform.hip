@@ -101,8 +101,11 @@ static void update_wl(BfState& s, int f)          // calcSidelobeCancellerP_f / 
 
 static void refresh_effective(BfState& s)
 {
-  const int M = s.M, C = s.C, F = M / 2 + 1;
-  if (s.halfBandShift) throw Error(DSR_E_PARAMETER, "halfBandShift==true apply is not supported on the device path");
+  const int M = s.M, C = s.C;
+  // halfBandShift == true: every one of the M bins is computed on its own -- no mirror, no special bin 0 (SubbandDS::next beamformer.cc:1159-1175,
+  // SubbandGSC::next :1321-1330); the snapshots then carry all M bins, [U][C][Tmax][M].  SubbandMVDR refuses the flag at construction (:2324-2327).
+  const int F = s.halfBandShift ? M : M / 2 + 1;
+  if (s.halfBandShift && (s.mode == 1 || s.mode == 4)) throw Error(DSR_E_ALLOCATION, "halfBandShift==true is not yet supported");
   s.eff.assign((size_t) F * C, zc(0, 0));
   if (s.mode == 0) {
     if (!s.haveWq) throw Error(DSR_E_ERROR, "call calcArrayManifoldVectorsX() once");          // beamformer.cc:1140-1143
@@ -118,8 +121,8 @@ static void refresh_effective(BfState& s)
   } else {
     if (!s.haveWq || !s.haveB) throw Error(DSR_E_ERROR, "call calcGSCWeightsX() once");          // :1310-1313
     const int bs = C - 1;
-    for (int c = 0; c < C; c++) s.eff[c] = s.wq[c];                                              // bin 0: wq only (:1335-1338)
-    for (int f = 1; f < F; f++) {
+    if (!s.halfBandShift) for (int c = 0; c < C; c++) s.eff[c] = s.wq[c];                       // bin 0: wq only (:1335-1338)
+    for (int f = s.halfBandShift ? 0 : 1; f < F; f++) {
       double nrm = 0;
       for (int i = 0; i < C; i++) {
         zc wl(0, 0); for (int j = 0; j < bs; j++) wl += s.B[((size_t) f * C + i) * bs + j] * s.wa[(size_t) f * bs + j];
@@ -326,6 +329,8 @@ dsr_status dsr_bf_create(int fftLen, int chanN, int halfBandShift, dsr_bf** out)
 void dsr_bf_destroy(dsr_bf* s) { delete s; }
 int dsr_bf_fft_len(const dsr_bf* s) { return s->M; }
 int dsr_bf_chan_n(const dsr_bf* s) { return s->C; }
+int dsr_bf_half_band_shift(const dsr_bf* s) { return s->halfBandShift ? 1 : 0; }
+int dsr_bf_bins(const dsr_bf* s) { return s->halfBandShift ? s->M : s->M / 2 + 1; }
 
 dsr_status dsr_bf_calc_array_manifold(dsr_bf* s, double fs, const double* delays)
 { return guard([&] { if (!s || !delays) throw Error(DSR_E_PARAMETER, "null argument"); calc_mainlobe(*s, fs, delays); }); }
@@ -483,7 +488,7 @@ dsr_status dsr_bf_apply(dsr_bf* s, const float* X, int U, int Tmax, float* Y, vo
     if (s->rlsOn) { gsc_rls_apply(*s, X, nullptr, U, Tmax, Y, nullptr, (hipStream_t) stream); return; }
     if (s->dirty) refresh_effective(*s);
     if (U <= 0 || Tmax <= 0) return;
-    const int F = s->M / 2 + 1; const long perUtt = (long) Tmax * F;
+    const int F = s->halfBandShift ? s->M : s->M / 2 + 1; const long perUtt = (long) Tmax * F;
     const size_t lds = sizeof(float2) * (size_t) F * s->C;
     if (lds > 160 * 1024) throw Error(DSR_E_DIMENSION, "beamformer weights need %zu bytes of LDS", lds);
     DSR_HIP(hipFuncSetAttribute((const void*) k_bf_apply, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));

@@ -13,6 +13,7 @@
 // (mu-x)^2*iv accumulation by ~1e-6 relative -- this mode carries the stated GMM tolerance (rel 1e-5), argmin equal to
 // mode 0 except when the two best distances are closer than that.  Mode 0 stays the bit-exact path.
 #include "common.h"
+#include <algorithm>
 #include <cmath>
 #include <string>
 
@@ -167,11 +168,202 @@ __global__ __launch_bounds__(256) void k_gmm_mfma(const float* __restrict__ x, l
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Candidate search in the accumulator layout (codebooks of R = 4, 8, 16 or 32 Gaussians, all the same size).
+// v_mfma_f32_32x32x2_f32 leaves, in lane l, column (frame) l % 32 and the sixteen rows (Gaussians) 8 (i / 4) + 4 (l / 32) + i % 4, i = 0..15:
+//   R = 4 : the four registers acc[4q .. 4q+3] ARE one codebook (number 2q + l/32 of the chunk's eight): minimum, second minimum and their
+//           indices are found with a dozen vector instructions per codebook, no LDS tile, no cross-lane traffic;
+//   R >= 8: a codebook's rows are split evenly between the lane and its partner l ^ 32; each finds the two best of its R/2 registers and one
+//           exchange merges them -- ties go to the smaller Gaussian index, as the reference's strict '<' in file order.
+// Near ties (the two best closer than 1e-4 relative: the expanded form cannot order them) are NOT settled inside this kernel: a call -- or
+// even an inlined 2 x 39-step exact loop -- in the middle of the contraction costs more than the contraction (80 live operand registers
+// around every call: measured 24 ms of 33).  The lane appends (frame, codebook, the two candidates) to a list in memory and moves on;
+// k_gmm_ties settles the list afterwards in the reference's own arithmetic, one thread per entry, and overwrites score and argmin.  A list that
+// is full sends the lane through the exact computation on the spot (cold code, never reached at the list size the launcher picks).
+// Scores wait in an LDS strip [frame][64 codebooks] (pitch 65: conflict free) and leave as 128-byte runs.  One wave owns two 32-frame tiles (B
+// fragments in registers); the Gaussian operand is read from LDS four contraction steps at a time (one ds_read_b128 per four MFMA pairs).
+__device__ __forceinline__ float exact_dist_inl(const float* __restrict__ xr, const float* __restrict__ mu, const float* __restrict__ iv, float cst, int D)
+{
+  float d = cst;
+  for (int i = 0; i < D; i++) { const float df = __fsub_rn(mu[i], xr[i]); d = __fadd_rn(d, __fmul_rn(__fmul_rn(df, df), iv[i])); }
+  return d;
+}
+// (the list is cut into one segment per workgroup of the contraction kernel, filled through a counter in that workgroup's LDS: a single
+// counter in memory serialises a million atomics at one L2 channel -- measured 8 ms)
+__global__ void k_gmm_ties(const unsigned long long* __restrict__ list, const unsigned* __restrict__ counts, unsigned cap, const float* __restrict__ x, int D, int Dp,
+                           int K, int R, const float* __restrict__ mean, const float* __restrict__ ivar, const float* __restrict__ cst, const float* __restrict__ val,
+                           const float* __restrict__ scale, float* __restrict__ score, unsigned char* __restrict__ argmin)
+{
+  unsigned cnt = counts[blockIdx.x]; if (cnt > cap) cnt = cap;
+  for (unsigned i = threadIdx.x; i < cnt; i += blockDim.x) {
+    const unsigned long long e = list[(size_t) blockIdx.x * cap + i];
+    const long n = (long) (e >> 32); const int k = (int) ((e >> 16) & 0xFFFFu), a1 = (int) ((e >> 8) & 0xFFu), a2 = (int) (e & 0xFFu);
+    const int cb = k * R; const float* xr = x + n * D;
+    const float e1 = exact_dist_inl(xr, mean + (size_t) (cb + a1) * Dp, ivar + (size_t) (cb + a1) * Dp, cst[cb + a1], D);
+    const float e2 = exact_dist_inl(xr, mean + (size_t) (cb + a2) * Dp, ivar + (size_t) (cb + a2) * Dp, cst[cb + a2], D);
+    float best; int ba;
+    if (e2 < e1 || (e2 == e1 && a2 < a1)) { best = e2; ba = a2; } else { best = e1; ba = a1; }
+    float sc = 0.5f * (best + 2.0f * val[cb + ba]);
+    const float sl = scale[k]; if (sl != 1.0f) sc *= sl;
+    score[n * K + k] = sc; if (argmin) argmin[n * K + k] = (unsigned char) ba;
+  }
+}
+
+// Every wavefront runs on its own: 64 frames (two MFMA column tiles, B fragments in registers), the Gaussian operand straight from memory
+// (it is 1.3 MB and lives in L2; one fully coalesced 16-byte load per lane feeds four MFMA pairs; the next chunk's loads are in flight during
+// this chunk's MFMAs), a wave-private LDS strip for the scores.  No workgroup barrier inside the contraction.
+template <int S4, int R>   // S4 = KP/8: contraction steps in groups of four
+__global__ __launch_bounds__(256) void k_gmm_mfma_reg(const float* __restrict__ x, long N, int D, int Dp, int K, int G, int nChunks,
+                                                      const float* __restrict__ Apack, const float* __restrict__ mean, const float* __restrict__ ivar,
+                                                      const float* __restrict__ cst, const float* __restrict__ val, const float* __restrict__ scale, int unitScale,
+                                                      float* __restrict__ score, unsigned char* __restrict__ argmin,
+                                                      unsigned long long* __restrict__ tieList, unsigned* __restrict__ tieCount, unsigned tieCap, int valInLds, int dbg)
+{
+  constexpr int S2 = 4 * S4;
+  constexpr int CPC = 32 / R;                                    // codebooks per 32-row chunk
+  constexpr int SCP = 33;                                        // pitch of a strip row: 32 staged codebooks + 1
+  constexpr int FLUSH = 32 / CPC;                                // chunks between flushes: 32 codebooks staged
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  float* valL = reinterpret_cast<float*>(smem);                  // [G] -log w of every Gaussian (when it fits)
+  float* sbuf = valL + (valInLds ? ((G + 3) & ~3) : 0) + wave * (64 * SCP);      // this wave's [64 frames][SCP]
+  unsigned char* abuf = reinterpret_cast<unsigned char*>(valL + (valInLds ? ((G + 3) & ~3) : 0) + 4 * 64 * SCP) + wave * (64 * 32);   // [64][32]
+  const long n0 = (long) blockIdx.x * FT + 64 * wave;            // first frame of this wave
+  const int col = lane & 31, kh = lane >> 5;
+  __shared__ unsigned s_tie;
+  if (tid == 0) s_tie = 0u;
+  if (valInLds) for (int i = tid; i < G; i += 256) valL[i] = val[i];
+  __syncthreads();
+  unsigned long long* myList = tieList + (size_t) blockIdx.x * tieCap;
+  const float* vsrc = valInLds ? valL : val;
+
+  float b[2][S2];
+#pragma unroll
+  for (int t = 0; t < 2; t++) {
+    const long n = n0 + 32 * t + col;
+    const bool live = n < N;
+#pragma unroll
+    for (int s = 0; s < S2; s++) {
+      const int k = 2 * s + kh; float v = 0.0f;
+      if (live) {
+        if (k < D) { const float q = x[n * D + k]; v = q * q; }
+        else if (k < 2 * D) v = x[n * D + (k - D)];
+        else if (k == 2 * D) v = 1.0f;
+      }
+      b[t][s] = v;
+    }
+  }
+  const float4* Ap4 = reinterpret_cast<const float4*>(Apack) + lane;
+  int kFlush0 = 0;                                               // first codebook of the strip
+  // closes one codebook for one frame: score from the best candidate; a near tie goes to the list
+  auto finish = [&](const long nme, const int fr, const int kcb, const float m1, const int a1, const float m2, const int a2) __attribute__((always_inline)) {
+    float best = m1; int ba = a1;
+    if (m2 - m1 <= 1e-4f * (fabsf(m1) + 1.0f) && nme < N) {
+      const unsigned slot = atomicAdd(&s_tie, 1u);
+      if (slot < tieCap) myList[slot] = ((unsigned long long) nme << 32) | ((unsigned long long) kcb << 16) | ((unsigned long long) a1 << 8) | (unsigned long long) a2;
+      else {                                                     // list full: settle it here (cold)
+        const int cb = kcb * R; const float* xr = x + nme * D;
+        const float e1 = exact_dist_inl(xr, mean + (size_t) (cb + a1) * Dp, ivar + (size_t) (cb + a1) * Dp, cst[cb + a1], D);
+        const float e2 = exact_dist_inl(xr, mean + (size_t) (cb + a2) * Dp, ivar + (size_t) (cb + a2) * Dp, cst[cb + a2], D);
+        if (e2 < e1 || (e2 == e1 && a2 < a1)) { best = e2; ba = a2; } else { best = e1; ba = a1; }
+      }
+    }
+    float sc = 0.5f * (best + 2.0f * vsrc[kcb * R + ba]);
+    if (!unitScale) { const float sl = scale[kcb]; if (sl != 1.0f) sc *= sl; }
+    sbuf[fr * SCP + (kcb - kFlush0)] = sc; abuf[fr * 32 + (kcb - kFlush0)] = (unsigned char) ba;
+  };
+  // search of one codebook group (tile t, group q) of a finished chunk
+  auto search = [&](const f32x16 (&acc)[2], const int ch, const int t, const int q) __attribute__((always_inline)) {
+    const long nme = n0 + 32 * t + col; const int fr = 32 * t + col;
+    if (R == 4) {
+      const int kcb = ch * 8 + 2 * q + kh;                       // codebook of registers 4q .. 4q+3
+      float m1 = acc[t][4 * q], m2 = 1E20f; int a1 = 0, a2 = 0;
+#pragma unroll
+      for (int j = 1; j < 4; j++) {
+        const float v = acc[t][4 * q + j];
+        const bool lt1 = v < m1, lt2 = v < m2;
+        m2 = lt1 ? m1 : (lt2 ? v : m2); a2 = lt1 ? a1 : (lt2 ? j : a2);
+        m1 = lt1 ? v : m1; a1 = lt1 ? j : a1;
+      }
+      if (kcb < K) finish(nme, fr, kcb, m1, a1, m2, a2);
+    } else {
+      constexpr int RH = R / 2;                                  // registers of a codebook in this lane
+      const int c = q;                                           // q counts the chunk's codebooks here
+      const int kcb = ch * CPC + c;
+      float m1 = 1E20f, m2 = 1E20f; int a1 = 0, a2 = 0;
+#pragma unroll
+      for (int i = 0; i < RH; i++) {
+        const float v = acc[t][c * RH + i]; const int idx = 8 * (i >> 2) + 4 * kh + (i & 3);          // row inside the codebook
+        const bool lt1 = v < m1, lt2 = v < m2;
+        m2 = lt1 ? m1 : (lt2 ? v : m2); a2 = lt1 ? a1 : (lt2 ? idx : a2);
+        m1 = lt1 ? v : m1; a1 = lt1 ? idx : a1;
+      }
+      // merge with the partner lane's two best: order by (value, index)
+      const float p1 = __shfl_xor(m1, 32, 64), p2 = __shfl_xor(m2, 32, 64); const int pa = __shfl_xor(a1 | (a2 << 8), 32, 64);
+      const int q1 = pa & 255, q2 = pa >> 8;
+      auto before = [](float va, int ia, float vb, int ib) { return va < vb || (va == vb && ia < ib); };
+      float r1, r2; int s1, s2;
+      if (before(m1, a1, p1, q1)) { r1 = m1; s1 = a1; if (before(m2, a2, p1, q1)) { r2 = m2; s2 = a2; } else { r2 = p1; s2 = q1; } }
+      else { r1 = p1; s1 = q1; if (before(p2, q2, m1, a1)) { r2 = p2; s2 = q2; } else { r2 = m1; s2 = a1; } }
+      if (kh == (c & 1) && kcb < K) finish(nme, fr, kcb, r1, s1, r2, s2);          // one of the pair closes the codebook
+    }
+  };
+  constexpr int NSRCH = 2 * (R == 4 ? 4 : CPC);                  // search groups per chunk (two tiles)
+  auto flush = [&](const int ch) __attribute__((always_inline)) {     // after chunk ch has been searched
+    if (((ch + 1) % FLUSH) == 0 || ch + 1 == nChunks) {          // the wave's own strip: 64 frames x <= 32 codebooks leave as 128-byte runs
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
+      const int staged = (ch + 1) * CPC - kFlush0;
+      const int cnt = (kFlush0 + staged < K ? staged : K - kFlush0);
+      for (int f = kh; f < 64; f += 2) {
+        const long n = n0 + f;
+        if (n < N && col < cnt) { score[n * K + kFlush0 + col] = sbuf[f * SCP + col]; if (argmin) argmin[n * K + kFlush0 + col] = abuf[f * 32 + col]; }
+      }
+      kFlush0 += staged;
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
+    }
+  };
+  // Per chunk: the contraction (the next chunk's operand loads in flight), then the search of its accumulators.  Two waves share a SIMD: one's
+  // search runs under the other's MFMAs.  (Tried and dropped: searching chunk ch - 1 between the MFMAs of chunk ch inside one wave -- the second
+  // accumulator set and the longer live ranges cost the second wave per SIMD, 10.5 -> 11.6 ms.)
+  float4 acur[S4];
+#pragma unroll
+  for (int q = 0; q < S4; q++) acur[q] = Ap4[q * 64];
+  for (int ch = 0; ch < nChunks; ch++) {
+    float4 anext[S4];
+    if (ch + 1 < nChunks) {
+#pragma unroll
+      for (int q = 0; q < S4; q++) anext[q] = Ap4[((size_t) (ch + 1) * S4 + q) * 64];
+    }
+    f32x16 acc[2];
+#pragma unroll
+    for (int i = 0; i < 16; i++) { acc[0][i] = 0.0f; acc[1][i] = 0.0f; }
+#pragma unroll
+    for (int s4 = 0; s4 < S4; s4++) {
+      const float av[4] = {acur[s4].x, acur[s4].y, acur[s4].z, acur[s4].w};
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j], b[0][4 * s4 + j], acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j], b[1][4 * s4 + j], acc[1], 0, 0, 0);
+      }
+    }
+    if (dbg & 1) { if (acc[0][0] + acc[1][3] == 123.456f) sbuf[lane] = 1.0f; }
+    else {
+#pragma unroll
+      for (int g = 0; g < NSRCH; g++) search(acc, ch, g & 1, g >> 1);
+      flush(ch);
+    }
+#pragma unroll
+    for (int q = 0; q < S4; q++) acur[q] = anext[q];
+  }
+  __syncthreads();
+  if (tid == 0) tieCount[blockIdx.x] = s_tie;
+}
+
 void gmm_prepare_mfma(GmmModel& m)
 {
   if (m.mfmaReady) return;
   if (m.D > 64) throw Error(DSR_E_DIMENSION, "MFMA scoring supports dimN <= 64 (got %d); use mode 0", m.D);
-  { const int need = (2 * m.D + 1 + 1) / 2; const int sup[6] = {14, 20, 33, 40, 48, 65}; int S = 65; for (int i = 5; i >= 0; i--) if (sup[i] >= need) S = sup[i]; m.KP = 2 * S; }
+  { const int need = (2 * m.D + 1 + 1) / 2; const int sup[6] = {16, 20, 36, 40, 48, 68}; int S = 68; for (int i = 5; i >= 0; i--) if (sup[i] >= need) S = sup[i]; m.KP = 2 * S; }   // multiples of four
   const int S2 = m.KP / 2;
   m.GT = (m.G + 31) / 32;
   std::vector<float> A((size_t) m.GT * S2 * 64, 0.0f);
@@ -191,6 +383,13 @@ void gmm_prepare_mfma(GmmModel& m)
   // padding rows of the last chunk must never win
   for (int g = m.G; g < m.GT * 32; g++) { const int ch = g / 32, i = g % 32; const int kk = 2 * m.D; A[((size_t) ch * S2 + kk / 2) * 64 + (kk & 1) * 32 + i] = 1E30f; }
   m.d_A.upload(A);
+  {
+    // the same operand with four consecutive steps of a lane side by side: A4[(chunk S4 + s4) 64 + lane][j] = A[(chunk S2 + 4 s4 + j) 64 + lane]
+    const int S4 = S2 / 4; std::vector<float> A4(A.size());
+    for (int chk = 0; chk < m.GT; chk++) for (int s4 = 0; s4 < S4; s4++) for (int l = 0; l < 64; l++) for (int j = 0; j < 4; j++)
+      A4[(((size_t) chk * S4 + s4) * 64 + l) * 4 + j] = A[((size_t) chk * S2 + 4 * s4 + j) * 64 + l];
+    m.d_bn.upload(A4);
+  }
   m.mfmaReady = true;
 }
 
@@ -198,13 +397,47 @@ void gmm_score_mfma(GmmModel& m, const float* x, long N, float* score, unsigned 
 {
   gmm_prepare_mfma(m);
   const int S2 = m.KP / 2;
+  // codebooks of one size R in {4, 8, 16, 32}: the candidate search stays in the accumulator registers
+  int R = m.refN.empty() ? 0 : m.refN[0];
+  for (int k = 1; k < m.K; k++) if (m.refN[k] != R) R = 0;
+  if ((R == 4 || R == 8 || R == 16 || R == 32) && !getenv("DSR_GMM_MFMA_SCAN") && m.K < 65536 && N < ((long) 1 << 32)) {
+    const int S4 = S2 / 4;
+    const int valInLds = (m.G <= 8192) ? 1 : 0;
+    const size_t ldsR = sizeof(float) * ((size_t) (valInLds ? ((m.G + 3) & ~3) : 0) + (size_t) 4 * 64 * 33) + (size_t) 4 * 64 * 32;
+    int unitScale = 1; for (int k = 0; k < m.K; k++) if (m.scale[k] != 1.0f) unitScale = 0;
+    // near ties: one list entry each (frame, codebook, two candidates); sized for 1 in 32 (measured: 1 in a few hundred), and a full list
+    // is settled in place
+    static thread_local DevBuf<unsigned long long> tieList; static thread_local DevBuf<unsigned> tieCount;
+    const unsigned nBlk = (unsigned) cdiv(N, FT);
+    // per workgroup (256 frames x K codebooks): room for 1 near tie in 32 (measured: 1 in a thousand); a full segment is settled in place
+    const unsigned cap = (unsigned) std::min<size_t>(std::max<size_t>((size_t) FT * (size_t) m.K / 32, 256), ((size_t) 1 << 30) / nBlk);
+    tieList.reserve((size_t) nBlk * cap); tieCount.reserve(nBlk);
+    dim3 gridR(cdiv(N, FT));
+    const int dbg = getenv("DSR_GMM_DBG") ? atoi(getenv("DSR_GMM_DBG")) : 0;
+#define LR(SS, RR) { DSR_HIP(hipFuncSetAttribute((const void*) k_gmm_mfma_reg<SS, RR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) ldsR)); \
+  hipLaunchKernelGGL((k_gmm_mfma_reg<SS, RR>), gridR, dim3(256), ldsR, st, x, N, m.D, m.Dp, m.K, m.G, m.GT, m.d_bn.p, m.d_mean.p, m.d_ivar.p, m.d_cst.p, m.d_val.p, m.d_scale.p, unitScale, \
+                     score, argmin, tieList.p, tieCount.p, cap, valInLds, dbg); }
+#define LRS(RR) switch (S4) { case 4: LR(4, RR) break; case 5: LR(5, RR) break; case 9: LR(9, RR) break; case 10: LR(10, RR) break; case 12: LR(12, RR) break; default: LR(17, RR) break; }
+    if (R == 4) LRS(4) else if (R == 8) LRS(8) else if (R == 16) LRS(16) else LRS(32)
+#undef LRS
+#undef LR
+    DSR_HIP(hipGetLastError());
+    hipLaunchKernelGGL(k_gmm_ties, dim3(nBlk), dim3(64), 0, st, tieList.p, tieCount.p, cap, x, m.D, m.Dp, m.K, R, m.d_mean.p, m.d_ivar.p, m.d_cst.p, m.d_val.p, m.d_scale.p, score, argmin);
+    DSR_HIP(hipGetLastError());
+    if (getenv("DSR_GMM_TIES")) {
+      std::vector<unsigned> c(nBlk); DSR_HIP(hipStreamSynchronize(st)); DSR_HIP(hipMemcpy(c.data(), tieCount.p, 4 * (size_t) nBlk, hipMemcpyDeviceToHost));
+      size_t tot = 0; unsigned mx = 0; for (unsigned v : c) { tot += v; if (v > mx) mx = v; }
+      fprintf(stderr, "[dsr gmm] near ties: %zu of %zu (fullest segment %u of %u)\n", tot, (size_t) N * m.K, mx, cap);
+    }
+    return;
+  }
   const size_t lds = sizeof(float) * ((size_t) 2 * S2 * 64 + (size_t) FT * TS + (size_t) FT * SC) + (size_t) FT * SC;
   dim3 grid(cdiv(N, FT));
 #define LAUNCH(SS) { DSR_HIP(hipFuncSetAttribute((const void*) k_gmm_mfma<SS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds)); \
   hipLaunchKernelGGL(k_gmm_mfma<SS>, grid, dim3(256), lds, st, x, N, m.D, m.Dp, m.K, m.G, m.GT, m.d_off.p, m.d_A.p, m.d_mean.p, m.d_ivar.p, m.d_cst.p, m.d_val.p, m.d_scale.p, score, argmin); }
   switch (S2) {
-    case 14: LAUNCH(14) break; case 20: LAUNCH(20) break; case 33: LAUNCH(33) break;
-    case 40: LAUNCH(40) break; case 48: LAUNCH(48) break; default: LAUNCH(65) break;
+    case 16: LAUNCH(16) break; case 20: LAUNCH(20) break; case 36: LAUNCH(36) break;
+    case 40: LAUNCH(40) break; case 48: LAUNCH(48) break; default: LAUNCH(68) break;
   }
 #undef LAUNCH
   DSR_HIP(hipGetLastError());

@@ -195,7 +195,7 @@ struct BfOp : dsr_stream {           // SubbandDS / SubbandGSC / SubbandMVDR as 
     if (C == 0 || C != dsr_bf_chan_n(w)) throw Error(DSR_E_DIMENSION, "Number of channels (%d) does not match the weights (%d)", C, dsr_bf_chan_n(w));
     int T = ups[0]->nFrames; for (int c = 1; c < C; c++) if (ups[c]->nFrames < T) T = ups[c]->nFrames;
     alloc(T); if (T <= 0) return;
-    const int F = M / 2 + 1; X.reserve((size_t) C * T * F); Y.reserve((size_t) T * F);
+    const int F = dsr_bf_bins(w); X.reserve((size_t) C * T * F); Y.reserve((size_t) T * F);       // M/2+1 unique bins, or all M with halfBandShift
     for (int c = 0; c < C; c++) op_pack_bins(ups[c]->d<double2>(), T, F, M, X.p + (size_t) c * T * F, S0);
     dsr_status s = dsr_bf_apply(w, (const float*) X.p, 1, T, (float*) Y.p, S0); if (s) throw Error(s, "%s", dsr_last_error());
     op_expand_bins(Y.p, T, F, M, d<double2>(), S0);

@@ -271,7 +271,7 @@ class Beamformer:
 
     def get(self, kind):
         F = self.M // 2 + 1
-        shape = {0: (self.M, self.C), 1: (F, self.C), 2: (F, self.C, self.C), 3: (self.M, self.C, self.C - 1), 4: (F, self.C)}[kind]
+        shape = {0: (self.M, self.C), 1: (F, self.C), 2: (F, self.C, self.C), 3: (self.M, self.C, self.C - 1), 4: (_lib.dsr_bf_bins(self.h), self.C)}[kind]
         out = np.zeros(shape, np.complex128)
         check(_lib.dsr_bf_get(self.h, kind, _ptr(out), out.size * 2))
         return out
@@ -331,6 +331,10 @@ class Beamformer:
 
     def rlsResetState(self):
         check(_lib.dsr_bf_rls_reset_state(self.h))
+
+    def bins(self):
+        """bins per frame of apply(): fftLen/2+1, or fftLen with halfBandShift"""
+        return _lib.dsr_bf_bins(self.h)
 
     def apply(self, X):
         """X: cuda complex64 [U][C][T][F] -> [U][T][F]"""

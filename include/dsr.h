@@ -118,6 +118,11 @@ dsr_status dsr_bf_create(int fftLen, int chanN, int halfBandShift, dsr_bf** out)
 void       dsr_bf_destroy(dsr_bf*);
 int        dsr_bf_fft_len(const dsr_bf*);
 int        dsr_bf_chan_n(const dsr_bf*);
+/* halfBandShift == true (beamformer.cc:544-555,1159-1175,1321-1330): all fftLen bins are computed independently -- no conjugate mirror, no special
+   bin 0; the snapshot and output arrays of dsr_bf_apply then carry dsr_bf_bins() = fftLen bins per frame instead of fftLen/2+1.  Delay-and-sum and
+   GSC only: SubbandMVDR refuses the flag (:2324-2327), SubbandGSCRLS::next says "not yet implemented" (:1580-1583) -- both kept. */
+int        dsr_bf_half_band_shift(const dsr_bf*);
+int        dsr_bf_bins(const dsr_bf*);
 /* calcArrayManifoldVectors (beamformer.cc:531-594): delays[chanN] seconds */
 dsr_status dsr_bf_calc_array_manifold(dsr_bf*, double sampleRate, const double* delays);
 /* calcDelaysPolar2 of the reference driver (btk/src/superdirectiveBeamformer.cc:118-137) */

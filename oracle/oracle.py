@@ -191,6 +191,25 @@ def calc_mainlobe(fs, delays, M):
     return wq[..., 0] + 1j * wq[..., 1]
 
 
+def calc_mainlobe_hbs(fs, delays, M):
+    """calcMainlobe with halfBandShift == true (beamformer.cc:544-555)"""
+    d = _f64(delays); Cn = len(d)
+    wq = np.zeros((M, Cn, 2), np.float64)
+    L = lib(); L.orc_calc_mainlobe_hbs.argtypes = [c_dbl, c_vp, c_int, c_int, c_vp]
+    L.orc_calc_mainlobe_hbs(fs, _p(d), Cn, M, _p(wq))
+    return wq[..., 0] + 1j * wq[..., 1]
+
+
+def apply_all_bins(X, wq, B=None, wa=None, normalize=False):
+    """halfBandShift == true: X [C][T][M], wq [M][C], B [M][C][C-1], wa [M][C-1] -> Y [T][M], every bin on its own (beamformer.cc:1159-1175,1321-1330)"""
+    X = np.ascontiguousarray(X, np.complex128); Cn, T, M = X.shape
+    wq = np.ascontiguousarray(wq, np.complex128); Y = np.zeros((T, M), np.complex128)
+    Bc = np.ascontiguousarray(B, np.complex128) if B is not None else None; wac = np.ascontiguousarray(wa, np.complex128) if wa is not None else None
+    L = lib(); L.orc_apply_all_bins.argtypes = [c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp]
+    L.orc_apply_all_bins(_p(X), _p(wq), _p(Bc) if Bc is not None else None, _p(wac) if wac is not None else None, Cn, T, M, int(normalize), _p(Y))
+    return Y
+
+
 def calc_delays_polar2(az, el, micpos):
     mp = _f64(micpos); Cn = mp.shape[0]
     d = np.zeros(Cn, np.float64)

@@ -46,6 +46,41 @@ void orc_calc_mainlobe(double fs, const double* delays, int C, int M, double* wq
   }
 }
 
+void orc_calc_mainlobe_hbs(double fs, const double* delays, int C, int M, double* wq)
+{
+  /* halfBandShift == true branch, beamformer.cc:544-555: bins f and M-1-f, half a bin up (fshift is a float 0.5) */
+  const float fshift = 0.5f; const int M2 = M / 2;
+  for (int f = 0; f < M2; f++)
+    for (int c = 0; c < C; c++) {
+      double val = -2.0 * M_PI * (fshift + f) * fs * delays[c] / M;
+      ZSET(wq, (size_t) f * C + c, (cos(val) + I * sin(val)) / (double) C);
+      ZSET(wq, (size_t) (M - 1 - f) * C + c, (cos(-val) + I * sin(-val)) / (double) C);
+    }
+}
+
+/* halfBandShift == true: every bin on its own (SubbandDS::next :1159-1175, SubbandGSC::next :1321-1330 through calcOutputOfGSC :1251-1287).
+   X [C][T][M], wq [M][C], B [M][C][C-1] and wa [M][C-1] (NULL: delay-and-sum) -> Y [T][M] */
+void orc_apply_all_bins(const double* X, const double* wq, const double* B, const double* wa, int C, int T, int M, int normalize, double* Y)
+{
+  const int bs = C - 1;
+  zc* w = (zc*) malloc(sizeof(zc) * (size_t) C);
+  for (int f = 0; f < M; f++) {
+    double nrm = 0.0;
+    for (int i = 0; i < C; i++) {
+      zc wl = 0.0;
+      if (B) for (int j = 0; j < bs; j++) wl += ZGET(B, ((size_t) f * C + i) * bs + j) * ZGET(wa, (size_t) f * bs + j);
+      w[i] = ZGET(wq, (size_t) f * C + i) - wl; nrm += creal(w[i] * conj(w[i]));
+    }
+    if (B && normalize) { nrm = sqrt(nrm); for (int i = 0; i < C; i++) w[i] = w[i] / (nrm * C); }
+    for (int t = 0; t < T; t++) {
+      zc val = 0.0;
+      for (int c = 0; c < C; c++) val += conj(w[c]) * ZGET(X, ((size_t) c * T + t) * M + f);
+      ZSET(Y, (size_t) t * M + f, val);
+    }
+  }
+  free(w);
+}
+
 void orc_calc_delays_polar2(float azimuth, float elevation, const double* micpos, int C,
                             double* delays)
 {

@@ -1173,3 +1173,46 @@ def test_viterbi_full_size(dsr, oracle, cuda, monkeypatch):
         assert all(out[u][k] == out2[u][k] for k in keys) and np.array_equal(out[u]["arcs"], out2[u]["arcs"]) and out2[u]["registerFrames"] == 0
     for v in range(320):
         assert all(out[v % U][k] == out3[v][k] for k in keys) and np.array_equal(out[v % U]["words"], out3[v]["words"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["ds", "gsc", "gsc_norm"])
+def test_beamformer_half_band_shift(dsr, oracle, cuda, mode):
+    """halfBandShift == true apply for SubbandDS / SubbandGSC (beamformer.cc:544-555,1159-1175,1321-1330): all M bins on their own,
+    steering half a bin up; SubbandMVDR refuses the flag (:2324-2327) and SubbandGSCRLS::next says "not yet implemented" (:1580-1583), as here."""
+    import torch
+    M, Cn, T, U = 64, 6, 9, 2
+    mp = synth.linear_array(Cn)
+    delays = dsr.calcDelaysPolar2(np.float32(0.5), np.float32(1.3), mp)
+    bf = dsr.Beamformer(M, Cn, halfBandShift=True)
+    if mode == "ds":
+        bf.calcArrayManifoldVectors(16000.0, delays)
+    else:
+        bf.calcGSCWeights(16000.0, delays)
+    bf.select(mode)
+    wq = bf.get(0)
+    assert np.abs(wq - oracle.calc_mainlobe_hbs(16000.0, delays, M)).max() < 1e-15
+    rng = np.random.default_rng(77)
+    X = (rng.standard_normal((U, Cn, T, M)) + 1j * rng.standard_normal((U, Cn, T, M))).astype(np.complex64)      # all M bins, no symmetry assumed
+    B = wa = None
+    if mode != "ds":
+        B = bf.get(3); wa = (rng.standard_normal((M, Cn - 1)) + 1j * rng.standard_normal((M, Cn - 1))) * 0.05
+        for f in range(M):
+            bf.setActiveWeights_f(f, np.ascontiguousarray(wa[f]).view(np.float64))
+        for f in (0, 5, M - 1):
+            Bo, ok = oracle.blocking_matrix(wq[f]); assert ok and np.abs(B[f] - Bo).max() < 1e-12
+    assert bf.bins() == M
+    Y = bf.apply(torch.from_numpy(X).to(cuda)).cpu().numpy()
+    assert Y.shape == (U, T, M)
+    for u in range(U):
+        Yo = oracle.apply_all_bins(X[u].astype(np.complex128), wq, B, wa, mode == "gsc_norm")
+        assert np.abs(Y[u] - Yo).max() <= 2e-5 * np.abs(Yo).max() * np.sqrt(Cn)
+    mv = dsr.Beamformer(M, Cn, halfBandShift=True); mv.calcArrayManifoldVectors(16000.0, delays); mv.setDiffuseNoiseModel(mp, 16000.0)
+    mv.calcMVDRWeights(16000.0); mv.select("mvdr")
+    with pytest.raises(dsr.DsrError) as e:
+        mv.apply(torch.from_numpy(X).to(cuda))
+    assert e.value.status == 2                                            # jallocation_error "halfBandShift==true is not yet supported"
+    if mode == "gsc":
+        bf.rlsConfig(0.9, 0.0); bf.initPrecisionMatrix(0.01)
+        with pytest.raises(dsr.DsrError):
+            bf.gsc_rls(torch.from_numpy(X[:, :, :, :M // 2 + 1].copy()).to(cuda))       # "not yet implemented"
