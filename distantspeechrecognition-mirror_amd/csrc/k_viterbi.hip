@@ -141,6 +141,7 @@ __global__ __launch_bounds__(kThreads) void k_viterbi(GraphDev G, DecDev Dd, con
   __shared__ int s_waveTot[kWaves];
   __shared__ int s_waveTotE[kWaves];
   __shared__ double s_waveMin[kWaves];
+  __shared__ float s_waveMag[kWaves];
   __shared__ unsigned long long s_waveKey[kWaves];
   __shared__ int s_sideN;
   __shared__ int s_tb[2];            // traceback: hops, words
@@ -295,7 +296,7 @@ __global__ __launch_bounds__(kThreads) void k_viterbi(GraphDev G, DecDev Dd, con
           float qac[kFastK], qlm[kFastK]; int qrec[kFastK]; unsigned ek[kFastK];
           double* ttlS = reinterpret_cast<double*>(cA);                        // unrounded totals, read back by later arrivals only
           uint4* ovf = reinterpret_cast<uint4*>(cB);                           // parked placements [slot - kFastK * nthr]
-          double locMin = HUGE_VAL;
+          double locMin = HUGE_VAL; float locMag = 0.0f;                       // locMag: largest |ac| + |lm| of the frame's placements (bounds the rounding of a score, see P4)
           const bool prevNull0 = (fr == 0);                                    // only the start token has no edge (decoder.h:960)
           const double lmS = Dd.lmScale, lsPen = __dmul_rn(Dd.lmScale, Dd.lmPenalty), lsSil = __dmul_rn(Dd.lmScale, Dd.silPenalty);
           const bool sil0 = (0u == Dd.silenceX);
@@ -315,24 +316,26 @@ __global__ __launch_bounds__(kThreads) void k_viterbi(GraphDev G, DecDev Dd, con
             atomicMin(&hfirst[h], (unsigned) c);
             return h;
           };
-          auto expand8 = [&](const int g8, float* ac8, float* lm8, int* rec8, unsigned* ek8) __attribute__((always_inline)) {
+          // slot -> (compact token index, position in its expansion list), then the token: score halves into the placement's own registers,
+          // record index = first record of the node + position, bit29 of ek = the token's edge was a silence edge
+          auto locate = [&](const int k, int& rec, unsigned& ekk) __attribute__((always_inline)) {
+            const int c = k * nthr + tq; const int grp = k * nw + wq;
+            unsigned e = 0u; int j = 0;
+            if (c < C) {
+              const unsigned long long W = ((unsigned long long) s_bm[2 * grp + 1] << 32) | s_bm[2 * grp];
+              e = (unsigned) s_gbase[grp] + (unsigned) __popcll(W & ((2ull << lq) - 1ull)) - 1u;
+              j = c - (int) eoff[e];
+            }
+            ekk = e; rec = j;
+          };
+          auto tokload = [&](float& ac, float& lm, int& rec, unsigned& ekk) __attribute__((always_inline)) {
+            const TokA t = ctk[ekk];
+            ac = t.ac; lm = t.lm; rec += (int) (t.xs & 0x7FFFFFFFu); ekk |= (t.xs >> 31) << 29;
+          };
+          auto expandR = [&](const int g8, float* ac8, float* lm8, int* rec8, unsigned* ek8) __attribute__((always_inline)) {
             int4 xr[kB]; int2 xd[kB]; bool tsil[kB];
 #pragma unroll
-            for (int i = 0; i < kB; i++) {                                      // slot -> (token, position in its expansion list)
-              const int k = g8 + i; const int c = k * nthr + tq; const int grp = k * nw + wq;
-              unsigned e = 0u; int j = 0;
-              if (c < C) {
-                const unsigned long long W = ((unsigned long long) s_bm[2 * grp + 1] << 32) | s_bm[2 * grp];
-                e = (unsigned) s_gbase[grp] + (unsigned) __popcll(W & ((2ull << lq) - 1ull)) - 1u;
-                j = c - (int) eoff[e];
-              }
-              ek8[i] = e; rec8[i] = j;
-            }
-#pragma unroll
-            for (int i = 0; i < kB; i++) {                                      // eight token loads in flight
-              const TokA t = ctk[ek8[i]];
-              ac8[i] = t.ac; lm8[i] = t.lm; rec8[i] += (int) (t.xs & 0x7FFFFFFFu); tsil[i] = (t.xs >> 31) != 0u;
-            }
+            for (int i = 0; i < kB; i++) { tsil[i] = (ek8[i] >> 29) & 1u; ek8[i] &= 0x1FFFu; }
 #pragma unroll
             for (int i = 0; i < kB; i++) {                                      // eight record loads in flight
               xr[i] = *reinterpret_cast<const int4*>(&G.xrecD[rec8[i]]); xd[i] = *reinterpret_cast<const int2*>(&G.xrecD[rec8[i]].dst);
@@ -383,12 +386,20 @@ __global__ __launch_bounds__(kThreads) void k_viterbi(GraphDev G, DecDev Dd, con
                 const double ttl = __dadd_rn(ac, lm);
                 ttlS[c] = ttl; ac8[i] = (float) ac; lm8[i] = (float) lm; rec8[i] |= (silArc ? 0x40000000 : 0);
                 if (ttl < locMin) locMin = ttl;                                // _topScore
+                locMag = fmaxf(locMag, __fadd_rn(fabsf(ac8[i]), fabsf(lm8[i])));
                 // state table: claim the bucket, keep the smallest slot (with two passes, the other half of the states waits)
                 const unsigned prod = (unsigned) xd[i].x * 2654435761u;
                 if (nPass > 1 && (prod >> 31)) ek8[i] |= 1u << 27;
                 else ek8[i] |= (table_insert((unsigned) xd[i].x, prod, c) << 13) | (1u << 28);      // bit28: in the table, not folded yet
               }
             }
+          };
+          auto expand8 = [&](const int g8, float* ac8, float* lm8, int* rec8, unsigned* ek8) __attribute__((always_inline)) {
+#pragma unroll
+            for (int i = 0; i < kB; i++) locate(g8 + i, rec8[i], ek8[i]);
+#pragma unroll
+            for (int i = 0; i < kB; i++) tokload(ac8[i], lm8[i], rec8[i], ek8[i]);
+            expandR(g8, ac8, lm8, rec8, ek8);
           };
 #pragma unroll
           for (int g8 = 0; g8 < kFastK; g8 += kB) if (g8 < K) expand8(g8, &qac[g8], &qlm[g8], &qrec[g8], &ek[g8]);
@@ -410,13 +421,28 @@ __global__ __launch_bounds__(kThreads) void k_viterbi(GraphDev G, DecDev Dd, con
           }
           TICK(2);
           locMin = wave_min_d(locMin);
-          if (lq == 0) s_waveMin[wq] = locMin;
+#pragma unroll
+          for (int d = 32; d >= 1; d >>= 1) locMag = fmaxf(locMag, __shfl_xor(locMag, d, 64));
+          if (lq == 0) { s_waveMin[wq] = locMin; s_waveMag[wq] = locMag; }
           TICK(3);
           __syncthreads();
           TICK(4);
           topScore = HUGE_VAL;
-          for (int w = 0; w < nw; w++) { const double v = s_waveMin[w]; if (v < topScore) topScore = v; }
+          float frameMag = 0.0f;
+          for (int w = 0; w < nw; w++) { const double v = s_waveMin[w]; if (v < topScore) topScore = v; frameMag = fmaxf(frameMag, s_waveMag[w]); }
           topScore = uni(topScore);
+          // A token whose score is above (this frame's best emitting total + beam) fails the beam test of the next frame
+          // (decoder.h:586-588) and is never looked at again: it is counted (activeHypos, maxActive) but neither written to the list
+          // nor to the back-pointer arena.  The order of the tokens that stay is unchanged, so the next frame's arrival slots are too.
+          // Not on the last frame (the end expansion takes every token) and not when the lists are dumped.
+          const double threshNext = __dadd_rn(topScore, Dd.beam);
+          const bool prune = !dump && (fr + 1 < T);
+          // A LATER arrival that far above the threshold cannot touch a token that stays: a token that stays has score <= threshNext, and its
+          // unrounded total (what the recombination compares, decoder.h:519-528) is within 2^-23 (|ac| + |lm|) of its score, so it beats
+          // both such an arrival and whatever incumbent that arrival would have replaced (whose score is above the arrival's total).  Which of
+          // two tokens above the threshold a state ends with is not observable (neither is written).  Such arrivals skip the chain: no side
+          // record, no replay -- about two thirds of the later arrivals at the usual beam.
+          const double doomT = prune ? __dadd_rn(threshNext, (double) __fmul_rn(frameMag, 4.76837158203125e-07f)) : HUGE_VAL;   // gap = 2^-21 x bound
           // ---- P4/P5, once per pass over the state table: later arrivals hang themselves on their bucket (the key word becomes
           // the chain head), then every first arrival folds its chain in slot order (decoder.h:519-528)
           unsigned long long firstMask = 0ull;
@@ -433,7 +459,7 @@ __global__ __launch_bounds__(kThreads) void k_viterbi(GraphDev G, DecDev Dd, con
               if (c < C && (ek8[i] & (1u << 28)) && (int) ((ek8[i] >> 27) & 1u) == pass && !((firstMask >> (g8 + i)) & 1ull)) {
                 const unsigned h = (ek8[i] >> 13) & 0x3FFFu;
                 if (hfirst[h] == (unsigned) c) firstMask |= 1ull << (g8 + i);
-                else {
+                else if (!((double) __fadd_rn(ac8[i], lm8[i]) > doomT)) {
                   const int sx = atomicAdd(&s_sideN, 1);
                   const unsigned nx = atomicExch(&hkey[h], 0x80000000u | (unsigned) sx);
                   Side sd; sd.ttl = tt[i]; sd.ac = ac8[i]; sd.lm = lm8[i]; sd.rec = rec8[i]; sd.prevBp = pb[i]; sd.c = c; sd.next = nx;
@@ -547,12 +573,6 @@ __global__ __launch_bounds__(kThreads) void k_viterbi(GraphDev G, DecDev Dd, con
           }
           TICK(12);
           if (s_err) { status = DSR_E_ALLOCATION; break; }                     // (uniform: written before the barriers above)
-          // A token whose score is above (this frame's best emitting total + beam) fails the beam test of the next frame
-          // (decoder.h:586-588) and is never looked at again: it is counted (activeHypos, maxActive) but neither written to the list
-          // nor to the back-pointer arena.  The order of the tokens that stay is unchanged, so the next frame's arrival slots are too.
-          // Not on the last frame (the end expansion takes every token) and not when the lists are dumped.
-          const double threshNext = __dadd_rn(topScore, Dd.beam);
-          const bool prune = !dump && (fr + 1 < T);
           unsigned long long keepMask = 0ull;
 #pragma unroll
           for (int k = 0; k < kFastK; k++) if (k < K && ((firstMask >> k) & 1ull)) {
