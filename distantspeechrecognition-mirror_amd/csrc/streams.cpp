@@ -202,6 +202,21 @@ struct BfOp : dsr_stream {           // SubbandDS / SubbandGSC / SubbandMVDR as 
   }
 };
 
+struct MmiOp : BfOp {                // SubbandMMI as a stream (beamformer.cc:1973-2072); channels through dsr_subband_bf_set_channel
+  dsr_mmi* mm = nullptr; DevBuf<int> nf;
+  void compute() override {
+    const int C = (int) ups.size();
+    if (C == 0 || C != dsr_mmi_chan_n(mm)) throw Error(DSR_E_DIMENSION, "Number of channels (%d) does not match the weights (%d)", C, dsr_mmi_chan_n(mm));
+    int T = ups[0]->nFrames; for (int c = 1; c < C; c++) if (ups[c]->nFrames < T) T = ups[c]->nFrames;
+    alloc(T); if (T <= 0) return;
+    const int F = dsr_mmi_bins(mm); X.reserve((size_t) C * T * F); Y.reserve((size_t) T * F);
+    for (int c = 0; c < C; c++) op_pack_bins(ups[c]->d<double2>(), T, F, M, X.p + (size_t) c * T * F, S0);
+    nf.upload(&T, 1);
+    dsr_status s = dsr_mmi_apply(mm, (const float*) X.p, nf.p, 1, T, (float*) Y.p, S0); if (s) throw Error(s, "%s", dsr_last_error());
+    op_expand_bins(Y.p, T, F, M, d<double2>(), S0);
+  }
+};
+
 struct OrthOp : dsr_stream {         // SubbandOrthogonalizer(beamformer, outChanX) (beamformer.cc:2817-2849): ups[0] = the SubbandMVDRGSC operator
   int outChanX = 0; DevBuf<float2> Z;
   void compute() override {
@@ -494,10 +509,17 @@ dsr_status dsr_subband_bf_create(dsr_bf* weights, const char* name, dsr_stream**
     BfOp* s = mk<BfOp>(name, "SubbandBeamformer", dsr_bf_fft_len(weights), DSR_T_COMPLEX); s->w = weights; s->M = dsr_bf_fft_len(weights); s->checkOrder = false; *out = s;
   });
 }
+dsr_status dsr_subband_mmi_stream_create(dsr_mmi* weights, int fftLen, const char* name, dsr_stream** out)
+{
+  return guard([&] {
+    if (!weights || !out) throw Error(DSR_E_PARAMETER, "null argument");
+    MmiOp* s = mk<MmiOp>(name, "SubbandMMI", fftLen, DSR_T_COMPLEX); s->w = nullptr; s->mm = weights; s->M = fftLen; s->checkOrder = false; *out = s;
+  });
+}
 dsr_status dsr_subband_orthogonalizer_create(dsr_stream* beamformer, int outChanX, const char* name, dsr_stream** out)
 {
   return guard([&] {
-    BfOp* q = dynamic_cast<BfOp*>(beamformer); if (!q || !out) throw Error(DSR_E_PARAMETER, "not a subband beamformer");
+    BfOp* q = dynamic_cast<BfOp*>(beamformer); if (!q || !q->w || !out) throw Error(DSR_E_PARAMETER, "not a subband beamformer");
     OrthOp* s = mk<OrthOp>(name, "SubbandOrthogonalizer", q->M, DSR_T_COMPLEX); s->outChanX = outChanX; s->checkOrder = false;
     s->add_up(beamformer); *out = s;
   });

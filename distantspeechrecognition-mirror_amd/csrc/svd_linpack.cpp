@@ -273,10 +273,13 @@ bool pseudoinverse(const std::complex<double>* A, std::complex<double>* invA, in
     if (std::abs(s[k]) < dThreshold) { s[k] = cf(0.0f, 0.0f); ret = false; }
     else s[k] = cdiv(cf(1.0f, 0.0f), s[k]);
   }
+  // (the shipped loop runs k to N whatever M is; for M < N that reads singular values csvdc never set and columns of u that do not exist --
+  // only scaling() of an nSource x chanN demixing matrix gets there, beamformer.cc:1862 -- those terms are zero here)
+  const int K = std::min(M, N);
   for (int i = 0; i < M; i++)
     for (int j = 0; j < N; j++) {
       cf xacc(0.0f, 0.0f);
-      for (int k = 0; k < N; k++) xacc = xacc + v[j + (size_t) k * N] * s[k] * std::conj(u[i + (size_t) k * M]);
+      for (int k = 0; k < K; k++) xacc = xacc + v[j + (size_t) k * N] * s[k] * std::conj(u[i + (size_t) k * M]);
       invA[(size_t) j * M + i] = std::complex<double>(xacc.real(), xacc.imag());
     }
   return ret;

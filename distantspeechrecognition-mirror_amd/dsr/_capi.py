@@ -484,6 +484,66 @@ class ZelinskiPostFilter:
         check(_lib.dsr_zelinski_reset_state(self.h))
 
 
+class SubbandMMI:
+    """SubbandMMI (beamformer.h:264-312, beamformer.cc:1753-2319) over dsr_mmi_*; the reference's method names."""
+
+    def __init__(self, fftLen=512, chanN=2, halfBandShift=False, targetSourceX=0, nSource=2, pfType=0, alpha=0.9):
+        L = load(); self.h = vp(); self.M, self.C, self.nSource, self.NC = fftLen, chanN, nSource, 1
+        check(L.dsr_mmi_create(fftLen, chanN, int(bool(halfBandShift)), targetSourceX, nSource, pfType, alpha, C.byref(self.h)))
+
+    def __del__(self):
+        if _lib is not None and getattr(self, "h", None):
+            _lib.dsr_mmi_destroy(self.h)
+
+    def bins(self):
+        return _lib.dsr_mmi_bins(self.h)
+
+    def useBinaryMask(self, avgFactor=-1.0, fwidth=1, type=0):
+        check(_lib.dsr_mmi_use_binary_mask(self.h, avgFactor, fwidth, type))
+
+    def calcWeights(self, sampleRate, delays):
+        d = np.ascontiguousarray(delays, np.float64)
+        if d.shape != (self.nSource, self.C):
+            raise DsrError(5, "delays must be [%d][%d]" % (self.nSource, self.C))
+        check(_lib.dsr_mmi_calc_weights(self.h, sampleRate, _ptr(d))); self.NC = 1
+
+    def calcWeightsN(self, sampleRate, delays, NC=2):
+        d = np.ascontiguousarray(delays, np.float64)
+        if d.shape != (self.nSource, self.C):
+            raise DsrError(5, "delays must be [%d][%d]" % (self.nSource, self.C))
+        check(_lib.dsr_mmi_calc_weights_n(self.h, sampleRate, _ptr(d), NC)); self.NC = NC
+
+    def setActiveWeights_f(self, fbinX, packedWeights, option=0):
+        w = np.ascontiguousarray(packedWeights, np.float64)
+        if w.ndim != 2:
+            raise DsrError(5, "packedWeights must be a matrix")
+        check(_lib.dsr_mmi_set_active_weights_f(self.h, fbinX, _ptr(w), w.shape[0], w.shape[1], option))
+
+    def setHiActiveWeights_f(self, fbinX, pkdWa, pkdwb, option=0):
+        a = np.ascontiguousarray(pkdWa, np.float64).ravel(); b = np.ascontiguousarray(pkdwb, np.float64).ravel()
+        check(_lib.dsr_mmi_set_hi_active_weights_f(self.h, fbinX, _ptr(a), a.size, _ptr(b), b.size, option))
+
+    def get(self, srcX, kind):
+        """kind: 'wq' [M][C], 'wl' [M][C], 'B' [M][C][C-NC], 'ta' [M][C], 'wa' [M][C-NC] (complex128)"""
+        k = {"wq": 0, "wl": 1, "B": 2, "ta": 3, "wa": 4}[kind]; bs = self.C - self.NC
+        shape = {0: (self.M, self.C), 1: (self.M, self.C), 2: (self.M, self.C, bs), 3: (self.M, self.C), 4: (self.M, bs)}[k]
+        out = np.zeros(shape, np.complex128)
+        check(_lib.dsr_mmi_get(self.h, srcX, k, _ptr(out), 2 * out.size))
+        return out
+
+    def apply(self, X, nframes=None):
+        """X: cuda complex64 [U][C][T][bins] -> [U][T][bins]"""
+        import torch
+        U, Cn, T, F = X.shape
+        if Cn != self.C or F != self.bins():
+            raise DsrError(5, "snapshots must be [U][%d][T][%d]" % (self.C, self.bins()))
+        if nframes is None:
+            nframes = torch.full((U,), T, dtype=torch.int32, device=X.device)
+        out = torch.zeros((U, T, F), dtype=torch.complex64, device=X.device)
+        check(_lib.dsr_mmi_apply(self.h, _dev(X.contiguous()), _dev(nframes), U, T, _dev(out), cur_stream()))
+        return out
+
+
 class McCowanPostFilter(ZelinskiPostFilter):
     """McCowan post-filter (postfilter.cc:502-945): Zelinski's recursions + a noise coherence matrix per bin."""
 

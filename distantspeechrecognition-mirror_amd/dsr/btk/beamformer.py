@@ -1,4 +1,4 @@
-"""btk.beamformer: SubbandDSPtr / SubbandGSCPtr / SubbandGSCRLSPtr / SubbandMVDRPtr (beamformer.i:227-323) as streams."""
+"""btk.beamformer: SubbandDSPtr / SubbandGSCPtr / SubbandGSCRLSPtr / SubbandMMIPtr / SubbandMVDRPtr (beamformer.i:227-323) as streams."""
 import numpy as np
 
 from .. import _capi as K
@@ -80,6 +80,53 @@ class SubbandGSCRLSPtr(SubbandGSCPtr):
 
     def updateActiveWeightVecotrs(self, flag):
         self._weights().updateActiveWeightVecotrs(flag)
+
+
+class SubbandMMIPtr(_Subband):
+    """beamformer.i:255-287 (SubbandMMI, beamformer.cc:1753-2319): one GSC per source, Zelinski post-filter, binary mask."""
+
+    def __init__(self, fftLen=512, halfBandShift=False, targetSourceX=0, nSource=2, pfType=0, alpha=0.9, nm="SubbandMMI"):
+        _Subband.__init__(self, fftLen, halfBandShift, nm)
+        self._args = (targetSourceX, nSource, pfType, alpha); self._mask = None
+
+    def _weights(self):
+        if self._w is None:
+            t, n, pf, a = self._args
+            self._w = K.SubbandMMI(self._fftLen, len(self._chans), self._hbs, t, n, pf, a)
+            if self._mask is not None:
+                self._w.useBinaryMask(*self._mask)
+            h, _ = _new(lib().dsr_subband_mmi_stream_create, self._w.h, self._fftLen, self._nm.encode()); self._h = h
+            for c in self._chans:
+                K.check(lib().dsr_subband_bf_set_channel(self._h, c._h))
+        return self._w
+
+    def useBinaryMask(self, avgFactor=-1.0, fwidth=1, type=0):
+        self._mask = (avgFactor, fwidth, type)
+        if self._w is not None:
+            self._w.useBinaryMask(avgFactor, fwidth, type)
+
+    def calcWeights(self, sampleRate, delays):
+        self._weights().calcWeights(sampleRate, delays)
+
+    def calcWeightsN(self, sampleRate, delays, NC=2):
+        self._weights().calcWeightsN(sampleRate, delays, NC)
+
+    def setActiveWeights_f(self, fbinX, packedWeights, option=0):
+        if self._w is None:
+            raise K.DsrError(1, "call calcWeightsX() once")
+        self._w.setActiveWeights_f(fbinX, packedWeights, option)
+
+    def setHiActiveWeights_f(self, fbinX, pkdWa, pkdwb, option=0):
+        if self._w is None:
+            raise K.DsrError(1, "call calcWeightsX() once")
+        self._w.setHiActiveWeights_f(fbinX, pkdWa, pkdwb, option)
+
+    def next(self, frameX=-5):
+        if self._w is None:
+            raise K.DsrError(1, "call calcWeightsX() once")
+        return FeatureStreamPtr.next(self, frameX)
+
+    __next__ = next
 
 
 class SubbandBlockingMatrixPtr(SubbandGSCPtr):

@@ -454,6 +454,35 @@ dsr_status dsr_zelinski_apply(dsr_zelinski*, const float* X_dev, const float* Y_
 dsr_status dsr_zelinski_carry(dsr_zelinski*, int on);
 dsr_status dsr_zelinski_reset_state(dsr_zelinski*);
 
+/* SubbandMMI (btk/beamformer/beamformer.h:264-312, beamformer.cc:1753-2319; beamformer.i:255-287): one generalized sidelobe canceller per
+ * sound source; the output is the target source's GSC output, Zelinski post-filtered (pfType: postfilter.h:63-69 bits -- 0x01 real part /
+ * 0x02 magnitude of the summed cross densities, 0x08 steer with the beamformer's own vector; 0 = no post-filter) and, after
+ * use_binary_mask, zeroed (avgFactor < 0) or replaced by avgFactor x the recursive average of earlier outputs where another source's output
+ * is stronger (type 0: the other sources' GSC outputs, 1: every source's upper-branch output).
+ *   calc_weights      = calcWeights(sampleRate, delays[nSource][chanN])            one linear constraint per source (:1769-1780)
+ *   calc_weights_n    = calcWeightsN(sampleRate, delays, NC)                       NC constraints: target + NC-1 nulls (:1788-1811)
+ *   set_active_weights_f    = setActiveWeights_f(fbinX, packedWeights[rows][cols], option)      rows = nSource, cols = 2 (chanN - NC); option 1
+ *                             resolves the scaling of the demixing matrix through its pseudo-inverse (:1821-1880)
+ *   set_hi_active_weights_f = setHiActiveWeights_f(fbinX, pkdWa, pkdwb, option)    (:1891-1968)
+ *   get: kind 0 wq [M][C], 1 wl [M][C], 2 B [M][C][C-NC], 3 array manifold [M][C], 4 wa [M][C-NC] of one source, complex128
+ *   apply = next() for a batch: X_dev [U][chanN][Tmax][bins] complex64 snapshots -> Y_dev [U][Tmax][bins], bins = dsr_mmi_bins()
+ *           (fftLen/2+1, or fftLen with halfBandShift); every utterance starts like a fresh object (frame counter, densities, average).
+ * Errors as the reference raises them: DSR_E_ERROR "call calcWeightsX() once" / wrong number of rows, DSR_E_DIMENSION for packed sizes and
+ * bins.  The TYPE_APAB bit (0x04) is refused (DSR_E_PARAMETER): that filter leaves a spectrum that is not conjugate-symmetric. */
+typedef struct dsr_mmi dsr_mmi;
+dsr_status dsr_mmi_create(int fftLen, int chanN, int halfBandShift, int targetSourceX, int nSource, int pfType, double alpha, dsr_mmi** out);
+void       dsr_mmi_destroy(dsr_mmi*);
+int        dsr_mmi_bins(const dsr_mmi*);
+int        dsr_mmi_chan_n(const dsr_mmi*);
+int        dsr_mmi_fft_len(const dsr_mmi*);
+dsr_status dsr_mmi_use_binary_mask(dsr_mmi*, double avgFactor, unsigned fwidth, unsigned type);
+dsr_status dsr_mmi_calc_weights(dsr_mmi*, double sampleRate, const double* delays /*[nSource][chanN]*/);
+dsr_status dsr_mmi_calc_weights_n(dsr_mmi*, double sampleRate, const double* delays /*[nSource][chanN]*/, unsigned NC);
+dsr_status dsr_mmi_set_active_weights_f(dsr_mmi*, unsigned fbinX, const double* packedWeights, size_t rows, size_t cols, int option);
+dsr_status dsr_mmi_set_hi_active_weights_f(dsr_mmi*, unsigned fbinX, const double* pkdWa, size_t nWa, const double* pkdwb, size_t nWb, int option);
+dsr_status dsr_mmi_get(const dsr_mmi*, int srcX, int kind, double* out, size_t outDoubles);
+dsr_status dsr_mmi_apply(dsr_mmi*, const float* X_dev, const int32_t* nframes_dev, int U, int Tmax, float* Y_dev, void* stream);
+
 /* Single-channel WPE dereverberation of a subband sequence (SingleChannelWPEDereverberationFeature, btk/dereverberation/
  * dereverberation.cc:28-300; SWIG defaults iterationsN 2, loadDb -20, bandWidth 0, sampleRate 16000).  Y_dev [U][Nmax][M/2+1]
  * complex64 -> out_dev same shape; gn_dev (optional) [U][M/2+1][upperN-lowerN+1] complex128 = the prediction filters.  The
@@ -550,6 +579,8 @@ dsr_status dsr_wpe_multi_feature_set_filter_channel(dsr_stream* feature, int fil
 /* SubbandDS/GSC/MVDR as a stream: channels are analysis-bank streams (setChannel) */
 dsr_status dsr_subband_bf_create(dsr_bf* weights, const char* name, dsr_stream** out);
 dsr_status dsr_subband_bf_set_channel(dsr_stream* bf, dsr_stream* chan);
+/* SubbandMMI as a stream (beamformer.i:255-287): channels through dsr_subband_bf_set_channel; frames beyond fftLen/2 are the conjugate mirror */
+dsr_status dsr_subband_mmi_stream_create(dsr_mmi* weights, int fftLen, const char* name, dsr_stream** out);
 /* SubbandOrthogonalizer(beamformer, outChanX) (beamformer.h:436-..., beamformer.cc:2817-2849) as a stream over a subband-beamformer operator:
  * outChanX <= 0: the beamformer's output; > 0: column outChanX-1 of the blocking matrices applied to the same snapshots (bins above M/2 as the
  * reference leaves them: the beamformer output's mirror) */

@@ -305,6 +305,80 @@ def gsc_rls(X, wq, B, myu=0.9, sigma2=0.0, sigma2init=0.01, alpha=-1.0, qctype=0
     return Y, wa
 
 
+class SubbandMMI:
+    """SubbandMMI (beamformer.h:264-312, beamformer.cc:1753-2319) over oracle/orc_mmi.c; method names as in the reference."""
+
+    def __init__(self, fftLen=512, halfBandShift=False, targetSourceX=0, nSource=2, pfType=0, alpha=0.9, chanN=None):
+        L = lib(); L.orc_mmi_create.restype = C.c_void_p
+        self.M, self.Cn, self.nSource, self.hbs, self.NC = fftLen, int(chanN), nSource, bool(halfBandShift), 1
+        self.h = C.c_void_p(L.orc_mmi_create(fftLen, int(chanN), int(bool(halfBandShift)), targetSourceX, nSource, pfType, C.c_double(alpha)))
+
+    def __del__(self):
+        try:
+            L = lib(); L.orc_mmi_free.argtypes = [C.c_void_p]; L.orc_mmi_free(self.h)
+        except Exception:
+            pass
+
+    def reset(self):
+        L = lib(); L.orc_mmi_reset.argtypes = [C.c_void_p]; L.orc_mmi_reset(self.h)
+
+    def useBinaryMask(self, avgFactor=-1.0, fwidth=1, type=0):
+        L = lib(); L.orc_mmi_use_binary_mask.argtypes = [C.c_void_p, C.c_double, C.c_uint, C.c_uint]
+        L.orc_mmi_use_binary_mask(self.h, avgFactor, fwidth, type)
+
+    def calcWeights(self, sampleRate, delays):
+        d = np.ascontiguousarray(delays, np.float64); assert d.shape == (self.nSource, self.Cn)
+        L = lib(); L.orc_mmi_calc_weights.argtypes = [C.c_void_p, C.c_double, C.c_void_p]
+        L.orc_mmi_calc_weights(self.h, sampleRate, _p(d)); self.NC = 1
+
+    def calcWeightsN(self, sampleRate, delays, NC=2):
+        d = np.ascontiguousarray(delays, np.float64); assert d.shape == (self.nSource, self.Cn)
+        L = lib(); L.orc_mmi_calc_weights_n.argtypes = [C.c_void_p, C.c_double, C.c_void_p, C.c_uint]
+        rc = L.orc_mmi_calc_weights_n(self.h, sampleRate, _p(d), NC)
+        if rc != 0:
+            raise ValueError("calcWeightsN: rc %d" % rc)
+        self.NC = NC
+
+    def setActiveWeights_f(self, fbinX, packedWeights, option=0):
+        w = np.ascontiguousarray(packedWeights, np.float64)
+        if w.shape != (self.nSource, 2 * (self.Cn - self.NC)):
+            raise ValueError("packed weights must be [%d][%d]" % (self.nSource, 2 * (self.Cn - self.NC)))
+        L = lib(); L.orc_mmi_set_active_weights_f.argtypes = [C.c_void_p, C.c_uint, C.c_void_p, C.c_int]
+        rc = L.orc_mmi_set_active_weights_f(self.h, fbinX, _p(w), option)
+        if rc != 0:
+            raise ValueError("setActiveWeights_f: rc %d" % rc)
+
+    def setHiActiveWeights_f(self, fbinX, pkdWa, pkdwb, option=0):
+        a = np.ascontiguousarray(pkdWa, np.float64); b = np.ascontiguousarray(pkdwb, np.float64)
+        if a.size != 2 * self.nSource * (self.Cn - self.NC) * self.nSource or b.size != 2 * self.nSource * self.nSource:
+            raise ValueError("sizes")
+        L = lib(); L.orc_mmi_set_hi_active_weights_f.argtypes = [C.c_void_p, C.c_uint, C.c_void_p, C.c_void_p, C.c_int]
+        rc = L.orc_mmi_set_hi_active_weights_f(self.h, fbinX, _p(a), _p(b), option)
+        if rc != 0:
+            raise ValueError("setHiActiveWeights_f: rc %d" % rc)
+
+    def get(self, srcX, kind):
+        """kind: 'wq' [M][C], 'wl' [M][C], 'B' [M][C][C-NC], 'ta' [M][C], 'wa' [M][C-NC]"""
+        k = {"wq": 0, "wl": 1, "B": 2, "ta": 3, "wa": 4}[kind]; bs = self.Cn - self.NC
+        shape = {0: (self.M, self.Cn), 1: (self.M, self.Cn), 2: (self.M, self.Cn, bs), 3: (self.M, self.Cn), 4: (self.M, bs)}[k]
+        out = np.zeros(shape, np.complex128)
+        L = lib(); L.orc_mmi_get.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+        L.orc_mmi_get(self.h, srcX, k, _p(out))
+        return out
+
+    def run(self, X):
+        """X [C][T][Fin] complex (Fin = fftLen with halfBandShift, else >= fftLen/2+1) -> the frames' output vectors [T][fftLen]."""
+        X = np.ascontiguousarray(X, np.complex128); Cn, T, Fin = X.shape
+        out = np.zeros((T, self.M), np.complex128)
+        L = lib(); L.orc_mmi_next.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+        for t in range(T):
+            xt = np.ascontiguousarray(X[:, t, :])
+            rc = L.orc_mmi_next(self.h, _p(xt), Fin, _p(out[t]))
+            if rc != 0:
+                raise ValueError("SubbandMMI.next: rc %d" % rc)
+        return out
+
+
 # ------------------------------------------------------------------ MFCC chain
 def zelinski_postfilter(X, Y, wq, alpha=0.6, type=2, minFrames=0):
     """X [C][T][F], Y [T][F], wq [F][C] complex -> (out [T][F] complex128, wp1 [T][F]) (postfilter.cc:56-221,428-493)."""

@@ -77,6 +77,20 @@ void orc_divide_nondiag(double* R, int C, int M, float mu);
 void orc_diagonal_loading(double* R, int C, int M, float w);
 /* complex<float> SVD based pseudo inverse (beamformer.cc:253-305). returns 1 ok / 0 failed */
 int  orc_pseudoinverse(const double* A, int n, double* invA, float thr);
+int  orc_pseudoinverse_mn(const double* A, int M, int N, double* invA /*[N][M]*/, float thr);
+
+/* SubbandMMI (beamformer.cc:1753-2319): one weight set per source, GSC output of the target, Zelinski post-filter, binary mask */
+typedef struct orc_mmi orc_mmi;
+orc_mmi* orc_mmi_create(int fftLen, int chanN, int halfBandShift, int targetSourceX, int nSource, int pfType, double alpha);
+void orc_mmi_free(orc_mmi*);
+void orc_mmi_reset(orc_mmi*);
+void orc_mmi_use_binary_mask(orc_mmi*, double avgFactor, unsigned fwidth, unsigned type);
+int  orc_mmi_calc_weights(orc_mmi*, double sampleRate, const double* delays /*[nSource][C]*/);
+int  orc_mmi_calc_weights_n(orc_mmi*, double sampleRate, const double* delays, unsigned NC);
+int  orc_mmi_set_active_weights_f(orc_mmi*, unsigned fbinX, const double* packed /*[nSource][2(C-NC)]*/, int option);
+int  orc_mmi_set_hi_active_weights_f(orc_mmi*, unsigned fbinX, const double* pkdWa, const double* pkdwb, int option);
+void orc_mmi_get(const orc_mmi*, int srcX, int kind /*0 wq, 1 wl, 2 B, 3 ta, 4 wa*/, double* out);
+int  orc_mmi_next(orc_mmi*, const double* X /*[C][Fin] complex*/, int Fin, double* out /*[fftLen] complex*/);
 /* LINPACK csvdc, job 11 (orc_svd.c): interleaved complex<float>, column major; s, e hold 2 (n + p) + 2 entries */
 int  orc_csvdc(float* x, int ldx, int n, int p, float* s, float* e, float* u, int ldu, float* v, int ldv);
 void orc_mvdr_weights(const double* wq, const double* R, int C, int M, double thr,

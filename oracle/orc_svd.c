@@ -295,6 +295,33 @@ int orc_csvdc(float* xf, int ldx, int n, int p, float* sf, float* ef, float* uf,
 #undef E
 }
 
+int orc_pseudoinverse_mn(const double* A, int M, int N, double* invA, float thr)
+{
+  /* beamformer.cc:253-305 for an M x N matrix (A row-major [M][N], invA row-major [N][M]): csvdc(job 11) in complex<float>; singular
+     values below the threshold are zeroed and flag failure; invA(j,i) = sum_k v(j,k) s(k) conj(u(i,k)) accumulated in float.  The shipped
+     loops run k to N whatever M is; for M < N that reads singular values csvdc never set and columns of u that do not exist -- those terms
+     are taken as zero here (only scaling() of a nSource x chanN demixing matrix gets there, beamformer.cc:1862). */
+  const int K = M < N ? M : N;
+  cc* a = (cc*) malloc(sizeof(cc) * M * N); cc* u = (cc*) calloc((size_t) M * M, sizeof(cc)); cc* v = (cc*) calloc((size_t) N * N, sizeof(cc));
+  cc* s = (cc*) calloc((size_t) 2 * (M + N) + 2, sizeof(cc)); cc* e = (cc*) calloc((size_t) 2 * (M + N) + 2, sizeof(cc));
+  int ret = 1;
+  for (int i = 0; i < M; i++) for (int j = 0; j < N; j++)
+    a[i + (size_t) j * M] = (float) A[2 * ((size_t) i * N + j)] + I * (float) A[2 * ((size_t) i * N + j) + 1];
+  if (orc_csvdc((float*) a, M, M, N, (float*) s, (float*) e, (float*) u, M, (float*) v, N) != 0) ret = 0;
+  for (int k = 0; k < N; k++) {
+    if (cabsf(s[k]) < thr) { s[k] = 0.0f; ret = 0; }
+    else s[k] = r_div(1.0f, s[k]);
+  }
+  for (int i = 0; i < M; i++)
+    for (int j = 0; j < N; j++) {
+      cc x = 0.0f;
+      for (int k = 0; k < K; k++) x = c_add(x, r_mul(r_mul(v[j + (size_t) k * N], s[k]), conjf(u[i + (size_t) k * M])));
+      invA[2 * ((size_t) j * M + i)] = crealf(x); invA[2 * ((size_t) j * M + i) + 1] = cimagf(x);
+    }
+  free(a); free(u); free(v); free(s); free(e);
+  return ret;
+}
+
 int orc_pseudoinverse(const double* A, int n, double* invA, float thr)
 {
   /* beamformer.cc:253-305: csvdc(job 11) in complex<float>; singular values below the threshold are zeroed and flag

@@ -1,0 +1,88 @@
+"""SubbandMMI weight design through the C-ABI (host set-up work: no GPU) against the oracle's restatement of beamformer.cc:1753-1968."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "distantspeechrecognition-mirror_amd"))
+from oracle import oracle as O
+import dsr._capi as K
+
+
+def _pair(M, Cn, hbs, nSource, NC, seed):
+    rng = np.random.default_rng(seed)
+    d = rng.uniform(0.0, 4e-4, (nSource, Cn))
+    a = K.SubbandMMI(M, Cn, hbs, 0, nSource, 0, 0.9); b = O.SubbandMMI(M, hbs, 0, nSource, 0, 0.9, chanN=Cn)
+    if NC == 1:
+        a.calcWeights(16000.0, d); b.calcWeights(16000.0, d)
+    else:
+        a.calcWeightsN(16000.0, d, NC); b.calcWeightsN(16000.0, d, NC)
+    return a, b, rng
+
+
+def _same(a, b, nSource, tol=1e-11):
+    for s in range(nSource):
+        for kind in ("wq", "wl", "B", "ta", "wa"):
+            x, y = a.get(s, kind), b.get(s, kind)
+            assert np.allclose(x, y, rtol=tol, atol=tol * max(1.0, np.abs(y).max())), (s, kind, np.abs(x - y).max())
+
+
+@pytest.mark.parametrize("M,Cn,hbs,nSource,NC", [(32, 4, False, 2, 1), (32, 5, False, 2, 2), (32, 6, False, 3, 3), (16, 4, True, 2, 1), (16, 5, True, 2, 2)])
+def test_mmi_weights(M, Cn, hbs, nSource, NC):
+    a, b, rng = _pair(M, Cn, hbs, nSource, NC, seed=M + Cn + NC)
+    _same(a, b, nSource)
+    if NC >= 2 and not hbs:                                                     # the null constraints hold (bins 1..M/2-1): unit gain on the target, zero on the others
+        wq = a.get(0, "wq"); f = 3
+        # (the delays are the ones _pair drew: re-draw them with the same seed)
+        d = np.random.default_rng(M + Cn + NC).uniform(0.0, 4e-4, (nSource, Cn))
+        vT = np.exp(-2j * np.pi * f * d[0] * 16000.0 / M); vI = np.exp(-2j * np.pi * f * d[1] * 16000.0 / M)
+        tol = 1e-9 if NC == 2 else 1e-4                                         # NC > 2 inverts through the complex<float> SVD (beamformer.cc:356-359)
+        assert abs(np.vdot(wq[f], vT) - 1.0) < tol and abs(np.vdot(wq[f], vI)) < tol
+    bs = Cn - NC
+    for f in (0, 1, M // 2, M - 1):
+        for option in (0, 1):
+            if option == 1 and nSource > 2:
+                continue
+            w = rng.standard_normal((nSource, 2 * bs))
+            a.setActiveWeights_f(f, w, option); b.setActiveWeights_f(f, w, option)
+    # option 1 goes through the complex<float> SVD: the scale factors carry float rounding (identical code on both sides: compared tightly all the same)
+    _same(a, b, nSource, tol=1e-9)
+    for f in (2, 5):
+        for option in (0, 1):
+            pa = rng.standard_normal(2 * nSource * bs * nSource); pb = rng.standard_normal(2 * nSource * nSource)
+            a.setHiActiveWeights_f(f, pa, pb, option); b.setHiActiveWeights_f(f, pa, pb, option)
+    _same(a, b, nSource, tol=1e-9)
+
+
+def test_mmi_errors():
+    m = K.SubbandMMI(16, 4, False, 0, 2, 0, 0.9)
+    with pytest.raises(K.DsrError) as e:
+        m.setActiveWeights_f(1, np.zeros((2, 6)))
+    assert e.value.status == 1 and "calcWeightsX" in str(e.value)             # j_error "call calcWeightsX() once" (beamformer.cc:1823-1826)
+    m.calcWeights(16000.0, np.zeros((2, 4)))
+    with pytest.raises(K.DsrError) as e:
+        m.setActiveWeights_f(1, np.zeros((3, 6)))
+    assert e.value.status == 1                                                   # rows != nSource (:1827-1830)
+    with pytest.raises(K.DsrError) as e:
+        m.setActiveWeights_f(1, np.zeros((2, 4)))
+    assert e.value.status == 5                                                   # jdimension_error from calcSidelobeCancellerP_f (:764-766)
+    with pytest.raises(K.DsrError) as e:
+        m.setHiActiveWeights_f(1, np.zeros(5), np.zeros(8))
+    assert e.value.status == 1
+    with pytest.raises(K.DsrError) as e:
+        m.calcWeightsN(16000.0, np.zeros((2, 4)), 1)
+    assert e.value.status == 5                                                   # calcMainlobeN: 1 < NC <= chanN (:633-635)
+    with pytest.raises(K.DsrError):
+        K.SubbandMMI(16, 4, False, 0, 2, 0x04, 0.9)                              # APAB: refused, see csrc/k_mmi.hip
+
+
+def test_pseudoinverse_wide_matrix():
+    """scaling() hands a nSource x chanN matrix to the pseudo-inverse (beamformer.cc:1862): W Wp = I for full row rank."""
+    rng = np.random.default_rng(3)
+    A = rng.standard_normal((2, 6)) + 1j * rng.standard_normal((2, 6))
+    L = O.lib()
+    P = np.zeros((6, 2), np.complex128)
+    L.orc_pseudoinverse_mn(O._p(np.ascontiguousarray(A)), 2, 6, O._p(P), O.C.c_float(1e-7))
+    assert np.abs(A @ P - np.eye(2)).max() < 1e-5
