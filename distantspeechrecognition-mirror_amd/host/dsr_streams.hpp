@@ -318,6 +318,42 @@ class SubbandMVDR : public SubbandDS {
   void setAllLevelsOfDiagonalLoading(float w) { dsr_throw(dsr_bf_diagonal_loading(weights(), w)); }
   bool calcMVDRWeights(double sampleRate, double dThreshold = 1.0E-8, bool calcInverseMatrix = true) { (void) calcInverseMatrix; dsr_throw(dsr_bf_calc_mvdr_weights(weights(), sampleRate, dThreshold)); return true; }
 };
+// ---- beamformer.h:264-312 (SubbandMMI): one GSC per source, Zelinski post-filter, binary mask; matrices row-major as gsl_matrix
+class SubbandMMI : public VectorComplexFeatureStream {
+ public:
+  SubbandMMI(unsigned fftLen = 512, bool halfBandShift = false, unsigned targetSourceX = 0, unsigned nSource = 2, int pfType = 0, double alpha = 0.9, const String& nm = "SubbandMMI")
+    : _fftLen(fftLen), _hbs(halfBandShift), _target(targetSourceX), _nSource(nSource), _pfType(pfType), _alpha(alpha), _nm(nm), _w(0), _mask(false), _avg(-1.0), _fwidth(1), _mtype(0) {}
+  ~SubbandMMI() { if (_w) dsr_mmi_destroy(_w); }
+  void setChannel(VectorComplexFeatureStreamPtr& chan) { _channelList.push_back(chan); }
+  unsigned chanN() const { return (unsigned) _channelList.size(); }
+  void useBinaryMask(double avgFactor = -1.0, unsigned fwidth = 1, unsigned type = 0) { _mask = true; _avg = avgFactor; _fwidth = fwidth; _mtype = type; if (_w) dsr_throw(dsr_mmi_use_binary_mask(_w, avgFactor, fwidth, type)); }
+  void calcWeights(double sampleRate, const double* delays /*[nSource][chanN]*/) { dsr_throw(dsr_mmi_calc_weights(weights(), sampleRate, delays)); }
+  void calcWeightsN(double sampleRate, const double* delays, unsigned NC = 2) { dsr_throw(dsr_mmi_calc_weights_n(weights(), sampleRate, delays, NC)); }
+  void setActiveWeights_f(unsigned fbinX, const double* packedWeights, size_t rows, size_t cols, int option = 0) {
+    if (!_w) throw j_error(JERROR, "call calcWeightsX() once");
+    dsr_throw(dsr_mmi_set_active_weights_f(_w, fbinX, packedWeights, rows, cols, option));
+  }
+  void setHiActiveWeights_f(unsigned fbinX, const double* pkdWa, size_t nWa, const double* pkdwb, size_t nWb, int option = 0) {
+    if (!_w) throw j_error(JERROR, "call calcWeightsX() once");
+    dsr_throw(dsr_mmi_set_hi_active_weights_f(_w, fbinX, pkdWa, nWa, pkdwb, nWb, option));
+  }
+  virtual const std::complex<double>* next(int frameX = -5) {
+    if (!_h) throw j_error(JERROR, "call calcWeightsX() once");
+    return VectorComplexFeatureStream::next(frameX);
+  }
+ private:
+  dsr_mmi* weights() {
+    if (!_w) {
+      dsr_throw(dsr_mmi_create((int) _fftLen, (int) chanN(), _hbs, (int) _target, (int) _nSource, _pfType, _alpha, &_w));
+      if (_mask) dsr_throw(dsr_mmi_use_binary_mask(_w, _avg, _fwidth, _mtype));
+      dsr_stream* h = 0; dsr_throw(dsr_subband_mmi_stream_create(_w, (int) _fftLen, _nm.c_str(), &h)); adopt(h);
+      for (size_t i = 0; i < _channelList.size(); i++) dsr_throw(dsr_subband_bf_set_channel(_h, _channelList[i]->handle()));
+    }
+    return _w;
+  }
+  unsigned _fftLen; bool _hbs; unsigned _target, _nSource; int _pfType; double _alpha; String _nm; dsr_mmi* _w;
+  bool _mask; double _avg; unsigned _fwidth, _mtype; std::vector<VectorComplexFeatureStreamPtr> _channelList;
+};
 #undef DSR_OP
 
 // ======================================================================================================================
