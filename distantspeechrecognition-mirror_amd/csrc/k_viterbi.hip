@@ -1003,7 +1003,7 @@ struct DecoderState {
   DevBuf<uint4> d_lat; DevBuf<double> d_latTtl; DevBuf<long> d_latFrameOff; DevBuf<int> d_arenaLat; DevBuf<int4> d_latFinal; DevBuf<int> d_latInfo;
   int latU = 0, latTmax = 0; long latArenaCap = 0; WfstGraph graphCopy; DevBuf<TokA> d_tokA3; DevBuf<TokB> d_tokB3;
   // symbol tables of the transducer set last (borrowed) and the resolved silSymbol / eosSymbol (decoder.h:740-745)
-  const dsr_lexicon* lexIn = nullptr; const dsr_lexicon* lexOut = nullptr; uint32_t eosX = 0;
+  const dsr_lexicon* lexIn = nullptr; const dsr_lexicon* lexOut = nullptr; uint32_t eosX = 0; std::string eosSymbol;
   // what the last collected decode left: per-utterance results and best paths (pinned staging memory), for bestHypo / bestPath / finalStatesN
   int lastU = 0; size_t lastMaxPath = 0; bool lastPaths = false;
   PinBuf<dsr_decode_result> h_res; PinBuf<int> h_arcs; PinBuf<unsigned> h_words; hipEvent_t evDone = nullptr;
@@ -1138,7 +1138,7 @@ dsr_status dsr_decoder_set_symbols(dsr_decoder* d, const dsr_wfst* g, const char
     if (eosSymbol) { if (!g->lexOut) throw Error(DSR_E_KEY, "the transducer has no output lexicon to look '%s' up in", eosSymbol); eosX = g->lexOut->index(eosSymbol); }
     const dsr_status s = dsr_decoder_set(d, g);
     if (s != DSR_OK) throw Error(s, "%s", dsr_last_error());
-    d->cfg.silenceX = silX; d->eosX = eosX; d->lexIn = g->lexIn; d->lexOut = g->lexOut;
+    d->cfg.silenceX = silX; d->eosX = eosX; d->lexIn = g->lexIn; d->lexOut = g->lexOut; d->eosSymbol = eosSymbol ? eosSymbol : "";
   });
 }
 uint32_t dsr_decoder_eos_index(const dsr_decoder* d) { return d ? d->eosX : 0; }
@@ -1360,33 +1360,74 @@ dsr_status dsr_decoder_decode_batch(dsr_decoder* d, const float* score, const in
 
 // _Decoder::lattice() (decoder.h:805-860) for utterance u of the last decode (cfg.latticeTokens > 0)
 struct dsr_lattice : dsr::LatticeData {};
+// the placement log of utterance u of the last lattice-mode decode, copied to the host
+namespace {
+struct LatHost {
+  std::vector<long> frameOff; std::vector<dsr::LatPlace> place; std::vector<double> ttl; std::vector<dsr::LatBp> arena; std::vector<int> arenaLat; std::vector<dsr::LatFinalTok> fin;
+  dsr::LatInput in;
+};
+void load_lat(dsr_decoder* d, int u, uint32_t eosX, LatHost& H)
+{
+  if (d->latU <= 0) throw Error(DSR_E_CONSISTENCY, "Must enable lattice generation during decoding.");                 // decoder.h:807-808
+  if (d->pendingU > 0) throw Error(DSR_E_CONSISTENCY, "a decode is in flight: collect it first");
+  if (u < 0 || u >= d->latU) throw Error(DSR_E_INDEX, "utterance %d of %d", u, d->latU);
+  int info[4]; DSR_HIP(hipMemcpy(info, d->d_latInfo.p + 4 * (size_t) u, sizeof(info), hipMemcpyDeviceToHost));
+  const int finN = info[0], haveNext = info[1], T = info[3]; const long arenaN = info[2];
+  if (T <= 0) throw Error(DSR_E_CONSISTENCY, "utterance %d was not decoded to its end (status of its decode result)", u);
+  H.frameOff.assign((size_t) T + 2, 0);
+  DSR_HIP(hipMemcpy(H.frameOff.data(), d->d_latFrameOff.p + (size_t) u * (d->latTmax + 3), sizeof(long) * ((size_t) T + 2), hipMemcpyDeviceToHost));
+  const long nP = H.frameOff[(size_t) T + 1];
+  H.place.resize((size_t) (nP > 0 ? nP : 1)); H.ttl.resize((size_t) (nP > 0 ? nP : 1));
+  H.arena.resize((size_t) (arenaN > 0 ? arenaN : 1)); H.arenaLat.resize((size_t) (arenaN > 0 ? arenaN : 1)); H.fin.resize((size_t) (finN > 0 ? finN : 1));
+  const size_t cap = (size_t) d->cfg.latticeTokens;
+  if (nP > 0) { DSR_HIP(hipMemcpy(H.place.data(), d->d_lat.p + (size_t) u * cap, sizeof(LatPlace) * (size_t) nP, hipMemcpyDeviceToHost));
+                DSR_HIP(hipMemcpy(H.ttl.data(), d->d_latTtl.p + (size_t) u * cap, sizeof(double) * (size_t) nP, hipMemcpyDeviceToHost)); }
+  if (arenaN > 0) { DSR_HIP(hipMemcpy(H.arena.data(), d->d_arena.p + (size_t) u * (size_t) d->latArenaCap, sizeof(LatBp) * (size_t) arenaN, hipMemcpyDeviceToHost));
+                    DSR_HIP(hipMemcpy(H.arenaLat.data(), d->d_arenaLat.p + (size_t) u * (size_t) d->latArenaCap, sizeof(int) * (size_t) arenaN, hipMemcpyDeviceToHost)); }
+  if (finN > 0) DSR_HIP(hipMemcpy(H.fin.data(), d->d_latFinal.p + (size_t) u * d->cfg.maxActive, sizeof(LatFinalTok) * (size_t) finN, hipMemcpyDeviceToHost));
+  LatInput& in = H.in; in.graph = &d->graphCopy; in.csr = &d->csr; in.tab = &d->tab; in.lmScale = d->cfg.lmScale; in.lmPenalty = d->cfg.lmPenalty; in.silPenalty = d->cfg.silPenalty;
+  in.silenceX = d->cfg.silenceX; in.eosX = eosX; in.T = T; in.place = H.place.data(); in.ttl = H.ttl.data(); in.frameOff = H.frameOff.data();
+  in.arena = H.arena.data(); in.arenaLat = H.arenaLat.data(); in.arenaN = arenaN; in.fin = H.fin.data(); in.finN = finN; in.haveNext = haveNext;
+}
+}  // namespace
+
 dsr_status dsr_decoder_lattice(dsr_decoder* d, int u, uint32_t eosX, dsr_lattice** out)
 {
   return guard([&] {
     if (!d || !out) throw Error(DSR_E_PARAMETER, "null argument");
-    if (d->latU <= 0) throw Error(DSR_E_CONSISTENCY, "Must enable lattice generation during decoding.");                 // decoder.h:807-808
-    if (d->pendingU > 0) throw Error(DSR_E_CONSISTENCY, "a decode is in flight: collect it first");
-    if (u < 0 || u >= d->latU) throw Error(DSR_E_INDEX, "utterance %d of %d", u, d->latU);
-    int info[4]; DSR_HIP(hipMemcpy(info, d->d_latInfo.p + 4 * (size_t) u, sizeof(info), hipMemcpyDeviceToHost));
-    const int finN = info[0], haveNext = info[1], T = info[3]; const long arenaN = info[2];
-    if (T <= 0) throw Error(DSR_E_CONSISTENCY, "utterance %d was not decoded to its end (status of its decode result)", u);
-    std::vector<long> frameOff((size_t) T + 2);
-    DSR_HIP(hipMemcpy(frameOff.data(), d->d_latFrameOff.p + (size_t) u * (d->latTmax + 3), sizeof(long) * ((size_t) T + 2), hipMemcpyDeviceToHost));
-    const long nP = frameOff[(size_t) T + 1];
-    std::vector<LatPlace> place((size_t) (nP > 0 ? nP : 1)); std::vector<double> ttl((size_t) (nP > 0 ? nP : 1));
-    std::vector<LatBp> arena((size_t) (arenaN > 0 ? arenaN : 1)); std::vector<int> arenaLat((size_t) (arenaN > 0 ? arenaN : 1)); std::vector<LatFinalTok> fin((size_t) (finN > 0 ? finN : 1));
-    const size_t cap = (size_t) d->cfg.latticeTokens;
-    if (nP > 0) { DSR_HIP(hipMemcpy(place.data(), d->d_lat.p + (size_t) u * cap, sizeof(LatPlace) * (size_t) nP, hipMemcpyDeviceToHost));
-                  DSR_HIP(hipMemcpy(ttl.data(), d->d_latTtl.p + (size_t) u * cap, sizeof(double) * (size_t) nP, hipMemcpyDeviceToHost)); }
-    if (arenaN > 0) { DSR_HIP(hipMemcpy(arena.data(), d->d_arena.p + (size_t) u * (size_t) d->latArenaCap, sizeof(LatBp) * (size_t) arenaN, hipMemcpyDeviceToHost));
-                      DSR_HIP(hipMemcpy(arenaLat.data(), d->d_arenaLat.p + (size_t) u * (size_t) d->latArenaCap, sizeof(int) * (size_t) arenaN, hipMemcpyDeviceToHost)); }
-    if (finN > 0) DSR_HIP(hipMemcpy(fin.data(), d->d_latFinal.p + (size_t) u * d->cfg.maxActive, sizeof(LatFinalTok) * (size_t) finN, hipMemcpyDeviceToHost));
-    LatInput in; in.graph = &d->graphCopy; in.csr = &d->csr; in.tab = &d->tab; in.lmScale = d->cfg.lmScale; in.lmPenalty = d->cfg.lmPenalty; in.silPenalty = d->cfg.silPenalty;
-    in.silenceX = d->cfg.silenceX; in.eosX = eosX; in.T = T; in.place = place.data(); in.ttl = ttl.data(); in.frameOff = frameOff.data();
-    in.arena = arena.data(); in.arenaLat = arenaLat.data(); in.arenaN = arenaN; in.fin = fin.data(); in.finN = finN; in.haveNext = haveNext;
+    LatHost H; load_lat(d, u, eosX, H);
     dsr_lattice* L = new dsr_lattice();
-    try { build_lattice(in, *L); } catch (...) { delete L; throw; }
+    try { build_lattice(H.in, *L); } catch (...) { delete L; throw; }
     *out = L;
+  });
+}
+
+// _Decoder::writeGMM(conv, channel, spk, utt, cfrom, score, fileName, frameInterval) (decoder.h:1018-1102; decoder.i:177-178): the 1-best path as
+// runs of equal input symbols -- "# utt cfrom score", then per run "conv channel start duration label score", first run first, the end-of-sentence
+// label skipped.  The walk needs every token of the best path with its frame and scores: the decoder must have run with lattice bookkeeping
+// (latticeTokens > 0, the reference's generateLattice) and symbols set (dsr_decoder_set_symbols: labels come from the input lexicon, :1066).
+// fileName "" or NULL: stdout; files are appended to (:1023).  (spk is accepted and unused, as in the reference.)
+dsr_status dsr_decoder_write_gmm(dsr_decoder* d, int u, const char* conv, const char* channel, const char* spk, const char* utt, double cfrom, double score,
+                                 const char* fileName, double frameInterval)
+{
+  return guard([&] {
+    (void) spk;
+    if (!d || !conv || !channel || !utt) throw Error(DSR_E_PARAMETER, "null argument");
+    if (!d->lexIn) throw Error(DSR_E_KEY, "the transducer set on this decoder has no input lexicon");
+    LatHost H; load_lat(d, u, 0u, H);
+    std::vector<GmmRow> rows;
+    if (!best_path_gmm(H.in, rows)) throw Error(DSR_E_CONSISTENCY, "no best token");       // (the reference dereferences a null token here)
+    FILE* fp = (!fileName || !*fileName) ? stdout : fopen(fileName, "a");
+    if (!fp) throw Error(DSR_E_IO, "could not open %s", fileName);
+    fprintf(fp, "# %s %10.4f %10.4f\n", utt, cfrom, score);
+    for (int i = (int) rows.size() - 1; i >= 0; i--) {
+      if (rows[i].inX >= d->lexIn->syms.size()) { if (fp != stdout) fclose(fp); throw Error(DSR_E_INDEX, "input symbol %u is not in the lexicon", rows[i].inX); }
+      const std::string& lab = d->lexIn->symbol(rows[i].inX); const char* label = lab.c_str();
+      if (lab == d->eosSymbol) continue;
+      const double beg = cfrom + rows[i].startX * frameInterval, len = (rows[i].endX - rows[i].startX + 1) * frameInterval;
+      fprintf(fp, "%s %s %7.2f %7.2f %-20s %7.2f\n", conv, channel, beg, len, label, rows[i].score);
+    }
+    if (fp != stdout) fclose(fp); else fflush(stdout);
   });
 }
 void dsr_lattice_destroy(dsr_lattice* L) { delete L; }

@@ -188,6 +188,41 @@ struct Builder {
 
 }  // namespace
 
+// _Decoder::writeGMM (decoder.h:1018-1102) up to the printing: runs of equal input symbols along the best token's chain (epsilon tokens
+// skipped), in the order the reference collects them -- last run first.  The score column is what the shipped code computes: the acoustic
+// score at the end of the run for the first row, the TOTAL score of the run's first token afterwards (:1074), minus the acoustic score of
+// the token before the one the run stopped at.
+bool best_path_gmm(const LatInput& in, std::vector<GmmRow>& rows)
+{
+  rows.clear();
+  if (in.T <= 0 || in.finN <= 0) return false;
+  LatticeData dummy; Builder b(in, dummy); b.prepare();
+  int best = -1; double bestScore = HUGE_VAL;                                   // _bestToken (decoder.h:639-685): list order, strict '<'
+  for (int i = 0; i < in.finN; i++) { const float s = Builder::f((uint32_t) in.fin[i].ac) + Builder::f((uint32_t) in.fin[i].lm); if ((double) s < bestScore) { bestScore = (double) s; best = i; } }
+  if (best < 0) return false;
+  Tok tok = (Tok) in.arenaLat[in.fin[best].bp] << 16;
+  auto inOf = [&](Tok t) -> uint32_t { return in.csr->in[b.arcOf(t)]; };
+  auto acOf = [&](Tok t) -> float { float a, l; b.scoresOf(t, a, l); return a; };
+  auto scoreOf = [&](Tok t) -> float { float a, l; b.scoresOf(t, a, l); return a + l; };      // Token::score(): a float sum (lattice.h:57)
+  Tok nextTok = tok; uint32_t thisX = inOf(tok); int endX = 0;
+  while (tok >= 0 && thisX == 0) { nextTok = tok; tok = b.prevOf(tok); if (tok >= 0) thisX = inOf(tok); }
+  double wscore = (double) acOf(nextTok);
+  if (tok >= 0) endX = b.frameOfTok(tok);
+  while (tok >= 0) {
+    nextTok = tok; uint32_t inX = inOf(tok);
+    while (tok >= 0 && inX == thisX) { nextTok = tok; tok = b.prevOf(tok); if (tok >= 0) inX = inOf(tok); }
+    GmmRow r; r.inX = thisX; r.startX = b.frameOfTok(nextTok); r.endX = endX;
+    Tok pp = tok >= 0 ? b.prevOf(tok) : (Tok) -1;
+    const double oscore = (tok < 0 || pp < 0) ? 0.0 : (double) acOf(pp);
+    r.score = wscore - oscore; rows.push_back(r);
+    wscore = (double) scoreOf(nextTok);
+    thisX = inX;
+    while (tok >= 0 && thisX == 0) { tok = b.prevOf(tok); if (tok >= 0) thisX = inOf(tok); }
+    if (tok >= 0) endX = b.frameOfTok(tok);
+  }
+  return true;
+}
+
 void build_lattice(const LatInput& in, LatticeData& out)
 {
   out = LatticeData();

@@ -31,4 +31,7 @@ struct LatticeData {
 
 void build_lattice(const LatInput& in, LatticeData& out);
 
+struct GmmRow { uint32_t inX; int startX, endX; double score; };
+bool best_path_gmm(const LatInput& in, std::vector<GmmRow>& rows);      // false: no best token
+
 }  // namespace dsr

@@ -750,6 +750,11 @@ class Decoder:
         h = vp(); check(_lib.dsr_decoder_lattice(self.h, int(u), int(eosX), C.byref(h)))
         return Lattice(h)
 
+    def writeGMM(self, u, conv, channel, spk, utt, cfrom, score, fileName="", frameInterval=0.01):
+        """_Decoder::writeGMM (decoder.h:1018-1102) of utterance u of the last decode (needs latticeTokens > 0 and set_symbols)"""
+        check(_lib.dsr_decoder_write_gmm(self.h, int(u), conv.encode(), channel.encode(), spk.encode(), utt.encode(), float(cfrom), float(score),
+                                         (fileName or "").encode(), float(frameInterval)))
+
     def get_dump(self):
         n = i64(); fo = C.POINTER(i64)(); nd = C.POINTER(i32)(); ac = C.POINTER(f32)(); lm = C.POINTER(f32)(); arc = C.POINTER(i32)()
         check(_lib.dsr_decoder_get_dump(self.h, C.byref(n), C.byref(fo), C.byref(nd), C.byref(ac), C.byref(lm), C.byref(arc)))

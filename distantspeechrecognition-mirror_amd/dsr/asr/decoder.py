@@ -109,6 +109,13 @@ class DecoderFlyWeightPtr(object):
     def lattice(self):
         return self._dec.lattice(0, K.load().dsr_decoder_eos_index(self._dec.h))
 
+    def writeGMM(self, conv, channel, spk, utt, cfrom, score, fileName="", frameInterval=0.01):
+        """decoder.i:177-178"""
+        self._dec.writeGMM(0, conv, channel, spk, utt, cfrom, score, fileName, frameInterval)
+
+    def writeCTM(self, *args, **kw):
+        raise K.DsrError(1, "'writeCTM' is not supported in _Decoder base class template.")       # decoder.h:399-401
+
     def bestArcs(self):
         return self._last["arcs"]
 

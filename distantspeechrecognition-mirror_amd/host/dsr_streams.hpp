@@ -529,6 +529,12 @@ class DecoderFlyWeight {
   unsigned finalStatesN() const { int n = 0; dsr_throw(dsr_decoder_final_states_n(_h, 0, &n)); return (unsigned) n; }
   bool traceBackSucceeded() const { int ok = 0; dsr_throw(dsr_decoder_trace_back_succeeded(_h, 0, &ok)); return ok != 0; }
   LatticePtr lattice() { dsr_lattice* l = 0; dsr_throw(dsr_decoder_lattice(_h, 0, dsr_decoder_eos_index(_h), &l)); return LatticePtr(new Lattice(l)); }
+  void writeGMM(const String& conv, const String& channel, const String& spk, const String& utt, double cfrom, double score, const String& fileName = "", double frameInterval = 0.01) {
+    dsr_throw(dsr_decoder_write_gmm(_h, 0, conv.c_str(), channel.c_str(), spk.c_str(), utt.c_str(), cfrom, score, fileName.c_str(), frameInterval));
+  }
+  void writeCTM(const String&, const String&, const String&, const String&, double, double, const String& = "", double = 0.01) {
+    throw j_error(JERROR, "'writeCTM' is not supported in _Decoder base class template.");      // decoder.h:399-401
+  }
   void setBeam(double beam) { dsr_throw(dsr_decoder_set_beam(_h, beam)); }
   dsr_decoder* handle() const { return _h; }
  private:

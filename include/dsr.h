@@ -353,6 +353,13 @@ dsr_status dsr_decoder_decode_collect(dsr_decoder*, dsr_decode_result* res, int3
  * (:921-923).  The lattice object is host memory, independent of the decoder afterwards. */
 typedef struct dsr_lattice dsr_lattice;
 dsr_status dsr_decoder_lattice(dsr_decoder*, int u, uint32_t eosX, dsr_lattice** out);
+/* _Decoder::writeGMM(conv, channel, spk, utt, cfrom, score, fileName, frameInterval) (asr/decoder/decoder.h:1018-1102, decoder.i:177-178): the 1-best
+ * path of utterance u as runs of equal input symbols -- "# utt cfrom score", then "conv channel start duration label score" per run, the
+ * end-of-sentence label skipped; the score column as the shipped code computes it.  Needs lattice bookkeeping (latticeTokens > 0) and the
+ * symbols of dsr_decoder_set_symbols; fileName NULL or "": stdout, otherwise the file is appended to.  (writeCTM is not supported by the
+ * reference's decoder template either, decoder.h:399-401.) */
+dsr_status dsr_decoder_write_gmm(dsr_decoder*, int u, const char* conv, const char* channel, const char* spk, const char* utt, double cfrom, double score,
+                                 const char* fileName, double frameInterval);
 void       dsr_lattice_destroy(dsr_lattice*);
 int        dsr_lattice_num_nodes(const dsr_lattice*);
 int        dsr_lattice_num_edges(const dsr_lattice*);

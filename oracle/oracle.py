@@ -671,16 +671,24 @@ class Wfst:
         return d
 
     def decode(self, scores, beam=100.0, lmScale=12.0, lmPenalty=0.0, silPenalty=0.0, silenceX=0xFFFFFFFF, dump=False, lattice=False, eosX=0,
-               latticeFile=None, writeData=True, topN=0):
+               latticeFile=None, writeData=True, topN=0, gmmRows=False):
         """lattice=True: also _Decoder::lattice() (decoder.h:805-953) -> out["lattice"] = dict(nodeFinal, from, to, in, out, start, end, ac, lm), edges
         in creation order; latticeFile: Lattice::write(file, useSymbols=False, writeData) (lattice.cc:715-757)"""
         sc = _f32(scores); T, nDist = sc.shape
         cfg = DecCfg(beam, lmScale, lmPenalty, silPenalty, silenceX, int(dump), int(topN))
         res = DecResult(); lat = Lattice()
-        L = lib(); L.orc_decode_lat.argtypes = [c_vp, C.POINTER(DecCfg), c_vp, c_int, c_int, C.POINTER(DecResult), C.POINTER(Lattice), C.c_uint]
-        rc = L.orc_decode_lat(self.h, C.byref(cfg), _p(sc), T, nDist, C.byref(res), C.byref(lat) if lattice else None, int(eosX))
+        class GmmRows(C.Structure):
+            _fields_ = [("n", c_int), ("inX", C.POINTER(C.c_uint)), ("startX", C.POINTER(c_int)), ("endX", C.POINTER(c_int)), ("score", C.POINTER(C.c_double))]
+        rows = GmmRows()
+        L = lib(); L.orc_decode_ex.argtypes = [c_vp, C.POINTER(DecCfg), c_vp, c_int, c_int, C.POINTER(DecResult), C.POINTER(Lattice), C.c_uint, C.POINTER(GmmRows)]
+        rc = L.orc_decode_ex(self.h, C.byref(cfg), _p(sc), T, nDist, C.byref(res), C.byref(lat) if lattice else None, int(eosX), C.byref(rows) if gmmRows else None)
         if rc != 0:
             return dict(rc=rc)
+        gmm = None
+        if gmmRows:
+            n = rows.n
+            gmm = None if n < 0 else [(int(rows.inX[i]), int(rows.startX[i]), int(rows.endX[i]), float(rows.score[i])) for i in range(n)]
+            L.orc_gmm_rows_free.argtypes = [C.POINTER(GmmRows)]; L.orc_gmm_rows_free(C.byref(rows))
         latd = None
         if lattice:
             n, e = lat.nNodes, lat.nEdges
@@ -701,6 +709,8 @@ class Wfst:
                    topScore=np.array(res.topScore[:res.nActive], np.float64), finalStatesN=res.finalStatesN)
         if latd is not None:
             out["lattice"] = latd
+        if gmmRows:
+            out["gmmRows"] = gmm          # _Decoder::writeGMM's label runs (decoder.h:1018-1102), last run first: (input symbol, first frame, last frame, score)
         if dump:
             n = res.nActive
             off = np.array(res.dumpOff[: n + 1], np.int64)

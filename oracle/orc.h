@@ -204,6 +204,10 @@ typedef struct {
   int nNodes, capNodes; int* nodeFinal; int* nodeFirstEdge;
   int nEdges, capEdges; int* from; int* to; unsigned* in; unsigned* out; int* start; int* end; double* ac; double* lm; int* nextEdge;
 } orc_lattice;
+/* label runs of the best path as _Decoder::writeGMM collects them (decoder.h:1018-1102), last run first; n = -1: no best token */
+typedef struct { int n; unsigned* inX; int* startX; int* endX; double* score; } orc_gmm_rows;
+int  orc_decode_ex(const orc_wfst* g, const orc_dec_cfg* cfg, const float* scores, int T, int nDist, orc_dec_result* res, orc_lattice* lat, unsigned eosX, orc_gmm_rows* gmm);
+void orc_gmm_rows_free(orc_gmm_rows* R);
 int  orc_decode_lat(const orc_wfst* g, const orc_dec_cfg* cfg, const float* scores, int T, int nDist, orc_dec_result* res, orc_lattice* lat, unsigned eosX);
 int  orc_lattice_write(const orc_lattice* L, const char* file, int writeData);   /* Lattice::write(file, false, writeData) (lattice.cc:715-757) */
 void orc_lattice_free(orc_lattice* L);

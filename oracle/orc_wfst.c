@@ -412,6 +412,41 @@ static void build_lattice(const dec_t* d, orc_lattice* L, unsigned eosX)
   }
   free(t.map);
 }
+/* _Decoder::writeGMM (decoder.h:1018-1102) up to the printing: the runs of equal input symbols along the best token's chain, in the order the
+   reference pushes them (last run first).  Row i: input symbol, first and last frame of the run, score as shipped -- the acoustic score at
+   the end of the run (for the first row pushed; afterwards the TOTAL score of the run's first token: decoder.h:1074) minus the acoustic score
+   of the token two before the run. */
+static void build_gmm_rows(const dec_t* d, orc_gmm_rows* R)
+{
+  const orc_wfst* g = d->g;
+  int reached = 0; int tok = best_token(d, &reached);
+  memset(R, 0, sizeof(*R));
+  if (tok < 0) { R->n = -1; return; }                          /* the reference dereferences a null token here */
+  const int cap = 4096; int capN = cap;
+  R->inX = (unsigned*) malloc(sizeof(unsigned) * capN); R->startX = (int*) malloc(sizeof(int) * capN); R->endX = (int*) malloc(sizeof(int) * capN);
+  R->score = (double*) malloc(sizeof(double) * capN);
+#define TIN(t) (g->arcs[d->tok[t].arc].in)
+  int nextTok = tok; unsigned thisX = TIN(tok); int endX = 0; double wscore;
+  while (tok >= 0 && thisX == 0) { nextTok = tok; tok = d->tok[tok].prev; if (tok >= 0) thisX = TIN(tok); }
+  wscore = d->tok[nextTok].ac;
+  if (tok >= 0) endX = d->tok[tok].frame;
+  while (tok >= 0) {
+    nextTok = tok; unsigned inX = TIN(tok);
+    while (tok >= 0 && inX == thisX) { nextTok = tok; tok = d->tok[tok].prev; if (tok >= 0) inX = TIN(tok); }
+    const int startX = d->tok[nextTok].frame;
+    if (R->n == capN) { capN *= 2; R->inX = (unsigned*) realloc(R->inX, sizeof(unsigned) * capN); R->startX = (int*) realloc(R->startX, sizeof(int) * capN);
+                        R->endX = (int*) realloc(R->endX, sizeof(int) * capN); R->score = (double*) realloc(R->score, sizeof(double) * capN); }
+    const double oscore = (tok < 0 || d->tok[tok].prev < 0) ? 0.0 : d->tok[d->tok[tok].prev].ac;
+    R->inX[R->n] = thisX; R->startX[R->n] = startX; R->endX[R->n] = endX; R->score[R->n] = wscore - oscore; R->n++;
+    wscore = (float) (d->tok[nextTok].ac + d->tok[nextTok].lm);                /* Token::score() is a float sum (lattice.h:57) */
+    thisX = inX;
+    while (tok >= 0 && thisX == 0) { tok = d->tok[tok].prev; if (tok >= 0) thisX = TIN(tok); }
+    if (tok >= 0) endX = d->tok[tok].frame;
+  }
+#undef TIN
+}
+void orc_gmm_rows_free(orc_gmm_rows* R) { if (!R) return; free(R->inX); free(R->startX); free(R->endX); free(R->score); memset(R, 0, sizeof(*R)); }
+
 void orc_lattice_free(orc_lattice* L)
 { if (!L) return; free(L->nodeFinal); free(L->nodeFirstEdge); free(L->from); free(L->to); free(L->in); free(L->out); free(L->start); free(L->end); free(L->ac); free(L->lm); free(L->nextEdge); memset(L, 0, sizeof(*L)); }
 
@@ -445,9 +480,12 @@ int orc_lattice_write(const orc_lattice* L, const char* file, int writeData)
 }
 
 int orc_decode_lat(const orc_wfst* g, const orc_dec_cfg* cfg, const float* scores, int T, int nDist, orc_dec_result* res, orc_lattice* lat, unsigned eosX);
+int orc_decode_ex(const orc_wfst* g, const orc_dec_cfg* cfg, const float* scores, int T, int nDist, orc_dec_result* res, orc_lattice* lat, unsigned eosX, orc_gmm_rows* gmm);
 int orc_decode(const orc_wfst* g, const orc_dec_cfg* cfg, const float* scores, int T, int nDist, orc_dec_result* res)
 { return orc_decode_lat(g, cfg, scores, T, nDist, res, NULL, 0); }
 int orc_decode_lat(const orc_wfst* g, const orc_dec_cfg* cfg, const float* scores, int T, int nDist, orc_dec_result* res, orc_lattice* lat, unsigned eosX)
+{ return orc_decode_ex(g, cfg, scores, T, nDist, res, lat, eosX, NULL); }
+int orc_decode_ex(const orc_wfst* g, const orc_dec_cfg* cfg, const float* scores, int T, int nDist, orc_dec_result* res, orc_lattice* lat, unsigned eosX, orc_gmm_rows* gmm)
 {
   memset(res, 0, sizeof(*res));
   if (g->initial < 0) return -3;
@@ -533,6 +571,7 @@ int orc_decode_lat(const orc_wfst* g, const orc_dec_cfg* cfg, const float* score
   res->finalStatesN = 0;
   for (int h = d.nxt->head; h >= 0; h = d.nxt->h[h].next) if (g->nodes[g->arcs[d.tok[d.nxt->h[h].tok].arc].dst].final) res->finalStatesN++;
   if (lat) { memset(lat, 0, sizeof(*lat)); build_lattice(&d, lat, eosX); }
+  if (gmm) build_gmm_rows(&d, gmm);
   tl_free(&A); tl_free(&B); free(d.tok); free(arcOff); free(csrOf);
   return 0;
 }

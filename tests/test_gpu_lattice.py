@@ -126,3 +126,69 @@ def test_lattice_capacity_and_errors(dsr, cuda):
         dec.lattice(0)
     with pytest.raises(dsr.DsrError):
         dec.lattice(5)
+
+
+@pytest.mark.parametrize("seed,S,nDist,T,beam,kw", [
+    (11, 300, 16, 40, 1e9, dict()),
+    (12, 1000, 32, 60, 30.0, dict(lmPenalty=0.7)),
+    (13, 300, 8, 40, 25.0, dict(eps_frac=0.35, out_frac=0.3)),                       # epsilon tokens on the best path: skipped as "null arcs"
+    (14, 400, 16, 30, 40.0, dict(nFinal=0)),                                          # no final state reached: the best token of _current
+    (15, 300, 12, 50, 30.0, dict(eps_frac=0.2, silPenalty=0.9, silSym=3)),
+])
+def test_write_gmm(dsr, oracle, cuda, tmp_path, seed, S, nDist, T, beam, kw):
+    """_Decoder::writeGMM (decoder.h:1018-1102): label runs of the 1-best path, the text file byte for byte against the oracle's rows"""
+    import torch
+    import ctypes as C
+    from dsr.asr.dictionary import LexiconPtr
+    from dsr.asr.decoder import WFSTFlyWeightPtr
+    gkw = {k: kw[k] for k in ("eps_frac", "nFinal", "out_frac") if k in kw}
+    arcs, fin = synth.random_wfst(S, nDist, seed=seed, nWords=50, **gkw)
+    inlex, outlex = LexiconPtr("in"), LexiconPtr("out")
+    inlex.index("eps", True)
+    for i in range(1, nDist + 1):
+        inlex.index("</s>" if i == 5 else "d%d" % i, True)                             # one label carries the end-of-sentence name: its runs are not printed (:1096)
+    outlex.index("eps", True)
+    for i in range(1, 60):
+        outlex.index("w%d" % i, True)
+    outlex.index("</s>", True)
+    wf = WFSTFlyWeightPtr(None, inlex, outlex)
+    go = oracle.Wfst()
+    for a in arcs:
+        go.add_arc(*a); wf._g.add_arc(*a)
+    for s, c in fin:
+        go.add_final(s, c); wf._g.add_final(s, c)
+    dkw = {k: kw[k] for k in ("lmPenalty", "silPenalty") if k in kw}
+    silSym = "d%d" % kw["silSym"] if "silSym" in kw else None
+    okw = dict(dkw); 
+    if silSym:
+        okw["silenceX"] = kw["silSym"]
+    rng = np.random.default_rng(300 + seed)
+    sc = rng.uniform(0, 10, (2, T, nDist)).astype(np.float32)
+    nfr = [T, T - 9]
+    dec = dsr.Decoder(beam=beam, lmScale=12.0, maxActive=8192, streams=2, latticeTokens=400000, **dkw)
+    dsr.check(dsr.load().dsr_decoder_set_symbols(dec.h, wf._g.h, silSym.encode() if silSym else None, b"</s>"))
+    out = dec.decode_batch(torch.from_numpy(sc).to(cuda), torch.tensor(nfr, dtype=torch.int32, device=cuda))
+    for u in range(2):
+        ro = go.decode(sc[u, :nfr[u]], beam=beam, lmScale=12.0, gmmRows=True, **okw)
+        assert ro["rc"] == 0 and out[u]["status"] == 0 and ro["score"] == out[u]["score"]
+        rows = ro["gmmRows"]; assert rows is not None and len(rows) > 0
+        fn = str(tmp_path / ("u%d.gmm" % u))
+        open(fn, "w").write("kept\n")                                                  # the reference opens the file for appending (:1023)
+        dec.writeGMM(u, "conv7", "A", "spk", "utt%d" % u, 1.25, ro["score"], fn, 0.01)
+        exp = "kept\n" + "# %s %10.4f %10.4f\n" % ("utt%d" % u, 1.25, ro["score"])
+        skipped = 0
+        for inX, startX, endX, score in reversed(rows):
+            label = inlex.symbol(inX)
+            if label == "</s>":
+                skipped += 1; continue
+            exp += "%s %s %7.2f %7.2f %-20s %7.2f\n" % ("conv7", "A", 1.25 + startX * 0.01, (endX - startX + 1) * 0.01, label, score)
+        assert open(fn).read() == exp
+        # the runs tile the utterance: last frame of a run = first frame of the next run - 1 (label runs of the emitting tokens)
+        fr = [(s, e) for _, s, e, _ in reversed(rows)]
+        assert fr[0][0] == 0 and all(a[1] + 1 == b[0] for a, b in zip(fr, fr[1:])) and fr[-1][1] == nfr[u] - 1
+    plain = dsr.Decoder(beam=beam, lmScale=12.0, maxActive=8192, streams=2, **dkw)
+    dsr.check(dsr.load().dsr_decoder_set_symbols(plain.h, wf._g.h, None, b"</s>"))
+    plain.decode_batch(torch.from_numpy(sc).to(cuda), torch.tensor(nfr, dtype=torch.int32, device=cuda))
+    with pytest.raises(dsr.DsrError) as e:
+        plain.writeGMM(0, "c", "A", "s", "u", 0.0, 0.0, str(tmp_path / "x.gmm"))
+    assert e.value.status == 4                                                         # no bookkeeping: "Must enable lattice generation during decoding."
