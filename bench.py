@@ -354,7 +354,7 @@ def main():
             except AttributeError:
                 ncores = os.cpu_count() or 1
             nthr = args.cpu_threads if args.cpu_threads > 0 else min(16, ncores)
-            ncpu = min(24, U)                                           # ~0.35 s per utterance and core: about 8 s single-threaded
+            ncpu = min(36, U)                                           # ~0.31 s per utterance and core: about 11 s single-threaded
             xh = x[:min(U, max(ncpu, 4 * nthr))].cpu().numpy()         # N-core leg: four utterances per core
             done, cdt, cwords, nat = cpu_baseline(mdl, xh[:ncpu], nsamp, beam, max_seconds=12.0, threads=1)
             cpu = dict(value=done * args.secs / 3600.0 / cdt, unit="audio_hours_per_sec", cores=1, kind="port",
