@@ -1078,7 +1078,7 @@ dsr_status dsr_decoder_create(const dsr_decoder_cfg* cfg, dsr_decoder** out)
     if (d->cfg.streams <= 0) {
       hipDeviceProp_t prop; int dev = 0; DSR_HIP(hipGetDevice(&dev)); DSR_HIP(hipGetDeviceProperties(&prop, dev));
       if (const char* e = getenv("DSR_VITERBI_TWO")) d->twoPerCu = atoi(e) != 0;
-      if (d->twoPerCu) d->threads = 256;
+      if (d->twoPerCu && !getenv("DSR_VITERBI_THREADS")) d->threads = 256;
       d->cfg.streams = prop.multiProcessorCount * (d->twoPerCu ? 2 : 1);
       if (const char* e = getenv("DSR_VITERBI_SLOTS")) { const int t = atoi(e); if (t > 0) d->cfg.streams = t; }
     }
@@ -1290,7 +1290,8 @@ dsr_status dsr_decoder_decode_launch(dsr_decoder* d, const float* score, const i
     // utterances advance side by side and fill each other's stalls).  The region after the table holds the slot offsets
     // (u16 per expanding token) and later the LDS side records.
     const bool two = d->twoPerCu;
-    size_t eoffB = two ? 6528 : (size_t) kSideLds * sizeof(Side); const size_t ldsCap = two ? 76160 : 159 * 1024;
+    size_t eoffB = two ? 8960 : (size_t) kSideLds * sizeof(Side); const size_t ldsCap = two ? 74752 : 159 * 1024;     // two per CU: 2 x (74752 + 7 KB of static LDS) <= 160 KB
+    if (two) { if (const char* e = getenv("DSR_VITERBI_EOFFB")) eoffB = (size_t) atoi(e); }
     static_assert((size_t) kSideLds * sizeof(Side) >= (size_t) (kFastE + 2) * sizeof(unsigned short), "side region must cover the slot offsets");
     const int hashMax = two ? 8192 : 16384;
     int useLds = (size_t) nDist * sizeof(float) <= 64 * 1024;
