@@ -188,8 +188,9 @@ __global__ __launch_bounds__(256) void k_mfcc_frames(MfccDev P, const float* __r
 }
 
 // mode 1: batch mean/variance (two sequential passes in fp32, as _calcMeanVariance), mode 2: run-on.
+// wgt (optional): per-frame weights [U][Tmax * wStride], element 0 of the weight stream's frames (MeanSubtractionFeature(src, weight, ...), feature.cc:2577-2707)
 __global__ void k_cmn(const float* __restrict__ cep, const int* __restrict__ Tarr, int U, int Tmax, int N, int mode,
-                      double devNormFactor, float* __restrict__ out)
+                      double devNormFactor, float* __restrict__ out, const float* __restrict__ wgt, int wStride)
 {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= U * N) return;
@@ -199,11 +200,12 @@ __global__ void k_cmn(const float* __restrict__ cep, const int* __restrict__ Tar
   const float* x = cep + (long) u * Tmax * N + i; float* o = out + (long) u * Tmax * N + i;
   if (mode == 1) {
     float m = 0.0f; double ttl = 0.0;
-    for (int t = 0; t < T; t++) { m = __fadd_rn(m, __fmul_rn(1.0f, x[(long) t * N])); ttl += 1.0; }
+    const float* wu = wgt ? wgt + (long) u * Tmax * wStride : nullptr;
+    for (int t = 0; t < T; t++) { const float w = wu ? wu[(long) t * wStride] : 1.0f; m = __fadd_rn(m, __fmul_rn(w, x[(long) t * N])); ttl += (double) w; }
     m = (float) ((double) m / ttl);
     float v = 0.0f;
     if (devNormFactor > 0.0) {
-      for (int t = 0; t < T; t++) { const float f = x[(long) t * N]; v = __fadd_rn(v, __fmul_rn(__fmul_rn(1.0f, f), f)); }
+      for (int t = 0; t < T; t++) { const float w = wu ? wu[(long) t * wStride] : 1.0f; const float f = x[(long) t * N]; v = __fadd_rn(v, __fmul_rn(__fmul_rn(w, f), f)); }
       v = (float) __dsub_rn((double) v / ttl, (double) __fmul_rn(m, m));
     }
     for (int t = 0; t < T; t++) {
@@ -213,8 +215,10 @@ __global__ void k_cmn(const float* __restrict__ cep, const int* __restrict__ Tar
     }
   } else {
     float m = 0.0f, sm = 1.0f; unsigned framesN = 0;
+    const float* wu = wgt ? wgt + (long) u * Tmax * wStride : nullptr;
     for (int t = 0; t < T; t++) {
       const float f = x[(long) t * N];
+      if (!wu || wu[(long) t * wStride] > 0.0f) {                      // frames without weight are normalised but leave the statistics alone (:2587)
       const float wgt = (framesN < 500) ? 0.98f : 0.995f;
       m = (float) __dadd_rn((double) __fmul_rn(wgt, m), __dmul_rn(__dsub_rn(1.0, (double) wgt), (double) f));
       if (devNormFactor > 0.0) {
@@ -222,6 +226,7 @@ __global__ void k_cmn(const float* __restrict__ cep, const int* __restrict__ Tar
         sm = (float) __dadd_rn((double) __fmul_rn(wgt, sm), __dmul_rn(__dsub_rn(1.0, (double) wgt), (double) __fmul_rn(diff, diff)));
       }
       framesN++;
+      }
       float r = __fsub_rn(f, m);
       if (devNormFactor > 0.0) { float va = sm; if (va < 0.0001f) va = 0.0001f; r = (float) ((double) r / __dmul_rn(devNormFactor, (double) __fsqrt_rn(va))); }
       o[(long) t * N] = r;
@@ -409,8 +414,8 @@ void build_dct(int ncep, int nmel, int type, std::vector<float>& dct)
       for (int f = 0; f < nmel; f++) { const double fr = deltaF * (f + 0.5); double cv = cos(fr) / nmel; if (f == 0) cv *= 0.5; dct[(size_t) k * nmel + f] = cv; } }
   } else throw Error(DSR_E_INDEX, "Unknown DCT type");
 }
-void op_cmn(const float* in, int T, int N, int mode, double devNormFactor, float* out, hipStream_t st)
-{ if (T > 0) hipLaunchKernelGGL(k_cmn, dim3(cdiv(N, 64)), dim3(64), 0, st, in, (const int*) nullptr, 1, T, N, mode, devNormFactor, out); }
+void op_cmn(const float* in, int T, int N, int mode, double devNormFactor, float* out, hipStream_t st, const float* wgt, int wStride)
+{ if (T > 0) hipLaunchKernelGGL(k_cmn, dim3(cdiv(N, 64)), dim3(64), 0, st, in, (const int*) nullptr, 1, T, N, mode, devNormFactor, out, wgt, wStride); }
 
 }  // namespace dsr
 
@@ -511,7 +516,7 @@ dsr_status dsr_mfcc_run(dsr_mfcc* p, const float* y, const int32_t* nsamp, int U
     float* cmnOut = cepOut;
     if (c.cmnMode != 0) {
       cmnOut = (stage == 2) ? feat : (p->w_cmn.reserve(nT * c.ncep), p->w_cmn.p);
-      hipLaunchKernelGGL(k_cmn, dim3(cdiv((long) U * c.ncep, 64)), dim3(64), 0, st, cepOut, p->d_T.p, U, Tmax, c.ncep, c.cmnMode, c.devNormFactor, cmnOut);
+      hipLaunchKernelGGL(k_cmn, dim3(cdiv((long) U * c.ncep, 64)), dim3(64), 0, st, cepOut, p->d_T.p, U, Tmax, c.ncep, c.cmnMode, c.devNormFactor, cmnOut, (const float*) nullptr, 0);
       DSR_HIP(hipGetLastError());
     } else if (stage == 2) { DSR_HIP(hipMemcpyAsync(feat, cepOut, nT * c.ncep * sizeof(float), hipMemcpyDeviceToDevice, st)); }
     if (stage == 2) return;

@@ -120,7 +120,15 @@ struct LpcOp : dsr_stream {         // WarpMVDR/BurgMVDR/WarpLPC/BurgLPC feature
     if (nFrames > 0) { dsr_status s = dsr_lpc_run(plan, ups[0]->d<float>(), nFrames, d<double>(), S0); if (s) throw Error(s, "%s", dsr_last_error()); }
   }
 };
-struct CmnOp : dsr_stream { int mode; double dnf; void compute() override { alloc(ups[0]->nFrames); op_cmn(ups[0]->d<float>(), nFrames, size_, mode, dnf, d<float>(), S0); } };
+struct CmnOp : dsr_stream {          // MeanSubtractionFeature(src, weight, devNormFactor, runon): ups[1] (optional) = the weight stream, element 0 of each frame
+  int mode; double dnf;
+  void compute() override {
+    int T = ups[0]->nFrames;
+    if (ups.size() > 1 && ups[1]->nFrames < T) T = ups[1]->nFrames;           // the weight stream ends first: so does the loop over the frames (feature.cc:2640-2644)
+    alloc(T);
+    op_cmn(ups[0]->d<float>(), nFrames, size_, mode, dnf, d<float>(), S0, ups.size() > 1 ? ups[1]->d<float>() : nullptr, ups.size() > 1 ? ups[1]->size_ : 0);
+  }
+};
 struct AdjOp : dsr_stream {
   int delta;
   void compute() override { int T = ups[0]->nFrames; if (delta > 0 && T < delta) T = 0; alloc(T); op_adjacent(ups[0]->d<float>(), T, ups[0]->size_, delta, d<float>(), S0); }
@@ -618,6 +626,14 @@ dsr_status dsr_storage_create(dsr_stream* src, const char* name, dsr_stream** ou
 { return guard([&] { need(src, DSR_T_FLOAT, "StorageFeature"); StorageOp* s = mk<StorageOp>(name, "Storage", src->size_, DSR_T_FLOAT); s->randomAccess = true; s->checkOrder = false; s->add_up(src); *out = s; }); }
 dsr_status dsr_mean_subtraction_create(dsr_stream* src, double dnf, int runon, const char* name, dsr_stream** out)
 { return guard([&] { need(src, DSR_T_FLOAT, "MeanSubtractionFeature"); CmnOp* s = mk<CmnOp>(name, "Mean Subtraction", src->size_, DSR_T_FLOAT); s->mode = runon ? 2 : 1; s->dnf = dnf; s->add_up(src); *out = s; }); }
+dsr_status dsr_mean_subtraction_set_weight(dsr_stream* cmn, dsr_stream* weight)
+{
+  return guard([&] {
+    CmnOp* q = dynamic_cast<CmnOp*>(cmn); if (!q) throw Error(DSR_E_PARAMETER, "not a MeanSubtractionFeature");
+    need(weight, DSR_T_FLOAT, "MeanSubtractionFeature weight"); if (q->ups.size() > 1) throw Error(DSR_E_CONSISTENCY, "the weight stream is already set");
+    q->add_up(weight); q->ready = false;
+  });
+}
 dsr_status dsr_adjacent_create(dsr_stream* single, int delta, const char* name, dsr_stream** out)
 { return guard([&] { need(single, DSR_T_FLOAT, "AdjacentFeature"); AdjOp* s = mk<AdjOp>(name, "Adjacent", (2 * delta + 1) * single->size_, DSR_T_FLOAT); s->delta = delta; s->add_up(single); *out = s; }); }
 dsr_status dsr_linear_transform_create(dsr_stream* src, int sz, const char* name, dsr_stream** out)

@@ -47,6 +47,8 @@ def _unary(create, dflt):
         def __init__(self, src, *a, **kw):
             nm = kw.pop("nm", dflt)
             h, _ = _new(create, src._h, *self._args(src, *a, **kw), _b(nm)); FeatureStreamPtr.__init__(self, h, keep=(src,))
+            if hasattr(self, "_post"):
+                self._post()
     return Op
 
 
@@ -145,9 +147,12 @@ class StorageFeaturePtr(_unary(lambda *a: lib().dsr_storage_create(*a), "Storage
 
 class MeanSubtractionFeaturePtr(_unary(lambda *a: lib().dsr_mean_subtraction_create(*a), "Mean Subtraction")):
     def _args(self, src, weight=None, devNormFactor=0.0, runon=False):
-        if weight is not None:
-            raise K.DsrError(13, "per-frame weights are not supported")
+        self._weight = weight
         return (float(devNormFactor), int(runon))
+
+    def _post(self):
+        if getattr(self, "_weight", None) is not None:                    # (the operator keeps a reference of its own; self._weight keeps the Python face alive)
+            K.check(lib().dsr_mean_subtraction_set_weight(self._h, self._weight._h))
 
 
 class AdjacentFeaturePtr(_unary(lambda *a: lib().dsr_adjacent_create(*a), "Adjacent")):

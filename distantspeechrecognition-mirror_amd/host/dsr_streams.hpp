@@ -125,9 +125,14 @@ class StorageFeature : public VectorFloatFeatureStream {
  private: VectorFloatFeatureStreamPtr _s;
 };
 class MeanSubtractionFeature : public VectorFloatFeatureStream {
- public: MeanSubtractionFeature(const VectorFloatFeatureStreamPtr& src, double devNormFactor = 0.0, bool runon = false, const String& nm = "Mean Subtraction")
+ public: MeanSubtractionFeature(const VectorFloatFeatureStreamPtr& src, const VectorFloatFeatureStreamPtr& weight, double devNormFactor = 0.0, bool runon = false, const String& nm = "Mean Subtraction")
+  : _s(src), _w(weight) {                                        // the reference's signature (feature.h): weight may be a null pointer
+    DSR_OP(MeanSubtractionFeature, float, dsr_mean_subtraction_create(src->handle(), devNormFactor, runon, nm.c_str(), &h))
+    if (_w.get()) dsr_throw(dsr_mean_subtraction_set_weight(_h, _w->handle()));
+  }
+  MeanSubtractionFeature(const VectorFloatFeatureStreamPtr& src, double devNormFactor = 0.0, bool runon = false, const String& nm = "Mean Subtraction")
   : _s(src) { DSR_OP(MeanSubtractionFeature, float, dsr_mean_subtraction_create(src->handle(), devNormFactor, runon, nm.c_str(), &h)) }
- private: VectorFloatFeatureStreamPtr _s;
+ private: VectorFloatFeatureStreamPtr _s, _w;
 };
 class AdjacentFeature : public VectorFloatFeatureStream {
  public: AdjacentFeature(const VectorFloatFeatureStreamPtr& single, unsigned delta = 5, const String& nm = "Adjacent")

@@ -604,6 +604,9 @@ dsr_status dsr_cepstral_create(dsr_stream* mel, int ncep, int type, const char* 
 dsr_status dsr_lpc_feature_create(dsr_stream* src, int order, int correlate, float warp, int method, int kind, const char* name, dsr_stream** out);
 dsr_status dsr_storage_create(dsr_stream* src, const char* name, dsr_stream** out);
 dsr_status dsr_mean_subtraction_create(dsr_stream* src, double devNormFactor, int runon, const char* name, dsr_stream** out);
+/* the optional weight stream of MeanSubtractionFeature(src, weight, devNormFactor, runon) (feature.h, feature.cc:2577-2707): element 0 of its frames weighs
+ * the frame in the batch statistics; in run-on mode frames with weight <= 0 do not update them */
+dsr_status dsr_mean_subtraction_set_weight(dsr_stream* cmn, dsr_stream* weight);
 dsr_status dsr_adjacent_create(dsr_stream* single, int delta, const char* name, dsr_stream** out);
 dsr_status dsr_linear_transform_create(dsr_stream* src, int sz, const char* name, dsr_stream** out);
 dsr_status dsr_linear_transform_set(dsr_stream*, const float* matrix /*[sz][srcSize]*/);

@@ -58,7 +58,7 @@ class MfccCfg(C.Structure):
                 ("vtlnVersion", c_int), ("rate", c_flt), ("low", c_flt), ("up", c_flt),
                 ("filterN", c_int), ("melVersion", c_int), ("logM", c_dbl), ("logA", c_dbl),
                 ("ncep", c_int), ("dctType", c_int), ("devNormFactor", c_dbl), ("delta", c_int),
-                ("outDim", c_int), ("lda", c_vp)]
+                ("outDim", c_int), ("lda", c_vp), ("sphinxFlooring", c_int)]
 
 
 class CbSet(C.Structure):
@@ -546,17 +546,21 @@ def vtln(pw, ratio, edge, version):
     return out
 
 
-def cmn_batch(x, devNormFactor=0.0):
+def cmn_batch(x, devNormFactor=0.0, weights=None):
     x = _f32(x); T, N = x.shape
     out = np.zeros_like(x); mean = np.zeros(N, np.float32); var = np.zeros(N, np.float32)
-    lib().orc_cmn_batch(_p(x), T, N, devNormFactor, _p(out), _p(mean), _p(var))
+    w = None if weights is None else _f32(weights)
+    L = lib(); L.orc_cmn_batch_w.argtypes = [c_vp, c_int, c_int, c_dbl, c_vp, c_vp, c_vp, c_vp]
+    L.orc_cmn_batch_w(_p(x), T, N, devNormFactor, _p(w) if w is not None else None, _p(out), _p(mean), _p(var))
     return out, mean, var
 
 
-def cmn_runon(x, devNormFactor=0.0):
+def cmn_runon(x, devNormFactor=0.0, weights=None):
     x = _f32(x); T, N = x.shape
     out = np.zeros_like(x)
-    lib().orc_cmn_runon(_p(x), T, N, devNormFactor, _p(out))
+    w = None if weights is None else _f32(weights)
+    L = lib(); L.orc_cmn_runon_w.argtypes = [c_vp, c_int, c_int, c_dbl, c_vp, c_vp]
+    L.orc_cmn_runon_w(_p(x), T, N, devNormFactor, _p(w) if w is not None else None, _p(out))
     return out
 
 

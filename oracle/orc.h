@@ -131,6 +131,9 @@ void orc_sgemv_rows(const float* A, int rows, int cols, const float* X, int T, f
 void orc_cmn_batch(const float* in, int T, int N, double devNormFactor, float* out,
                    float* mean, float* var);
 void orc_cmn_runon(const float* in, int T, int N, double devNormFactor, float* out);
+/* with the per-frame weights of MeanSubtractionFeature(src, weight, ...) (feature.cc:2577-2707); weights NULL = all 1 */
+void orc_cmn_batch_w(const float* in, int T, int N, double devNormFactor, const float* weights, float* out, float* mean, float* var);
+void orc_cmn_runon_w(const float* in, int T, int N, double devNormFactor, const float* weights, float* out);
 int  orc_adjacent(const float* in, int T, int N, int delta, float* out);
 /* full chain (config 1): returns number of frames, out [T][outDim] */
 typedef struct {
@@ -139,6 +142,7 @@ typedef struct {
   float rate, low, up; int filterN, melVersion;
   double logM, logA; int ncep, dctType; double devNormFactor; int delta;
   int outDim; const float* lda; /* [outDim][(2delta+1)*ncep] or NULL */
+  int sphinxFlooring;           /* LogFeature: floor the mel energies at 1e-5 instead of adding a (feature.cc:2411-2418) */
 } orc_mfcc_cfg;
 void orc_mfcc_default_cfg(orc_mfcc_cfg* c);
 int  orc_mfcc_num_frames(const orc_mfcc_cfg* c, int nsamp);

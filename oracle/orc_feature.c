@@ -323,14 +323,16 @@ void orc_sgemv_rows(const float* A, int rows, int cols, const float* X, int T, f
 }
 
 void orc_cmn_batch(const float* in, int T, int N, double devNormFactor, float* out, float* mean, float* var)
+{ orc_cmn_batch_w(in, T, N, devNormFactor, NULL, out, mean, var); }
+void orc_cmn_batch_w(const float* in, int T, int N, double devNormFactor, const float* weights, float* out, float* mean, float* var)
 {
-  /* _calcMeanVariance, feature.cc:2633-2707: float accumulators, double total weight */
+  /* _calcMeanVariance, feature.cc:2633-2707: float accumulators, double total weight; weights: element 0 of the weight stream's frames (:2640-2644), NULL = 1 */
   float* mu = (float*) calloc(N, sizeof(float)); float* vr = (float*) calloc(N, sizeof(float));
-  double ttl = 0.0; float wgt = 1.0;
-  for (int t = 0; t < T; t++) { for (int i = 0; i < N; i++) mu[i] = mu[i] + wgt * in[(size_t) t * N + i]; ttl += wgt; }
+  double ttl = 0.0;
+  for (int t = 0; t < T; t++) { float wgt = weights ? weights[t] : 1.0f; for (int i = 0; i < N; i++) mu[i] = mu[i] + wgt * in[(size_t) t * N + i]; ttl += wgt; }
   for (int i = 0; i < N; i++) mu[i] = mu[i] / ttl;
   ttl = 0.0;
-  for (int t = 0; t < T; t++) { for (int i = 0; i < N; i++) { float f = in[(size_t) t * N + i]; vr[i] = vr[i] + wgt * f * f; } ttl += wgt; }
+  for (int t = 0; t < T; t++) { float wgt = weights ? weights[t] : 1.0f; for (int i = 0; i < N; i++) { float f = in[(size_t) t * N + i]; vr[i] = vr[i] + wgt * f * f; } ttl += wgt; }
   for (int i = 0; i < N; i++) { float m = mu[i]; vr[i] = (vr[i] / ttl) - (m * m); }
   for (int t = 0; t < T; t++)
     for (int i = 0; i < N; i++) {
@@ -344,18 +346,22 @@ void orc_cmn_batch(const float* in, int T, int N, double devNormFactor, float* o
 }
 
 void orc_cmn_runon(const float* in, int T, int N, double devNormFactor, float* out)
+{ orc_cmn_runon_w(in, T, N, devNormFactor, NULL, out); }
+void orc_cmn_runon_w(const float* in, int T, int N, double devNormFactor, const float* weights, float* out)
 {
-  /* _nextRunon, feature.cc:2586-2630 */
+  /* _nextRunon, feature.cc:2577-2618: frames whose weight is not positive are normalised but do not update the statistics */
   float* mu = (float*) calloc(N, sizeof(float)); float* vr = (float*) malloc(sizeof(float) * N);
   for (int i = 0; i < N; i++) vr[i] = 1.0f;
   unsigned framesN = 0;
   for (int t = 0; t < T; t++) {
     const float* s = in + (size_t) t * N;
+    if (!weights || weights[t] > 0.0) {
     float wgt = (framesN < 500) ? 0.98f : 0.995f;
     for (int i = 0; i < N; i++) { float comp = wgt * mu[i] + (1.0 - wgt) * s[i]; mu[i] = comp; }
     if (devNormFactor > 0.0)
       for (int i = 0; i < N; i++) { float diff = s[i] - mu[i]; float comp = wgt * vr[i] + (1.0 - wgt) * (diff * diff); vr[i] = comp; }
     framesN++;
+    }
     for (int i = 0; i < N; i++) {
       float v = s[i] - mu[i];
       if (devNormFactor > 0.0) { float va = vr[i]; if (va < 0.0001f) va = 0.0001f; v = v / (devNormFactor * sqrtf(va)); /* C++ sqrt(float) overload */ }
@@ -420,7 +426,7 @@ int orc_mfcc_from_blocks(const orc_mfcc_cfg* c, const float* blocks, int T, int 
   orc_spectral_power(fft, T, F, P, pw);
   orc_vtln(pw, T, P, c->vtlnRatio, c->vtlnEdge, c->vtlnVersion, vt);
   orc_mel(mb, vt, T, P, c->melVersion, mel);
-  orc_log(mel, T, NM, c->logM, c->logA, 0, lg);
+  orc_log(mel, T, NM, c->logM, c->logA, c->sphinxFlooring, lg);
   orc_cosine_matrix(NC, NM, c->dctType, Cm);
   orc_sgemv_rows(Cm, NC, NM, lg, T, cep);
   orc_cmn_batch(cep, T, NC, c->devNormFactor, cmn, NULL, NULL);

@@ -191,11 +191,13 @@ def test_mfcc_chain(dsr, oracle, cuda, headset, stage, tol):
 
 @pytest.mark.parametrize("kw", [dict(vtlnRatio=1.1, vtlnEdge=0.8), dict(vtlnRatio=0.9, vtlnEdge=0.8, vtlnVersion=2),
                                 dict(melVersion=2), dict(dctType=0), dict(dctType=2), dict(cmnMode=2, devNormFactor=3.0),
-                                dict(cmnMode=1, devNormFactor=3.0), dict(padZeros=1), dict(delta=1), dict(delta=5)])
+                                dict(cmnMode=1, devNormFactor=3.0), dict(padZeros=1), dict(delta=1), dict(delta=5), dict(sphinxFlooring=1)])
 def test_mfcc_variants(dsr, oracle, cuda, headset, kw):
     import torch
     n = 24000
     y = headset[5000:5000 + n].copy()
+    if kw.get("sphinxFlooring"):
+        y[3000:9000] = 0.0                                          # digital silence: mel energies below the 1e-5 floor (feature.cc:2411-2418)
     mf = dsr.Mfcc(**kw)
     stage = 2 if "cmnMode" in kw else 0
     out = mf.run(torch.from_numpy(y[None]).to(cuda), stage=stage).cpu().numpy()[0]

@@ -359,3 +359,28 @@ def test_legacy_formats_behind_the_operators(dsr, oracle, cuda, headset, tmp_pat
         with pytest.raises(dsr.DsrError) as e:
             dsr.Gmm(files=(str(tmp_path / fn), str(tmp_path / "one.ds")))
         assert e.value.status == 8
+
+
+@pytest.mark.parametrize("runon,dnf", [(False, 0.0), (False, 3.0), (True, 0.0), (True, 2.0)])
+def test_mean_subtraction_with_frame_weights(dsr, oracle, cuda, runon, dnf):
+    """MeanSubtractionFeature(src, weight, devNormFactor, runon) (feature.cc:2577-2707): element 0 of the weight stream's frames weighs the batch
+    statistics; in run-on mode frames with weight <= 0 are normalised without updating them"""
+    from dsr.btk.feature import MeanSubtractionFeaturePtr
+    from dsr.btk.stream import PyVectorFloatFeatureStreamPtr
+    T, N = 700, 13
+    rng = np.random.default_rng(4)
+    x = (rng.standard_normal((T, N)) * 3.0 + 1.5).astype(np.float32)
+    w = np.zeros((T, 2), np.float32); w[:, 0] = (rng.random(T) > 0.3) * rng.uniform(0.2, 1.0, T); w[:, 1] = 7.0      # only element 0 counts
+
+    class Frames:
+        def __init__(self, a): self.a = a
+        def size(self): return self.a.shape[1]
+        def reset(self): pass
+        def __iter__(self): return iter(self.a)
+    src = PyVectorFloatFeatureStreamPtr(Frames(x)); wsrc = PyVectorFloatFeatureStreamPtr(Frames(w))
+    op = MeanSubtractionFeaturePtr(src, weight=wsrc, devNormFactor=dnf, runon=runon)
+    got = np.stack([np.array(v) for v in op])
+    ref = oracle.cmn_runon(x, dnf, weights=w[:, 0]) if runon else oracle.cmn_batch(x, dnf, weights=w[:, 0])[0]
+    assert got.shape == ref.shape and np.abs(got - ref).max() < 1e-5
+    plain = oracle.cmn_runon(x, dnf) if runon else oracle.cmn_batch(x, dnf)[0]
+    assert np.abs(ref - plain).max() > 1e-3                                  # the weights matter
