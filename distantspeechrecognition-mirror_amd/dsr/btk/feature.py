@@ -13,8 +13,7 @@ def _b(s):
 
 
 class SampleFeaturePtr(FeatureStreamPtr):
-    """feature.i:526-528.  read() takes 16-bit PCM WAV (libsndfile in the reference, feature.cc:243-393; samples are
-    kept un-normalised, i.e. at int16 scale, as with norm == 0)."""
+    """feature.i:526-528; read(): see there."""
 
     def __init__(self, fn="", blockLen=320, shiftLen=160, padZeros=False, nm="Sample"):
         h, _ = _new(lib().dsr_sample_feature_create, blockLen, shiftLen, int(padZeros), _b(nm)); FeatureStreamPtr.__init__(self, h)
@@ -22,17 +21,57 @@ class SampleFeaturePtr(FeatureStreamPtr):
         if fn != "":
             self.read(fn)
 
-    def read(self, fn, samplerate=44100, chX=1, chN=1):
+    def read(self, fn, format=0, samplerate=16000, chX=1, chN=1, cfrom=0, to=-1, outsamplerate=-1, norm=0.0):
+        """SampleFeature::read (feature.cc:243-393, feature.i:487-489).  The reference reads through libsndfile's sf_readf_float; here RIFF/WAV
+        PCM of 8, 16, 24 or 32 bits (Python's wave module).  norm == 0 keeps the file's integer scale (SFC_SET_NORM_FLOAT off), otherwise samples
+        are normalised to [-1, 1) and, for norm != 1, multiplied by norm.  The error branches are the reference's: chX == 0 and chX out of range
+        are jconsistency errors, an empty range a jio error.  Sample-rate conversion (outsamplerate != the file's rate; SRCONV builds only) is
+        refused.  Returns the number of frames read."""
         try:
             w = wave.open(fn, "rb")
-        except (IOError, OSError, wave.Error) as e:
-            raise IOError("Could not open file %s: %s" % (fn, e))
-        if w.getsampwidth() != 2:
-            raise IOError("only 16-bit PCM is supported")
-        a = np.frombuffer(w.readframes(w.getnframes()), dtype="<i2").reshape(-1, w.getnchannels())
-        self._rate = w.getframerate()
-        self.setSamples(a[:, max(0, chX - 1)].astype(np.float32), self._rate)
-        return a.shape[0]
+        except (IOError, OSError, wave.Error, EOFError) as e:
+            raise IOError("Could not open file %s." % fn)
+        try:
+            nch, sw, rate, frames = w.getnchannels(), w.getsampwidth(), w.getframerate(), w.getnframes()
+            if outsamplerate == -1:
+                outsamplerate = rate
+            if to < 0 or to >= frames:
+                to = frames - 1
+            if cfrom < 0:
+                cfrom = 0
+            if cfrom > to or cfrom > frames:
+                raise IOError("Cannot load samples from %d to %d." % (cfrom, to))
+            n = to - cfrom + 1
+            w.setpos(cfrom); raw = w.readframes(n)
+        finally:
+            w.close()
+        if sw == 1:
+            a = (np.frombuffer(raw, np.uint8).astype(np.int32) - 128)
+        elif sw == 2:
+            a = np.frombuffer(raw, "<i2").astype(np.int32)
+        elif sw == 3:
+            b = np.frombuffer(raw, np.uint8).reshape(-1, 3).astype(np.int32)
+            a = b[:, 0] | (b[:, 1] << 8) | (b[:, 2] << 16); a = np.where(a >= 1 << 23, a - (1 << 24), a)
+        elif sw == 4:
+            a = np.frombuffer(raw, "<i4").astype(np.int64)
+        else:
+            raise IOError("sndfile error: unsupported sample width %d." % sw)
+        a = a.reshape(-1, nch)
+        if chX > nch or chX < 1:
+            if chX == 0:
+                raise K.DsrError(4, "Multi-channel read is not yet supported.")
+            raise K.DsrError(4, "Selected channel out of range of available channels.")
+        x = a[:, chX - 1].astype(np.float64)
+        if norm != 0.0:
+            x = x / float(1 << (8 * sw - 1))                          # libsndfile's float normalisation
+        x = x.astype(np.float32)
+        if rate != outsamplerate:
+            raise K.DsrError(1, "sample rate conversion (%d -> %d) is not supported" % (rate, outsamplerate))
+        if norm != 1.0 and norm != 0.0:
+            x = x * np.float32(norm)
+        self._rate = rate
+        self.setSamples(x, rate)
+        return x.shape[0]
 
     def setSamples(self, samples, sampleRate=16000):
         a = np.ascontiguousarray(samples, dtype=np.float32)

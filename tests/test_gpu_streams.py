@@ -384,3 +384,48 @@ def test_mean_subtraction_with_frame_weights(dsr, oracle, cuda, runon, dnf):
     assert got.shape == ref.shape and np.abs(got - ref).max() < 1e-5
     plain = oracle.cmn_runon(x, dnf) if runon else oracle.cmn_batch(x, dnf)[0]
     assert np.abs(ref - plain).max() > 1e-3                                  # the weights matter
+
+
+def test_sample_feature_read_formats_and_branches(dsr, cuda, tmp_path):
+    """SampleFeature::read (feature.cc:243-393): channel selection, sample range, the integer scale of norm == 0 and libsndfile's float normalisation
+    otherwise, and the reference's error branches -- on PCM WAV files of 8, 16, 24 and 32 bits"""
+    import wave
+    from dsr.btk.feature import SampleFeaturePtr
+    rng = np.random.default_rng(9)
+    n, nch = 1000, 2
+    for sw in (1, 2, 3, 4):
+        bits = 8 * sw
+        v = rng.integers(-(1 << (bits - 1)), 1 << (bits - 1), size=(n, nch), dtype=np.int64)
+        fn = str(tmp_path / ("s%d.wav" % bits))
+        with wave.open(fn, "wb") as w:
+            w.setnchannels(nch); w.setsampwidth(sw); w.setframerate(16000)
+            if sw == 1:
+                raw = (v + 128).astype(np.uint8).tobytes()
+            elif sw == 3:
+                u = (v & 0xFFFFFF).astype(np.uint32)
+                raw = np.stack([u & 255, (u >> 8) & 255, (u >> 16) & 255], axis=-1).astype(np.uint8).tobytes()
+            else:
+                raw = v.astype("<i%d" % sw).tobytes()
+            w.writeframes(raw)
+        s = SampleFeaturePtr(blockLen=100, shiftLen=100)
+        assert s.read(fn, chX=2) == n and s.getSampleRate() == 16000
+        got = np.concatenate([np.array(b) for b in s])
+        assert len(got) >= n - 100 and np.array_equal(got, v[:len(got), 1].astype(np.float32))  # norm == 0: the file's integer scale (the framing may hold back the last block)
+        assert s.read(fn, chX=1, cfrom=100, to=499, norm=1.0) == 400
+        got = np.concatenate([np.array(b) for b in s])
+        assert len(got) >= 300 and np.array_equal(got, (v[100:100 + len(got), 0] / float(1 << (bits - 1))).astype(np.float32))
+        s.read(fn, chX=1, cfrom=100, to=499, norm=3.0)
+        got3 = np.concatenate([np.array(b) for b in s])
+        assert np.array_equal(got3, got * np.float32(3.0))
+        with pytest.raises(dsr.DsrError) as e:
+            s.read(fn, chX=0)
+        assert e.value.status == 4 and "Multi-channel" in str(e.value)
+        with pytest.raises(dsr.DsrError) as e:
+            s.read(fn, chX=3)
+        assert e.value.status == 4
+        with pytest.raises(IOError):
+            s.read(fn, cfrom=900, to=100)
+        with pytest.raises(dsr.DsrError):
+            s.read(fn, outsamplerate=8000)
+    with pytest.raises(IOError):
+        SampleFeaturePtr(blockLen=100, shiftLen=100).read(str(tmp_path / "missing.wav"))
