@@ -765,8 +765,8 @@ def test_mccowan_postfilter(dsr, oracle, cuda, Cn, ptype, alpha, minFrames, myu)
 def test_lefkimmiatis_postfilter(dsr, oracle, cuda, Cn, ptype, alpha, minFrames, fbinX1, load):
     """postfilter.cc:948-1210 on McCowan's recursions: noise estimate sum (0.5(phi_ii+phi_jj) - phi_ij)/(1 - R_ij), divided by d^H pinv(R) d
     from bin fbinX1 on.  The pseudo-inverse is the reference's single-precision LINPACK csvdc on both sides (product: csrc/svd_linpack.cpp,
-    oracle: orc_svd.c; both pinned bit for bit against the reference's own routine), so the weights agree as McCowan's do: 1e-6 (round 1: a
-    the restated LINPACK csvdc on both sides since round 2; the 2e-4 bar dates from the Jacobi SVD of round 1)."""
+    oracle: orc_svd.c; both pinned bit for bit against the reference's own routine), so the weights agree as McCowan's do: 1e-6 (round 1 ran a
+    double-precision Jacobi SVD on the product side and could only hold 2e-4)."""
     import torch
     rng = np.random.default_rng(70 + Cn)
     U, T, M = 2, 25, 64
