@@ -12,7 +12,7 @@ Outputs:
   Lexicon.txt               copied verbatim (data)
   linpack_csvdc.npz         seeded complex matrices (2x2 .. 64x64: random, diffuse-field coherence matrices of 8/16/64-microphone
                             arrays, rank deficient, zero) and the singular values, U, V and pseudo-inverse that the reference's own
-                            LINPACK csvdc (oracle/_ref) produces for them
+                            LINPACK csvdc (oracle/_ref) produces for them; six rectangular matrices (2x8 .. 8x2, 2x64) the same way
 """
 import os, sys, wave, shutil
 import numpy as np
@@ -80,6 +80,25 @@ for i, (name, A) in enumerate(cases):
             P[b_, a_] = acc
     out["A%d" % i] = A; out["s%d" % i] = s; out["P%d" % i] = P; out["U%d" % i] = np.ascontiguousarray(u); out["V%d" % i] = np.ascontiguousarray(v)
     out["info%d" % i] = np.int32(info)
+# rectangular matrices (round 2): scaling() of SubbandMMI hands an nSource x chanN demixing matrix to the pseudo-inverse (beamformer.cc:1862).  For rows <
+# columns the shipped assembly loop (:283-297) runs over singular values and left vectors csvdc never produced; the golden pseudo-inverse sums the
+# min(rows, cols) terms that exist (same complex<float> accumulation, k ascending).
+rect = [("wide2x8", 2, 8), ("wide3x8", 3, 8), ("wide2x5", 2, 5), ("tall8x2", 8, 2), ("tall6x3", 6, 3), ("wide2x64", 2, 64)]
+for i, (name, n, p_) in enumerate(rect):
+    A = rng.standard_normal((n, p_)) + 1j * rng.standard_normal((n, p_))
+    info, s, u, v = O.ref_csvdc(A)
+    thr = np.float32(1e-7); K = min(n, p_)
+    sinv = np.array([np.complex64(0) if np.abs(x) < thr else np.complex64(1) / x for x in s], np.complex64)
+    P = np.zeros((p_, n), np.complex64)
+    for a_ in range(n):
+        for b_ in range(p_):
+            acc = np.complex64(0)
+            for k in range(K):
+                acc = np.complex64(acc + np.complex64(np.complex64(v[b_, k] * sinv[k]) * np.conj(u[a_, k])))
+            P[b_, a_] = acc
+    out["RA%d" % i] = A; out["Rs%d" % i] = s; out["RP%d" % i] = P; out["RU%d" % i] = np.ascontiguousarray(u); out["RV%d" % i] = np.ascontiguousarray(v)
+    out["Rinfo%d" % i] = np.int32(info)
+out["rnames"] = np.array([c[0] for c in rect])
 out["names"] = np.array([c[0] for c in cases])
 np.savez_compressed(f"{HERE}/linpack_csvdc.npz", **out)
 print("fixtures written to", HERE)

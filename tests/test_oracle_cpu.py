@@ -97,6 +97,28 @@ def test_pseudoinverse_pinned_by_linpack(oracle):
         assert np.abs(np.sort(s.real)[::-1] - sl).max() <= 2e-5 * max(sl[0], 1e-30), name
 
 
+def test_rectangular_csvdc_pinned_by_linpack(oracle):
+    """the same pin for rectangular matrices (2x8 .. 8x2, 2x64): what scaling() of SubbandMMI's nSource x chanN demixing matrix needs
+    (beamformer.cc:1455-1490, 1862) -- singular values, U, V bit for bit; the pseudo-inverse with the min(rows, cols) terms csvdc provides"""
+    z = np.load(os.path.join(GOLDEN, "linpack_csvdc.npz"))
+    names = [str(n) for n in z["rnames"]]
+    assert len(names) >= 6
+    L = oracle.lib()
+    for i, name in enumerate(names):
+        A = z["RA%d" % i]; n, p = A.shape
+        info, s, u, v = oracle.csvdc(A)
+        assert info == int(z["Rinfo%d" % i]), name
+        assert np.array_equal(s.view(np.float32), z["Rs%d" % i].view(np.float32)), name
+        assert np.array_equal(np.ascontiguousarray(u).view(np.float32), z["RU%d" % i].view(np.float32)), name
+        assert np.array_equal(np.ascontiguousarray(v).view(np.float32), z["RV%d" % i].view(np.float32)), name
+        P = np.zeros((p, n), np.complex128)
+        L.orc_pseudoinverse_mn(oracle._p(np.ascontiguousarray(A, np.complex128)), n, p, oracle._p(P), oracle.C.c_float(1e-7))
+        assert np.array_equal(P.astype(np.complex64).view(np.float32), z["RP%d" % i].view(np.float32)), name
+        # Moore-Penrose on the side that has full rank
+        E = A @ P if n <= p else P @ A
+        assert np.abs(E - np.eye(min(n, p))).max() < 2e-5, name
+
+
 def test_linpack_ref_live(oracle):
     """When the reference sources are present (authoring container) run csvdc itself again, on fresh matrices: same bits."""
     if oracle.build_ref() is None:
