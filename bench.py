@@ -187,16 +187,24 @@ def main():
     ap.add_argument("--overlap", action="store_true", help="two pipes on two streams: the ragged end of a step's decode runs under the next step's front end "
                     "(+2 %% throughput; the per-kernel event intervals then include waiting for CUs, so the default keeps steps strictly one after the other)")
     ap.add_argument("--serial", action="store_true", help="(default) one pipe, steps strictly one after the other")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend of the multi-rank run: nccl (= RCCL, the default) or gloo -- gloo with "
+                    "DSR_BENCH_DEVICE=0 rehearses the multi-rank control flow with several ranks on ONE GPU (collectives on host tensors)")
     args = ap.parse_args()
 
     import torch
     import torch.distributed as dist
     world = int(os.environ.get("WORLD_SIZE", "1")); rank = int(os.environ.get("RANK", "0")); lrank = int(os.environ.get("LOCAL_RANK", "0"))
+    if os.environ.get("DSR_BENCH_DEVICE"):
+        lrank = int(os.environ["DSR_BENCH_DEVICE"])                              # rehearsal: every rank on this device
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", lrank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", lrank))
+        else:
+            dist.init_process_group(args.backend, rank=rank, world_size=world)
     torch.cuda.set_device(lrank)
     dev = torch.device("cuda", lrank)
+    cdev = dev if args.backend == "nccl" else torch.device("cpu")             # where the (tiny) collectives' tensors live
     import dsr._capi as dsr
     from tests import synth
     dsr.load()
@@ -226,7 +234,7 @@ def main():
     else:
         beam, act = tune_beam(dsr, torch, mdl, sc_probe, nfr_probe)
         if world > 1:   # every rank must use the same beam
-            b = torch.tensor([beam], dtype=torch.float64, device=dev); dist.broadcast(b, 0); beam = float(b.item())
+            b = torch.tensor([beam], dtype=torch.float64, device=cdev); dist.broadcast(b, 0); beam = float(b.item())
     del pp, probe
     # Steps run one after the other on one pipe (clean per-kernel event intervals).  With --overlap, two pipes on two HIP
     # streams: a step is enqueued whole and collected when the pipe is needed again, so the ragged end of one step's decode
@@ -247,7 +255,7 @@ def main():
         # the path's only exchange: gather the 1-best word sequences on rank 0 (RCCL over xGMI)
         if world > 1:
             from dsr.dist import gather_one_best
-            gather_one_best(words, np.array([r.nWords for r in res], np.int32), world, rank, dev, dist)
+            gather_one_best(words, np.array([r.nWords for r in res], np.int32), world, rank, cdev, dist)
         return res, words, pipes[i].stage_ms()
 
     def submit(i):
@@ -297,7 +305,7 @@ def main():
             print("step stage ms: " + " ".join("%.2f" % v for v in sms), file=sys.stderr, flush=True)
         placements += sum(r.placements for r in res); active += sum(r.activeHypos for r in res)
         frames += sum(r.frames + 1 for r in res); bad += sum(1 for r in res if r.status != 0)
-    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    tmax = torch.tensor([dt], dtype=torch.float64, device=cdev)
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
