@@ -99,6 +99,23 @@ __device__ __forceinline__ int wave_incl_scan(int v, int /*lane*/)
   v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xC, 0xF, false);     // row_bcast:31 -> rows 2, 3
   return v;
 }
+// full-wave min / max by DPP row shifts and row broadcasts (as the scan above): vector-ALU speed, the result in lane 63, handed out as a uniform value.
+// (__shfl_xor goes through the LDS crossbar: six dependent ds_bpermute round trips, ~0.3 us per reduction, twice that for a double)
+__device__ __forceinline__ float wave_max_f_uni(float v)
+{
+#define DSR_DPP_F(ctrl, rm) { const float o = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), ctrl, rm, 0xF, false)); v = fmaxf(v, o); }
+  DSR_DPP_F(0x111, 0xF) DSR_DPP_F(0x112, 0xF) DSR_DPP_F(0x114, 0xF) DSR_DPP_F(0x118, 0xF) DSR_DPP_F(0x142, 0xA) DSR_DPP_F(0x143, 0xC)
+#undef DSR_DPP_F
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+__device__ __forceinline__ double wave_min_d_uni(double v)
+{
+#define DSR_DPP_D(ctrl, rm) { const int lo = __double2loint(v), hi = __double2hiint(v); \
+    const double o = __hiloint2double(__builtin_amdgcn_update_dpp(hi, hi, ctrl, rm, 0xF, false), __builtin_amdgcn_update_dpp(lo, lo, ctrl, rm, 0xF, false)); v = (o < v) ? o : v; }
+  DSR_DPP_D(0x111, 0xF) DSR_DPP_D(0x112, 0xF) DSR_DPP_D(0x114, 0xF) DSR_DPP_D(0x118, 0xF) DSR_DPP_D(0x142, 0xA) DSR_DPP_D(0x143, 0xC)
+#undef DSR_DPP_D
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 63), __builtin_amdgcn_readlane(__double2loint(v), 63));
+}
 __device__ __forceinline__ double wave_min_d(double v)
 {
 #pragma unroll
@@ -110,6 +127,35 @@ __device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long v)
 #pragma unroll
   for (int d = 32; d >= 1; d >>= 1) { const unsigned long long o = __shfl_xor(v, d, 64); v = (o < v) ? o : v; }
   return v;
+}
+__device__ __forceinline__ float wave_max_f(float v)
+{
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) v = fmaxf(v, __shfl_xor(v, d, 64));
+  return v;
+}
+// clears a result record with a zero the optimiser cannot see through: the constant {0, 0, 0} tuple of a memset otherwise lives from the kernel's
+// first instruction to its last, in scratch memory, and its 96-bit reload is what trips the register-alignment bug mentioned below
+__device__ __forceinline__ void clear_result(dsr_decode_result* r)
+{
+  int z = 0; asm volatile("" : "+v"(z));
+  int* p = reinterpret_cast<int*>(r);
+#pragma unroll 1
+  for (int i = 0; i < (int) (sizeof(dsr_decode_result) / 4); i++) p[i] = z;
+}
+// a whole token as one 16-byte load (three of its four fields used -> the compiler narrows the load to 96 bits: same bug as below)
+__device__ __forceinline__ TokA ld_tok(const TokA* p)
+{
+  const unsigned long long a = reinterpret_cast<const volatile unsigned long long*>(p)[0], b = reinterpret_cast<const volatile unsigned long long*>(p)[1];
+  TokA t; t.ac = __uint_as_float((unsigned) (a & 0xFFFFFFFFull)); t.lm = __uint_as_float((unsigned) (a >> 32)); t.bp = (uint32_t) (b & 0xFFFFFFFFull); t.xs = (uint32_t) (b >> 32);
+  return t;
+}
+// a winner's {ac, lm, rec} out of a side record: an 8-byte and a 4-byte load on purpose -- as three adjacent fields the compiler merges them into one
+// 96-bit load, and a 96-bit value that gets spilled trips a register-alignment bug of this compiler on gfx950 ("requires even aligned vector registers")
+__device__ __forceinline__ void side_winner(const Side* p, float& ac, float& lm, int& rec)
+{
+  const unsigned long long a = *reinterpret_cast<const volatile unsigned long long*>(&p->ac); rec = *reinterpret_cast<const volatile int*>(&p->rec);
+  ac = __uint_as_float((unsigned) (a & 0xFFFFFFFFull)); lm = __uint_as_float((unsigned) (a >> 32));
 }
 // wave-uniform values computed from LDS land in vector registers; these move them to scalar ones
 __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
@@ -149,8 +195,8 @@ __global__ __launch_bounds__(kThreads) void k_viterbi(GraphDev G, DecDev Dd, con
   __shared__ unsigned short s_gbase[kFastC / 64 + 4]; // register path: expanding tokens that start before each group of 64 slots
   __shared__ int s_cnt[(kFastK + 32) * kWaves];
   __shared__ int s_err;             // register path: first arrivals per (k, wave) group, then their exclusive prefix
-  __shared__ long long s_prof[16]; __shared__ long long s_tlast;
-  if (threadIdx.x < 16) s_prof[threadIdx.x] = 0;
+  __shared__ long long s_prof[32]; __shared__ long long s_tlast;
+  if (threadIdx.x < 32) s_prof[threadIdx.x] = 0;
 #define TICK(ix) do { if (Dd.prof && tid == 0) { const long long tn = (long long) wall_clock64(); s_prof[ix] += tn - s_tlast; s_tlast = tn; } } while (0)
   const int nthr = blockDim.x, nw = nthr >> 6;      // 256 or 512 threads
   __shared__ int s_u;
@@ -215,6 +261,7 @@ __global__ __launch_bounds__(kThreads) void k_viterbi(GraphDev G, DecDev Dd, con
       if (mode == 0 && useLdsRow) { for (int i = tid; i < nDist; i += nthr) srow[i] = sc[(size_t) fr * nDist + i]; }
       const float* rowG = sc + (size_t) fr * nDist;                            // the frame's score row in memory
       int numNew = 0, numStat = -1;                                           // tokens written to the new list / tokens the reference's list would hold
+      if (fr > 0) TICK(23);                                                   // end of the frame before -> here
       if (Dd.prof && tid == 0) s_tlast = (long long) wall_clock64();
       bool fast = fastOK && mode == 0 && n <= fastCapN && !Dd.latOn && Dd.topN <= 0;          // lattice bookkeeping needs every placement in memory: the memory path has them
 
@@ -241,7 +288,9 @@ __global__ __launch_bounds__(kThreads) void k_viterbi(GraphDev G, DecDev Dd, con
               for (int it = g; it < g + 8; it++) { pcn[it] = 0; psc[it] = 0.0f; }
             }
           }
+          TICK(16);
           for (int i = tid; i < kFastC / 32; i += nthr) s_bm[i] = 0u;
+          TICK(17);
 #pragma unroll
           for (int it = 0; it < kP1; it++) {
             const int base = b0 + it * 64; pk[it] = 0u;
@@ -254,17 +303,24 @@ __global__ __launch_bounds__(kThreads) void k_viterbi(GraphDev G, DecDev Dd, con
               const int incl = wave_incl_scan(cnt, lane);
               const unsigned long long bal = __ballot(cnt > 0);
               if (cnt > 0) pk[it] = 0x80000000u | (unsigned) ((runC + incl - cnt) & 0x7FFF) | ((unsigned) ((runE + __popcll(bal & ((1ull << lane) - 1ull))) & 0xFFFF) << 15);
-              runC += __shfl(incl, 63, 64); runE += __popcll(bal);
+              runC += __builtin_amdgcn_readlane(incl, 63); runE += __popcll(bal);
             }
           }
+          TICK(18);
           if (lane == 0) { s_waveTot[wave] = runC; s_waveTotE[wave] = runE; }
           if (tid == 0) { s_sideN = 0; s_gbase[0] = 0; s_err = 0; }
         }
         __syncthreads();
         TICK(0);
-        int C = 0, E = 0, cbase = 0, ebase = 0;
-        for (int w = 0; w < nw; w++) { const int a = s_waveTot[w], b = s_waveTotE[w]; if (w < wave) { cbase += a; ebase += b; } C += a; E += b; }
-        C = uni(C); E = uni(E); cbase = uni(cbase); ebase = uni(ebase);
+        int C, E, cbase, ebase;
+        {                                                                      // lane w reads wave w's totals: two scans instead of a serial walk over 32 LDS words
+          const int a = (lane < nw) ? s_waveTot[lane] : 0, b = (lane < nw) ? s_waveTotE[lane] : 0;
+          const int sa = wave_incl_scan(a, lane), sb = wave_incl_scan(b, lane);
+          C = __builtin_amdgcn_readlane(sa, 63); E = __builtin_amdgcn_readlane(sb, 63);
+          const int wu = uni(wave);
+          cbase = __builtin_amdgcn_readlane(sa - a, wu); ebase = __builtin_amdgcn_readlane(sb - b, wu);
+        }
+        TICK(19);
         if (C > fastCapC || E > eCap || C > 2 * tableC) { fast = false; __syncthreads(); }     // uniform: the memory path redoes the frame
         else {
           // ---- P2: compact list of the expanding tokens (their slot offsets in LDS, the tokens themselves in memory); a bitmap
@@ -420,17 +476,15 @@ __global__ __launch_bounds__(kThreads) void k_viterbi(GraphDev G, DecDev Dd, con
             expand8(kb, oac, olm, orec, oek); park_store(kb, oac, olm, orec, oek);
           }
           TICK(2);
-          locMin = wave_min_d(locMin);
-#pragma unroll
-          for (int d = 32; d >= 1; d >>= 1) locMag = fmaxf(locMag, __shfl_xor(locMag, d, 64));
+          locMin = wave_min_d_uni(locMin); locMag = wave_max_f_uni(locMag);
           if (lq == 0) { s_waveMin[wq] = locMin; s_waveMag[wq] = locMag; }
           TICK(3);
           __syncthreads();
           TICK(4);
           topScore = HUGE_VAL;
-          float frameMag = 0.0f;
-          for (int w = 0; w < nw; w++) { const double v = s_waveMin[w]; if (v < topScore) topScore = v; frameMag = fmaxf(frameMag, s_waveMag[w]); }
-          topScore = uni(topScore);
+          float frameMag;
+          { const double v = (lq < nw) ? s_waveMin[lq] : HUGE_VAL; const float g = (lq < nw) ? s_waveMag[lq] : 0.0f;
+            topScore = wave_min_d_uni(v); frameMag = wave_max_f_uni(g); }
           // A token whose score is above (this frame's best emitting total + beam) fails the beam test of the next frame
           // (decoder.h:586-588) and is never looked at again: it is counted (activeHypos, maxActive) but neither written to the list
           // nor to the back-pointer arena.  The order of the tokens that stay is unchanged, so the next frame's arrival slots are too.
@@ -506,8 +560,7 @@ __global__ __launch_bounds__(kThreads) void k_viterbi(GraphDev G, DecDev Dd, con
                 } else if (defer) *defer = head;
                 else wIdx = fold_multi(k * nthr + tq, head, ac, lm);
                 if (wIdx >= 0) {
-                  if (wIdx < sideLds) { ac = sideL[wIdx].ac; lm = sideL[wIdx].lm; rec = sideL[wIdx].rec; }
-                  else { ac = side[wIdx].ac; lm = side[wIdx].lm; rec = side[wIdx].rec; }
+                  side_winner(wIdx < sideLds ? &sideL[wIdx] : &side[wIdx], ac, lm, rec);
                   ekk = 0x80000000u | (unsigned) wIdx;
                 }
               }
@@ -528,7 +581,7 @@ __global__ __launch_bounds__(kThreads) void k_viterbi(GraphDev G, DecDev Dd, con
             if (pass > 0) {
               __syncthreads();                                                 // every chain of the pass before has been folded
               { uint4* h4 = reinterpret_cast<uint4*>(hkey); const int q4 = hashN >> 2;
-                for (int i = tq; i < 2 * q4; i += nthr) h4[i] = (i < q4) ? make_uint4(0u, 0u, 0u, 0u) : make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu); }
+                for (int i = tq; i < 2 * q4; i += nthr) { unsigned wv = (i < q4) ? 0u : 0xFFFFFFFFu; asm volatile("" : "+v"(wv)); h4[i] = make_uint4(wv, wv, wv, wv); }   /* (opaque: a hoisted constant vector lived through the whole frame loop, partly in scratch) */ }
               __syncthreads();
 #pragma unroll
               for (int g8 = 0; g8 < kFastK; g8 += kB) if (g8 < K) insert8(g8, &qrec[g8], &ek[g8]);
@@ -538,9 +591,44 @@ __global__ __launch_bounds__(kThreads) void k_viterbi(GraphDev G, DecDev Dd, con
               }
               __syncthreads();
             }
+            {
+              // the status of every register slot first (one table read each, all in flight), then the few later arrivals that matter hang
+              // themselves on their buckets side by side: a lane works through its own, whatever their slot number, and only they fetch their
+              // unrounded total and the parent's back pointer from memory (fetching them for every slot cost a memory round trip per batch)
+              unsigned later = 0u;
 #pragma unroll
-            for (int g8 = 0; g8 < kFastK; g8 += kB) if (g8 < K) later8(g8, pass, &qac[g8], &qlm[g8], &qrec[g8], &ek[g8]);
+              for (int k = 0; k < kFastK; k++) {
+                const bool cand = k < K && k * nthr + tq < C && (ek[k] & (1u << 28)) && (int) ((ek[k] >> 27) & 1u) == pass && !((firstMask >> k) & 1ull);
+                if (cand) {
+                  const unsigned f1 = hfirst[(ek[k] >> 13) & 0x3FFFu];
+                  if (f1 == (unsigned) (k * nthr + tq)) firstMask |= 1ull << k;
+                  else if (!((double) __fadd_rn(qac[k], qlm[k]) > doomT)) later |= 1u << k;
+                }
+              }
+              asm volatile("" : "+v"(later));
+              __builtin_amdgcn_sched_barrier(0);
+              while (__any(later != 0u)) {
+                if (later) {
+                  const int k = __ffs((int) later) - 1; later &= later - 1u;
+                  unsigned ekk = ek[0];
+#pragma unroll
+                  for (int j = 1; j < kFastK; j++) ekk = (k == j) ? ek[j] : ekk;
+                  const int c = k * nthr + tq;
+                  const double tt = ttlS[c]; const uint32_t pb = ctk[ekk & 0x1FFFu].bp;
+                  const unsigned h = (ekk >> 13) & 0x3FFFu;
+                  const int sx = atomicAdd(&s_sideN, 1);
+                  const unsigned nx = atomicExch(&hkey[h], 0x80000000u | (unsigned) sx);
+                  float ac = qac[0], lm = qlm[0]; int rec = qrec[0];
+#pragma unroll
+                  for (int j = 1; j < kFastK; j++) { const bool is = (k == j); ac = is ? qac[j] : ac; lm = is ? qlm[j] : lm; rec = is ? qrec[j] : rec; }
+                  Side* dstS = (sx < sideLds) ? nullptr : &side[sx];
+                  if (!dstS) { Side& q = sideL[sx]; q.ttl = tt; q.ac = ac; q.lm = lm; q.rec = rec; q.prevBp = pb; q.c = c; q.next = nx; }
+                  else { dstS->ttl = tt; dstS->ac = ac; dstS->lm = lm; dstS->rec = rec; dstS->prevBp = pb; dstS->c = c; dstS->next = nx; }
+                }
+              }
+            }
             for (int kb = kFastK; kb < K; kb += kB) { float oac[kB], olm[kB]; int orec[kB]; unsigned oek[kB]; park_load(kb, oac, olm, orec, oek); later8(kb, pass, oac, olm, orec, oek); }
+            if (pass == 0) TICK(20);
             __syncthreads();
             if (pass == 0) TICK(5);
             {
@@ -556,8 +644,7 @@ __global__ __launch_bounds__(kThreads) void k_viterbi(GraphDev G, DecDev Dd, con
                   const int wIdx = fold_multi(k * nthr + tq, head, ac, lm);
                   if (wIdx >= 0) {
                     float wac, wlm; int wrec;
-                    if (wIdx < sideLds) { wac = sideL[wIdx].ac; wlm = sideL[wIdx].lm; wrec = sideL[wIdx].rec; }
-                    else { wac = side[wIdx].ac; wlm = side[wIdx].lm; wrec = side[wIdx].rec; }
+                    side_winner(wIdx < sideLds ? &sideL[wIdx] : &side[wIdx], wac, wlm, wrec);
 #pragma unroll
                     for (int j = 0; j < kFastK; j++) if (k == j) { qac[j] = wac; qlm[j] = wlm; qrec[j] = wrec; ek[j] = 0x80000000u | (unsigned) wIdx; }
                   }
@@ -611,7 +698,7 @@ __global__ __launch_bounds__(kThreads) void k_viterbi(GraphDev G, DecDev Dd, con
           __syncthreads();
           TICK(6);
           numNew = uni(s_waveTot[0]);
-          { int a = 0; for (int w = 0; w < nw; w++) a += s_waveTotE[w]; numStat = uni(a); }
+          { const int a = (lq < nw) ? s_waveTotE[lq] : 0; numStat = __builtin_amdgcn_readlane(wave_incl_scan(a, lq), 63); }
           if (numNew > Dd.maxTok || arenaOff + numNew > Dd.arenaCap) { status = DSR_E_ALLOCATION; break; }
           // ---- P6: the new list in reverse first-arrival order + back pointers; the state table is wiped for the next frame
           auto write4 = [&](auto NB, const int g4, const float* ac4, const float* lm4, const int* rec4, const unsigned* ek4) __attribute__((always_inline)) {
@@ -648,10 +735,12 @@ __global__ __launch_bounds__(kThreads) void k_viterbi(GraphDev G, DecDev Dd, con
             float oac[kB], olm[kB]; int orec[kB]; unsigned oek[kB]; park_load(kb, oac, olm, orec, oek);
             write4(std::integral_constant<int, kB>{}, kb, oac, olm, orec, oek);
           }
+          TICK(21);
           {
             uint4* h4 = reinterpret_cast<uint4*>(hkey); const int q4 = hashN >> 2;
-            for (int i = tid; i < 2 * q4; i += nthr) h4[i] = (i < q4) ? make_uint4(0u, 0u, 0u, 0u) : make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
+            for (int i = tid; i < 2 * q4; i += nthr) { unsigned wv = (i < q4) ? 0u : 0xFFFFFFFFu; asm volatile("" : "+v"(wv)); h4[i] = make_uint4(wv, wv, wv, wv); }   /* (opaque: a hoisted constant vector lived through the whole frame loop, partly in scratch) */
           }
+          TICK(22);
         }
       }
       if (!fast) {
@@ -881,7 +970,7 @@ __global__ __launch_bounds__(kThreads) void k_viterbi(GraphDev G, DecDev Dd, con
           long* cnt = Dd.dumpCount; const long o = cnt[0];
           if (o + numNew <= Dd.dumpCap) {
             for (int i = tid; i < numNew; i += nthr) {
-              const TokA t = nxtA[i]; Dd.dumpNode[o + i] = nxtB[i].node; Dd.dumpAc[o + i] = t.ac; Dd.dumpLm[o + i] = t.lm;
+              const TokA t = ld_tok(&nxtA[i]); Dd.dumpNode[o + i] = nxtB[i].node; Dd.dumpAc[o + i] = t.ac; Dd.dumpLm[o + i] = t.lm;
               Dd.dumpArc[o + i] = G.xarc[arena[t.bp].rec];
             }
           }
@@ -906,7 +995,7 @@ __global__ __launch_bounds__(kThreads) void k_viterbi(GraphDev G, DecDev Dd, con
         if (lane == 0) s_waveKey[wave] = key;
         if (Dd.latOn) {                                                        // _next after _expandToEnd (or _current when no token is final), list order
           const TokB* lstB = numNew > 0 ? nxtB : curB; int4* lf = Dd.latFinal + (size_t) u * Dd.maxTok;
-          for (int i = tid; i < cntL; i += nthr) { const TokA t = lst[i]; lf[i] = make_int4(lstB[i].node, (int) t.bp, __float_as_int(t.ac), __float_as_int(t.lm)); }
+          for (int i = tid; i < cntL; i += nthr) { const TokA t = ld_tok(&lst[i]); lf[i] = make_int4(lstB[i].node, (int) t.bp, __float_as_int(t.ac), __float_as_int(t.lm)); }
           if (tid == 0) { int* li = Dd.latInfo + 4 * (size_t) u; li[0] = cntL; li[1] = numNew > 0 ? 1 : 0; li[2] = (int) (arenaOff + (numNew > 0 ? numNew : 0)); li[3] = T; }
         }
         __syncthreads();
@@ -914,13 +1003,15 @@ __global__ __launch_bounds__(kThreads) void k_viterbi(GraphDev G, DecDev Dd, con
         // leaves the hop records in scratch memory; everything else -- arcs per hop, their places in the list, the word sequence --
         // is done by the whole workgroup with two prefix sums.
         int* hopRec = reinterpret_cast<int*>(cB); const int hopCap = 2 * Dd.maxCand; int* hopOff = hopRec + hopCap;
-        dsr_decode_result r; memset(&r, 0, sizeof(r));
+        // (the result record is written by thread 0 alone and lives in memory between its two steps: as a register struct of every thread it was
+        // a block of zeros carried -- and spilled -- through the whole kernel)
         if (tid == 0) {
+          clear_result(&res[u]); dsr_decode_result& r = res[u];
           unsigned long long k = ~0ull; for (int w = 0; w < nw; w++) if (s_waveKey[w] < k) k = s_waveKey[w];
           r.frames = T - 1; r.reachedFinal = numNew > 0 ? 1 : 0; r.finalStatesN = numNew; /* every token of _next after _expandToEnd sits in a final state */ r.activeHypos = activeHypos; r.placements = placements; r.registerFrames = regFrames; r.maxActiveSeen = maxActive; r.status = DSR_OK;
           int nH = 0;
           if (k != ~0ull) {
-            const TokA bt = lst[(unsigned) (k & 0xFFFFFFFFu)];
+            const TokA bt = ld_tok(&lst[(unsigned) (k & 0xFFFFFFFFu)]);
             r.ac = bt.ac; r.lm = bt.lm; r.score = __dadd_rn((double) bt.ac, (double) bt.lm);
             for (uint32_t bq = bt.bp; bq != kNone && nH < hopCap; ) { const uint2 e = *reinterpret_cast<const uint2*>(&arena[bq]); hopRec[nH++] = (int) e.y; bq = e.x; }
           } else r.status = DSR_E_CONSISTENCY;
@@ -972,8 +1063,10 @@ __global__ __launch_bounds__(kThreads) void k_viterbi(GraphDev G, DecDev Dd, con
           }
         }
         if (tid == 0) {
-          if (r.status == DSR_OK) { r.nArcs = nA; r.nWords = s_tb[1]; if (nH >= hopCap) r.status = DSR_E_ALLOCATION; else if (nA > maxPath && arcsOut) r.status = DSR_E_DIMENSION; }
-          res[u] = r;
+          if (res[u].status == DSR_OK) {
+            res[u].nArcs = nA; res[u].nWords = s_tb[1];
+            if (nH >= hopCap) res[u].status = DSR_E_ALLOCATION; else if (nA > maxPath && arcsOut) res[u].status = DSR_E_DIMENSION;
+          }
         }
         __syncthreads();
         TICK(9);
@@ -983,11 +1076,11 @@ __global__ __launch_bounds__(kThreads) void k_viterbi(GraphDev G, DecDev Dd, con
     if (Dd.prof && tid == 0) s_prof[15] = (long long) wall_clock64();
     if (status != DSR_OK) {
       // abort: the tagged state table needs no cleaning
-      if (tid == 0) { dsr_decode_result r; memset(&r, 0, sizeof(r)); r.status = status; r.frames = T - 1; res[u] = r; }
+      if (tid == 0) { clear_result(&res[u]); res[u].status = status; res[u].frames = T - 1; }
     }
   }
   if (tid == 0) Dd.tags[slot] = tag;
-  if (Dd.prof && tid < 16) Dd.prof[slot * 16 + tid] = s_prof[tid];
+  if (Dd.prof && tid < 32) Dd.prof[slot * 32 + tid] = s_prof[tid];
 #undef TICK
 }
 
@@ -1270,7 +1363,7 @@ dsr_status dsr_decoder_decode_launch(dsr_decoder* d, const float* score, const i
     D.tokA = d->d_tokA.p; D.tokB = d->d_tokB.p; D.ctok = d->d_ctok.p; D.side = d->d_side.p; D.fastOK = d->fastOK; D.tokOff = d->d_tokOff.p; D.owner = d->d_owner.p; D.rank = d->d_rank.p; D.cA = d->d_cA.p; D.cB = d->d_cB.p;
     D.first = d->d_first.p; D.tags = d->d_tags.p; D.tokCnt = d->d_tokCnt.p; D.chead = d->d_chead.p; D.arena = d->d_arena.p; D.queue = d->d_queue.p;
     D.prof = nullptr;
-    if (getenv("DSR_VITERBI_PROF")) { d->d_prof.reserve((size_t) slots * 16); D.prof = d->d_prof.p; }
+    if (getenv("DSR_VITERBI_PROF")) { d->d_prof.reserve((size_t) slots * 32); D.prof = d->d_prof.p; }
     D.dumpOn = d->dumpOn; D.dumpCap = d->dumpCap; D.dumpFrameOff = d->d_dumpFrameOff.p; D.dumpNode = d->d_dumpNode.p; D.dumpAc = d->d_dumpAc.p;
     D.dumpLm = d->d_dumpLm.p; D.dumpArc = d->d_dumpArc.p; D.dumpCount = d->d_dumpCount.p;
     D.topN = d->cfg.topN > 0 ? d->cfg.topN : 0; D.tokA3 = nullptr; D.tokB3 = nullptr;
@@ -1327,10 +1420,10 @@ dsr_status dsr_decoder_decode_collect(dsr_decoder* d, dsr_decode_result* res, in
     if (arcs_out && nPath) memcpy(arcs_out, d->h_arcs.p, sizeof(int) * nPath);
     if (words_out && nPath) memcpy(words_out, d->h_words.p, sizeof(unsigned) * nPath);
     if (prof) {
-      std::vector<long long> hp((size_t) slots * 16); DSR_HIP(hipMemcpy(hp.data(), prof, hp.size() * sizeof(long long), hipMemcpyDeviceToHost));
-      double acc[16] = {0}; for (int s2 = 0; s2 < slots; s2++) for (int i = 0; i < 16; i++) acc[i] += (double) hp[(size_t) s2 * 16 + i];
+      std::vector<long long> hp((size_t) slots * 32); DSR_HIP(hipMemcpy(hp.data(), prof, hp.size() * sizeof(long long), hipMemcpyDeviceToHost));
+      double acc[32] = {0}; for (int s2 = 0; s2 < slots; s2++) for (int i = 0; i < 32; i++) acc[i] += (double) hp[(size_t) s2 * 32 + i];
       fprintf(stderr, "[dsr viterbi prof] mean us per slot:");
-      for (int i = 0; i < 15; i++) fprintf(stderr, " p%d=%.0f", i, acc[i] / slots / 100.0);
+      for (int i = 0; i < 24; i++) if (i != 15) fprintf(stderr, " p%d=%.0f", i, acc[i] / slots / 100.0);
       fprintf(stderr, "\n");
     }
     if (d->dumpOn) {
