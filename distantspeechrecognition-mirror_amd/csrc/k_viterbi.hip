@@ -143,6 +143,11 @@ __device__ __forceinline__ void clear_result(dsr_decode_result* r)
 #pragma unroll 1
   for (int i = 0; i < (int) (sizeof(dsr_decode_result) / 4); i++) p[i] = z;
 }
+// LDS-typed views: "cond ? lds[i] : mem[i]" is compiled as a select of two generic pointers and ONE flat load -- a flat load pays the memory path's
+// latency even when it hits LDS.  Reads through these types are ds_read instructions; the two cases are kept in separate branches (fence below).
+typedef __attribute__((address_space(3))) float lds_float_t;
+typedef __attribute__((address_space(3))) Side lds_side_t;
+#define DSR_NO_MERGE() asm volatile("" ::: "memory")
 // a whole token as one 16-byte load (three of its four fields used -> the compiler narrows the load to 96 bits: same bug as below)
 __device__ __forceinline__ TokA ld_tok(const TokA* p)
 {
@@ -152,10 +157,32 @@ __device__ __forceinline__ TokA ld_tok(const TokA* p)
 }
 // a winner's {ac, lm, rec} out of a side record: an 8-byte and a 4-byte load on purpose -- as three adjacent fields the compiler merges them into one
 // 96-bit load, and a 96-bit value that gets spilled trips a register-alignment bug of this compiler on gfx950 ("requires even aligned vector registers")
-__device__ __forceinline__ void side_winner(const Side* p, float& ac, float& lm, int& rec)
+__device__ __forceinline__ void side_winner(const Side* sideL, const Side* side, int sideLds, int idx, float& ac, float& lm, int& rec)
 {
-  const unsigned long long a = *reinterpret_cast<const volatile unsigned long long*>(&p->ac); rec = *reinterpret_cast<const volatile int*>(&p->rec);
-  ac = __uint_as_float((unsigned) (a & 0xFFFFFFFFull)); lm = __uint_as_float((unsigned) (a >> 32));
+  if (idx < sideLds) {
+    const lds_side_t* p = (const lds_side_t*) sideL + idx;
+    const unsigned long long a = *reinterpret_cast<const volatile __attribute__((address_space(3))) unsigned long long*>(&p->ac);
+    rec = *reinterpret_cast<const volatile __attribute__((address_space(3))) int*>(&p->rec);
+    ac = __uint_as_float((unsigned) (a & 0xFFFFFFFFull)); lm = __uint_as_float((unsigned) (a >> 32));
+    DSR_NO_MERGE();
+  } else {
+    const Side* p = side + idx;
+    const unsigned long long a = *reinterpret_cast<const volatile unsigned long long*>(&p->ac); rec = *reinterpret_cast<const volatile int*>(&p->rec);
+    ac = __uint_as_float((unsigned) (a & 0xFFFFFFFFull)); lm = __uint_as_float((unsigned) (a >> 32));
+  }
+}
+// {slot, unrounded total, next} and {next, total} of a side record
+__device__ __forceinline__ void side_link(const Side* sideL, const Side* side, int sideLds, int idx, int& c, double& ttl, unsigned& next)
+{
+  if (idx < sideLds) { const lds_side_t* p = (const lds_side_t*) sideL + idx; c = p->c; ttl = p->ttl; next = p->next; DSR_NO_MERGE(); }
+  else { const Side* p = side + idx; c = p->c; ttl = p->ttl; next = p->next; }
+}
+__device__ __forceinline__ float side_score(const Side* sideL, const Side* side, int sideLds, int idx)
+{
+  float r;
+  if (idx < sideLds) { const lds_side_t* p = (const lds_side_t*) sideL + idx; r = __fadd_rn(p->ac, p->lm); DSR_NO_MERGE(); }
+  else { const Side* p = side + idx; r = __fadd_rn(p->ac, p->lm); }
+  return r;
 }
 // wave-uniform values computed from LDS land in vector registers; these move them to scalar ones
 __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
@@ -173,7 +200,7 @@ __device__ __forceinline__ unsigned f2ord(float f) { const unsigned u = __float_
 __global__ __launch_bounds__(kThreads) void k_viterbi(GraphDev G, DecDev Dd, const float* __restrict__ scores,
                                                       const int* __restrict__ nframesArr, int U, int Tmax, int nDist,
                                                       dsr_decode_result* __restrict__ res, int* __restrict__ arcsOut,
-                                                      unsigned* __restrict__ wordsOut, int maxPath, int useLdsRow, int hashN, int regionB)
+                                                      unsigned* __restrict__ wordsOut, int maxPath, int useLdsRow, int hashN, int regionB, int cntCap)
 {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   float* srow = reinterpret_cast<float*>(smem);                       // [nDist] when useLdsRow
@@ -184,6 +211,8 @@ __global__ __launch_bounds__(kThreads) void k_viterbi(GraphDev G, DecDev Dd, con
   unsigned* hfirst = hkey + hashN;
   unsigned short* eoff = reinterpret_cast<unsigned short*>(hfirst + hashN);     // [kFastC + 2] slot offset of every expanding token (register path)
   Side* sideL = reinterpret_cast<Side*>(hfirst + hashN);                        // [regionB / 32] same region, used after the expansion
+  // [cntCap] expansion counts of the list P6 wrote, by list position: the next frame's P1 scans them without waiting for the tokens to come back from memory
+  unsigned short* cntL = reinterpret_cast<unsigned short*>(reinterpret_cast<unsigned char*>(hfirst + hashN) + regionB);
   __shared__ int s_waveTot[kWaves];
   __shared__ int s_waveTotE[kWaves];
   __shared__ double s_waveMin[kWaves];
@@ -248,6 +277,10 @@ __global__ __launch_bounds__(kThreads) void k_viterbi(GraphDev G, DecDev Dd, con
     }
     __syncthreads();
 
+    bool cntOK = false;                                                        // cntL holds the counts of the current list, and every token of it passes the beam
+    const bool preRow = useLdsRow && nDist <= 2 * nthr;
+    float rowNext[2] = {0.0f, 0.0f};
+    if (preRow && T > 0) { if (tid < nDist) rowNext[0] = sc[tid]; if (tid + nthr < nDist) rowNext[1] = sc[tid + nthr]; }
     TICK(11);
     // frames 0..T-1 (mode 0), then the end expansion (mode 1)
     for (int fr = 0; fr <= T && status == DSR_OK; fr++) {
@@ -258,7 +291,18 @@ __global__ __launch_bounds__(kThreads) void k_viterbi(GraphDev G, DecDev Dd, con
       const int tid = tidO, lane = tid & 63, wave = tid >> 6;
 #endif
       const int mode = (fr == T) ? 1 : 0;
-      if (mode == 0 && useLdsRow) { for (int i = tid; i < nDist; i += nthr) srow[i] = sc[(size_t) fr * nDist + i]; }
+      if (mode == 0 && useLdsRow) {
+        if (preRow) {
+          // the frame's score row was fetched into registers a frame ago (the load -> LDS store round trip was ~0.9 us on every frame's critical path)
+          if (tid < nDist) srow[tid] = rowNext[0];
+          if (tid + nthr < nDist) srow[tid + nthr] = rowNext[1];
+          if (fr + 1 < T) {
+            const float* nr = sc + (size_t) (fr + 1) * nDist;
+            if (tid < nDist) rowNext[0] = nr[tid];
+            if (tid + nthr < nDist) rowNext[1] = nr[tid + nthr];
+          }
+        } else { for (int i = tid; i < nDist; i += nthr) srow[i] = sc[(size_t) fr * nDist + i]; }
+      }
       const float* rowG = sc + (size_t) fr * nDist;                            // the frame's score row in memory
       int numNew = 0, numStat = -1;                                           // tokens written to the new list / tokens the reference's list would hold
       if (fr > 0) TICK(23);                                                   // end of the frame before -> here
@@ -276,7 +320,12 @@ __global__ __launch_bounds__(kThreads) void k_viterbi(GraphDev G, DecDev Dd, con
           const int b0 = wave * chunkT, b1 = (b0 + chunkT < n) ? b0 + chunkT : n;
 #pragma unroll
           for (int g = 0; g < kP1; g += 8) {
-            if (g * 64 < chunkT) {
+            if (g * 64 < chunkT && cntOK) {
+              // the list was written by the register path with pruning on: every token is within the beam (it was tested against this very threshold
+              // when it was written) and its expansion count waits in LDS
+#pragma unroll
+              for (int it = g; it < g + 8; it++) { int i = b0 + it * 64 + lane; i = (i < n) ? i : n - 1; pcn[it] = (int) cntL[i]; psc[it] = -HUGE_VALF; }
+            } else if (g * 64 < chunkT) {
 #pragma unroll
               for (int it = g; it < g + 8; it++) {
                 int i = b0 + it * 64 + lane; i = (i < n) ? i : n - 1;
@@ -438,7 +487,9 @@ __global__ __launch_bounds__(kThreads) void k_viterbi(GraphDev G, DecDev Dd, con
                 { const double lm1 = __dadd_rn(lm, lsPen); lm = (xmeta & 0x10000u) ? lm1 : lm; }
                 const bool silArc = ((uint32_t) (xdist + 1) == Dd.silenceX);
                 { const double lm2 = __dadd_rn(lm, lsSil); lm = (silArc && (pnull || !pinSil)) ? lm2 : lm; }
-                const double ac = __dadd_rn((double) ac8[i], (double) (useLdsRow ? srow[xdist] : rowG[xdist]));
+                float rowv;                                                    // (two branches, not "useLdsRow ? srow[..] : rowG[..]": that is one FLAT load)
+                if (useLdsRow) { rowv = ((const lds_float_t*) srow)[xdist]; DSR_NO_MERGE(); } else rowv = rowG[xdist];
+                const double ac = __dadd_rn((double) ac8[i], (double) rowv);
                 const double ttl = __dadd_rn(ac, lm);
                 ttlS[c] = ttl; ac8[i] = (float) ac; lm8[i] = (float) lm; rec8[i] |= (silArc ? 0x40000000 : 0);
                 if (ttl < locMin) locMin = ttl;                                // _topScore
@@ -532,13 +583,13 @@ __global__ __launch_bounds__(kThreads) void k_viterbi(GraphDev G, DecDev Dd, con
               for (unsigned p = head; (p & 0x80000000u) && steps <= C; steps++) {
                 const int pi = (int) (p & 0x7FFFFFFFu);
                 int pc; double pt; unsigned pn;
-                if (pi < sideLds) { pc = sideL[pi].c; pt = sideL[pi].ttl; pn = sideL[pi].next; } else { pc = side[pi].c; pt = side[pi].ttl; pn = side[pi].next; }
+                side_link(sideL, side, sideLds, pi, pc, pt, pn);
                 if (pc > wslot && pc < best && pt < fw) { best = pc; bi = pi; }
                 p = pn;
               }
               if (bi < 0) break;
               wslot = best; wIdx = bi;
-              fw = (bi < sideLds) ? (double) __fadd_rn(sideL[bi].ac, sideL[bi].lm) : (double) __fadd_rn(side[bi].ac, side[bi].lm);
+              fw = (double) side_score(sideL, side, sideLds, bi);
             }
             return wIdx;
           };
@@ -554,13 +605,13 @@ __global__ __launch_bounds__(kThreads) void k_viterbi(GraphDev G, DecDev Dd, con
                 int wIdx = -1;
                 const int hi = (int) (head & 0x7FFFFFFFu);
                 unsigned hnext; double pt;
-                if (hi < sideLds) { hnext = sideL[hi].next; pt = sideL[hi].ttl; } else { hnext = side[hi].next; pt = side[hi].ttl; }
+                { int cdummy; side_link(sideL, side, sideLds, hi, cdummy, pt, hnext); }
                 if (!(hnext & 0x80000000u)) {                                  // one later arrival (the usual case): a single comparison
                   if (pt < (double) __fadd_rn(ac, lm)) wIdx = hi;
                 } else if (defer) *defer = head;
                 else wIdx = fold_multi(k * nthr + tq, head, ac, lm);
                 if (wIdx >= 0) {
-                  side_winner(wIdx < sideLds ? &sideL[wIdx] : &side[wIdx], ac, lm, rec);
+                  side_winner(sideL, side, sideLds, wIdx, ac, lm, rec);
                   ekk = 0x80000000u | (unsigned) wIdx;
                 }
               }
@@ -635,6 +686,7 @@ __global__ __launch_bounds__(kThreads) void k_viterbi(GraphDev G, DecDev Dd, con
               unsigned pend = 0u, dh[kFastK];
 #pragma unroll
               for (int k = 0; k < kFastK; k++) { dh[k] = 0u; if (k < K) { fold1(k, pass, qac[k], qlm[k], qrec[k], ek[k], &dh[k]); if (dh[k]) pend |= 1u << k; } }
+              if (pass == 0) TICK(24);
               while (__any(pend != 0u)) {                                     // deferred round(s): one chain per lane at a time
                 if (pend) {
                   const int k = __ffs((int) pend) - 1; pend &= pend - 1u;
@@ -644,13 +696,14 @@ __global__ __launch_bounds__(kThreads) void k_viterbi(GraphDev G, DecDev Dd, con
                   const int wIdx = fold_multi(k * nthr + tq, head, ac, lm);
                   if (wIdx >= 0) {
                     float wac, wlm; int wrec;
-                    side_winner(wIdx < sideLds ? &sideL[wIdx] : &side[wIdx], wac, wlm, wrec);
+                    side_winner(sideL, side, sideLds, wIdx, wac, wlm, wrec);
 #pragma unroll
                     for (int j = 0; j < kFastK; j++) if (k == j) { qac[j] = wac; qlm[j] = wlm; qrec[j] = wrec; ek[j] = 0x80000000u | (unsigned) wIdx; }
                   }
                 }
               }
             }
+            if (pass == 0) TICK(25);
             for (int kb = kFastK; kb < K; kb += kB) {
               float oac[kB], olm[kB]; int orec[kB]; unsigned oek[kB]; park_load(kb, oac, olm, orec, oek);
 #pragma unroll
@@ -725,6 +778,7 @@ __global__ __launch_bounds__(kThreads) void k_viterbi(GraphDev G, DecDev Dd, con
                   TokB nb; nb.node = dx[i].x; nb.cnt = dx[i].w;
                   Bp bp; bp.prev = pv[i]; bp.rec = (uint32_t) (rec4[i] & 0x3FFFFFFF);
                   nxtA[pos] = na; nxtB[pos] = nb; arena[arenaOff + pos] = bp;
+                  if (pos < cntCap) cntL[pos] = (unsigned short) dx[i].w;
                 }
               }
             }
@@ -741,9 +795,11 @@ __global__ __launch_bounds__(kThreads) void k_viterbi(GraphDev G, DecDev Dd, con
             for (int i = tid; i < 2 * q4; i += nthr) { unsigned wv = (i < q4) ? 0u : 0xFFFFFFFFu; asm volatile("" : "+v"(wv)); h4[i] = make_uint4(wv, wv, wv, wv); }   /* (opaque: a hoisted constant vector lived through the whole frame loop, partly in scratch) */
           }
           TICK(22);
+          cntOK = prune && numNew <= cntCap;
         }
       }
       if (!fast) {
+      cntOK = false;
       // ======================= memory path =======================
       int* tokOff = Dd.tokOff + (size_t) slot * (Dd.maxTok + 1);
       int* tokCnt = Dd.tokCnt + (size_t) slot * (Dd.maxTok + 1);
@@ -1089,7 +1145,7 @@ struct DecoderState {
   WfstGraph::Csr csr; WfstGraph::Tables tab;
   DevBuf<int> d_xoff, d_xarc, d_xpathOff, d_eoff, d_path, d_nodeFinal, d_queue; DevBuf<float> d_pathCost;
   DevBuf<XRec> d_xrec; DevBuf<ERec> d_erec; DevBuf<float> d_arcCost, d_nodeCost; DevBuf<uint32_t> d_arcOut, d_arcIn;
-  DevBuf<TokA> d_tokA, d_ctok; DevBuf<TokB> d_tokB; DevBuf<Side> d_side; DevBuf<XRecD> d_xrecD; int fastOK = 0; DevBuf<int> d_tokOff, d_tokCnt, d_owner, d_rank, d_chead; DevBuf<unsigned> d_tags; DevBuf<CandA> d_cA; DevBuf<CandB> d_cB; DevBuf<unsigned> d_first; DevBuf<Bp> d_arena;
+  DevBuf<TokA> d_tokA, d_ctok; DevBuf<TokB> d_tokB; DevBuf<Side> d_side; DevBuf<XRecD> d_xrecD; int fastOK = 0; int maxCnt = 0; DevBuf<int> d_tokOff, d_tokCnt, d_owner, d_rank, d_chead; DevBuf<unsigned> d_tags; DevBuf<CandA> d_cA; DevBuf<CandB> d_cB; DevBuf<unsigned> d_first; DevBuf<Bp> d_arena;
   DevBuf<long long> d_prof; DevBuf<dsr_decode_result> d_res; DevBuf<int> d_arcs; DevBuf<unsigned> d_words;
   long arenaCap = 0; int initial = 0; int threads = kThreads; bool twoPerCu = false;
   // lattice bookkeeping of the last decode (cfg.latticeTokens > 0), per utterance
@@ -1210,7 +1266,7 @@ dsr_status dsr_decoder_set(dsr_decoder* d, const dsr_wfst* g)
         if (o.dstCnt > maxCnt) maxCnt = o.dstCnt;
       }
       d->d_xrecD.upload(xd); d->d_pathCost.upload(pc);
-      d->fastOK = (maxCnt < (1 << 19) && nx < ((size_t) 1 << 30)) ? 1 : 0;
+      d->fastOK = (maxCnt < (1 << 19) && nx < ((size_t) 1 << 30)) ? 1 : 0; d->maxCnt = maxCnt;
       if (getenv("DSR_VITERBI_NOFAST")) d->fastOK = 0;
     }
     { std::vector<ERec> e = d->tab.erec; if (e.empty()) e.push_back(ERec{0, 0, 0, 0}); d->d_erec.upload(e); }
@@ -1392,10 +1448,13 @@ dsr_status dsr_decoder_decode_launch(dsr_decoder* d, const float* score, const i
     const size_t rowB = useLds ? (size_t) ((nDist + 3) & ~3) * sizeof(float) : 16;
     int hashN = hashMax; while (hashN > 0 && rowB + (size_t) hashN * 8 + eoffB > ldsCap) hashN >>= 1;
     if (getenv("DSR_VITERBI_NOHASH")) hashN = 0;
-    const size_t lds = rowB + (size_t) hashN * 8 + eoffB;
+    // + the expansion counts of up to 2048 tokens (u16) when the budget and the graph's largest fan-out allow
+    int cntCap = (!two && hashN > 0 && d->maxCnt < 65536 && rowB + (size_t) hashN * 8 + eoffB + 4096 <= ldsCap) ? 2048 : 0;
+    if (getenv("DSR_VITERBI_NOCNT")) cntCap = 0;
+    const size_t lds = rowB + (size_t) hashN * 8 + eoffB + 2 * (size_t) cntCap;
     DSR_HIP(hipFuncSetAttribute((const void*) k_viterbi, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
     hipLaunchKernelGGL(k_viterbi, dim3(slots), dim3(d->threads), lds, st, G, D, score, nframes, U, Tmax, nDist, d->d_res.p,
-                       (arcs_out || words_out) ? d->d_arcs.p : nullptr, (arcs_out || words_out) ? d->d_words.p : nullptr, maxPath, useLds, hashN, (int) eoffB);
+                       (arcs_out || words_out) ? d->d_arcs.p : nullptr, (arcs_out || words_out) ? d->d_words.p : nullptr, maxPath, useLds, hashN, (int) eoffB, cntCap);
     DSR_HIP(hipGetLastError());
     const size_t nPath = want_paths ? (size_t) U * maxPath : 0;
     d->h_res.reserve(U); d->h_arcs.reserve(nPath ? nPath : 1); d->h_words.reserve(nPath ? nPath : 1);
@@ -1423,7 +1482,7 @@ dsr_status dsr_decoder_decode_collect(dsr_decoder* d, dsr_decode_result* res, in
       std::vector<long long> hp((size_t) slots * 32); DSR_HIP(hipMemcpy(hp.data(), prof, hp.size() * sizeof(long long), hipMemcpyDeviceToHost));
       double acc[32] = {0}; for (int s2 = 0; s2 < slots; s2++) for (int i = 0; i < 32; i++) acc[i] += (double) hp[(size_t) s2 * 32 + i];
       fprintf(stderr, "[dsr viterbi prof] mean us per slot:");
-      for (int i = 0; i < 24; i++) if (i != 15) fprintf(stderr, " p%d=%.0f", i, acc[i] / slots / 100.0);
+      for (int i = 0; i < 28; i++) if (i != 15) fprintf(stderr, " p%d=%.0f", i, acc[i] / slots / 100.0);
       fprintf(stderr, "\n");
     }
     if (d->dumpOn) {
