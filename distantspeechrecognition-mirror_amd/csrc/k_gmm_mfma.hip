@@ -235,7 +235,6 @@ __global__ __launch_bounds__(256) void k_gmm_mfma_reg(const float* __restrict__ 
   if (valInLds) for (int i = tid; i < G; i += 256) valL[i] = val[i];
   __syncthreads();
   unsigned long long* myList = tieList + (size_t) blockIdx.x * tieCap;
-  const float* vsrc = valInLds ? valL : val;
 
   float b[2][S2];
 #pragma unroll
@@ -268,7 +267,10 @@ __global__ __launch_bounds__(256) void k_gmm_mfma_reg(const float* __restrict__ 
         if (e2 < e1 || (e2 == e1 && a2 < a1)) { best = e2; ba = a2; } else { best = e1; ba = a1; }
       }
     }
-    float sc = 0.5f * (best + 2.0f * vsrc[kcb * R + ba]);
+    float vv;                                                    // (two branches: "valInLds ? valL[i] : val[i]" through one pointer is a FLAT load, which pays
+    if (valInLds) { vv = ((const __attribute__((address_space(3))) float*) valL)[kcb * R + ba]; asm volatile("" ::: "memory"); }   // the memory path's latency even in LDS)
+    else vv = val[kcb * R + ba];
+    float sc = 0.5f * (best + 2.0f * vv);
     if (!unitScale) { const float sl = scale[kcb]; if (sl != 1.0f) sc *= sl; }
     sbuf[fr * SCP + (kcb - kFlush0)] = sc; abuf[fr * 32 + (kcb - kFlush0)] = (unsigned char) ba;
   };
