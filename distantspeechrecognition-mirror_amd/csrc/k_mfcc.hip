@@ -31,13 +31,21 @@ struct MfccPlan {
   DevBuf<int> d_vStart, d_vCount, d_vOff; DevBuf<double> d_vCoef, d_vDiv;
   DevBuf<int> d_mStart, d_mCount, d_mOff; DevBuf<float> d_mCoef;
   DevBuf<float> d_dct;         // [ncep][filterN]
+  int melCoefN = 0;            // entries of d_mCoef
   DevBuf<float> d_lda;         // [outDim][(2delta+1)*ncep]
   DevBuf<float> w_cep, w_cmn;  // workspaces [U][Tmax][ncep]
   DevBuf<float> w_pow, w_logmel;
   int vtlnRoundFloat = 0;
 };
 
-template <int N>
+// (a wavefront's LDS instructions execute in issue order: when the buffers belong to one wavefront a compiler fence is all a stage boundary needs)
+template <bool WAVE> __device__ __forceinline__ void stage_sync()
+{
+  if (WAVE) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); }
+  else __syncthreads();
+}
+
+template <int N, bool WAVE = false>
 __device__ __forceinline__ double2* fft_lds_d(double2* x, double2* y, const double2* tw, int twStep, int sign, int lane, int nl)
 {
   int n = N, s = 1; const double sj = (double) sign;
@@ -58,7 +66,7 @@ __device__ __forceinline__ double2* fft_lds_d(double2* x, double2* y, const doub
       y[q + s * (4 * p + 2)] = make_double2(t2.x * w2.x - t2.y * w2.y, t2.x * w2.y + t2.y * w2.x);
       y[q + s * (4 * p + 3)] = make_double2(t3.x * w3.x - t3.y * w3.y, t3.x * w3.y + t3.y * w3.x);
     }
-    __syncthreads();
+    stage_sync<WAVE>();
     double2* t = x; x = y; y = t; n >>= 2; s <<= 2;
   }
   if (n == 2) {
@@ -66,7 +74,7 @@ __device__ __forceinline__ double2* fft_lds_d(double2* x, double2* y, const doub
       const double2 a = x[q], b = x[q + s];
       y[q] = make_double2(a.x + b.x, a.y + b.y); y[q + s] = make_double2(a.x - b.x, a.y - b.y);
     }
-    __syncthreads();
+    stage_sync<WAVE>();
     double2* t = x; x = y; y = t;
   }
   return x;
@@ -185,6 +193,127 @@ __global__ __launch_bounds__(256) void k_mfcc_frames(MfccDev P, const float* __r
       if (live) for (int j = 0; j < P.filterN; j++) temp = __fadd_rn(temp, __fmul_rn(lg[j], P.dct[k * P.filterN + j]));
       cep[((long) u * Tmax + t) * P.ncep + k] = live ? __fadd_rn(0.0f, temp) : 0.0f;
     }
+}
+
+// The same chain with the tables in LDS and wave-private frames: a workgroup stages twiddles, window, mel triangles and the DCT matrix
+// once and each of its four wavefronts then walks FW consecutive frames on its own pair of buffers -- no workgroup barrier after the
+// staging, no table read from memory inside the frame loop (the first kernel spends most of a frame waiting on those: every mel group and
+// every DCT term is a dependent global load).  Same arithmetic, same order: the two kernels return the same bits.  VTLN tables stay in memory.
+template <int FFTN, int FW>
+__global__ __launch_bounds__(256) void k_mfcc_frames_w(MfccDev P, int melCoefN, const float* __restrict__ y, const int* __restrict__ nsampArr,
+                                                       long sampStride, int Tmax, float* __restrict__ cep,
+                                                       float* __restrict__ powOut, float* __restrict__ logmelOut)
+{
+  constexpr int N = FFTN / 2;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  double2* twL = reinterpret_cast<double2*>(smem);                                         // [FFTN]
+  double2* bufs = twL + FFTN;                                                              // [4][2][N]
+  double* hamL = reinterpret_cast<double*>(bufs + 4 * 2 * N);                              // [blockLen]
+  float* mCoefL = reinterpret_cast<float*>(hamL + P.blockLen);                             // [melCoefN]
+  float* dctL = mCoefL + melCoefN;                                                         // [ncep][filterN]
+  int* mIdxL = reinterpret_cast<int*>(dctL + P.ncep * P.filterN);                          // [3][filterN]: start, count, offset
+  for (int i = threadIdx.x; i < FFTN; i += 256) twL[i] = P.tw[i];
+  for (int i = threadIdx.x; i < P.blockLen; i += 256) hamL[i] = P.ham[i];
+  for (int i = threadIdx.x; i < melCoefN; i += 256) mCoefL[i] = P.mCoef[i];
+  for (int i = threadIdx.x; i < P.ncep * P.filterN; i += 256) dctL[i] = P.dct[i];
+  for (int i = threadIdx.x; i < P.filterN; i += 256) { mIdxL[i] = P.mStart[i]; mIdxL[P.filterN + i] = P.mCount[i]; mIdxL[2 * P.filterN + i] = P.mOff[i]; }
+  __syncthreads();
+  double2* bufA = bufs + (size_t) wave * 2 * N;
+  double2* bufB = bufA + N;
+  const int u = blockIdx.y;
+  const int nsamp = nsampArr[u];
+  int Tu;
+  if (P.padZeros) Tu = (nsamp + P.shiftLen - 1) / P.shiftLen;
+  else { long a = (long) nsamp - P.blockLen; Tu = (a > 0) ? (int) ((a + P.shiftLen - 1) / P.shiftLen) : 0; }
+  const float* ys = y + (long) u * sampStride;
+  const int t0 = (blockIdx.x * 4 + wave) * FW;
+  for (int fi = 0; fi < FW; fi++) {
+    const int t = t0 + fi;
+    if (t >= Tmax) break;                                                                  // wave-uniform
+    const bool live = (t < Tu);
+    const long cur = (long) t * P.shiftLen;
+    if (!live) {                                                                           // past the utterance's last frame: zero rows
+      for (int k = lane; k < P.ncep; k += 64) cep[((long) u * Tmax + t) * P.ncep + k] = 0.0f;
+      continue;
+    }
+    double* zr = reinterpret_cast<double*>(bufA);
+#pragma unroll
+    for (int i0 = 0; i0 < FFTN; i0 += 64) {
+      const int i = i0 + lane;
+      double v = 0.0;
+      if (i < P.blockLen) {
+        const long n = cur + i;
+        const float b = (n < nsamp) ? ys[n] : 0.0f;
+        float pre = b;
+        if (P.preOn) {
+          float prior;
+          if (i > 0) { const long n1 = n - 1; prior = (n1 < nsamp) ? ys[n1] : 0.0f; }
+          else if (t == 0) prior = 0.0f;
+          else { const long n1 = (long) (t - 1) * P.shiftLen + P.blockLen - 1; prior = (n1 < nsamp) ? ys[n1] : 0.0f; }
+          pre = (float) __dsub_rn((double) b, __dmul_rn(P.mu, (double) prior));
+        }
+        const float hm = (float) __dmul_rn(hamL[i], (double) pre);
+        v = (double) hm;
+      }
+      zr[i] = v;
+    }
+    stage_sync<true>();
+    double2* Z = fft_lds_d<N, true>(bufA, bufB, twL, 2, -1, lane, 64);
+    double* pw = reinterpret_cast<double*>(Z == bufA ? bufB : bufA);
+    for (int f = lane; f < P.powN; f += 64) {
+      const int ff = (f <= N) ? f : (FFTN - f);
+      const double2 zf = Z[ff & (N - 1)]; double2 zc = Z[(N - ff) & (N - 1)]; zc.y = -zc.y;
+      const double2 E = make_double2(0.5 * (zf.x + zc.x), 0.5 * (zf.y + zc.y));
+      const double2 dd = make_double2(zf.x - zc.x, zf.y - zc.y);
+      const double2 O = make_double2(0.5 * dd.y, -0.5 * dd.x);
+      double2 w = twL[ff]; w.y = -w.y;
+      const double re = E.x + (w.x * O.x - w.y * O.y), im = E.y + (w.x * O.y + w.y * O.x);
+      pw[f] = __dadd_rn(__dmul_rn(re, re), __dmul_rn(im, im));
+    }
+    stage_sync<true>();
+    if (powOut) for (int f = lane; f < P.powN; f += 64) powOut[((long) u * Tmax + t) * P.powN + f] = (float) pw[f];
+    double* vt = pw;                                                                       // no VTLN: the mel bank reads the power spectrum where it lies
+    if (P.vtlnOn) {
+      vt = reinterpret_cast<double*>(Z);
+      for (int k = lane; k < P.powN; k += 64) {
+        const int s0 = P.vStart[k], n = P.vCount[k], o = P.vOff[k];
+        double z = 0.0;
+        for (int i = 0; i < n; i++) {
+          double in = pw[s0 + i]; if (P.vtlnRoundFloat) in = (double) (float) in;
+          z = __dadd_rn(z, __dmul_rn(P.vCoef[o + i], in));
+        }
+        const double dv = P.vDiv[k]; if (dv != 0.0) z = z / dv;
+        vt[k] = z;
+      }
+      stage_sync<true>();
+    }
+    float* lg = reinterpret_cast<float*>(vt == pw ? reinterpret_cast<double*>(Z) : pw);    // the buffer the mel bank does not read
+    for (int j = lane; j < P.filterN; j += 64) {
+      const int s0 = mIdxL[j], n = mIdxL[P.filterN + j], o = mIdxL[2 * P.filterN + j];
+      double sum = 0.0; int i = 0;
+      for (; i + 4 <= n; i += 4) {
+        double g4 = __dmul_rn(vt[s0 + i], (double) mCoefL[o + i]);
+        g4 = __dadd_rn(g4, __dmul_rn(vt[s0 + i + 1], (double) mCoefL[o + i + 1]));
+        g4 = __dadd_rn(g4, __dmul_rn(vt[s0 + i + 2], (double) mCoefL[o + i + 2]));
+        g4 = __dadd_rn(g4, __dmul_rn(vt[s0 + i + 3], (double) mCoefL[o + i + 3]));
+        sum = __dadd_rn(sum, g4);
+      }
+      for (; i < n; i++) sum = __dadd_rn(sum, __dmul_rn(vt[s0 + i], (double) mCoefL[o + i]));
+      double val = sum;
+      if (P.sphinx) { if (val < 1.0E-05) val = 1.0E-05; }
+      else { val = __dadd_rn(val, P.logA); if (val <= 0.0) val = 1.0; }
+      lg[j] = (float) __dmul_rn(P.logM, log10(val));
+    }
+    stage_sync<true>();
+    if (logmelOut) for (int j = lane; j < P.filterN; j += 64) logmelOut[((long) u * Tmax + t) * P.filterN + j] = lg[j];
+    for (int k = lane; k < P.ncep; k += 64) {
+      float temp = 0.0f;
+      for (int j = 0; j < P.filterN; j++) temp = __fadd_rn(temp, __fmul_rn(lg[j], dctL[k * P.filterN + j]));
+      cep[((long) u * Tmax + t) * P.ncep + k] = __fadd_rn(0.0f, temp);
+    }
+    stage_sync<true>();                                                                    // the next frame overwrites the buffers
+  }
 }
 
 // mode 1: batch mean/variance (two sequential passes in fp32, as _calcMeanVariance), mode 2: run-on.
@@ -462,7 +591,7 @@ dsr_status dsr_mfcc_create(const dsr_mfcc_cfg* cfg, const float* lda, dsr_mfcc**
     if (c.powN < nReq) throw Error(DSR_E_CONSISTENCY, "Matrix columns differ: %d and %d.", c.powN, nReq);   // feature.cc:2111-2113
     for (size_t i = 0; i < ms.size(); i++) if (ms[i] + mc[i] > c.powN) throw Error(DSR_E_CONSISTENCY, "mel filter %zu reads past the power spectrum", i);
     if (mco.empty()) mco.push_back(0.f);
-    p->d_mStart.upload(ms); p->d_mCount.upload(mc); p->d_mOff.upload(mo); p->d_mCoef.upload(mco);
+    p->d_mStart.upload(ms); p->d_mCount.upload(mc); p->d_mOff.upload(mo); p->d_mCoef.upload(mco); p->melCoefN = (int) mco.size();
     std::vector<float> dct; build_dct(c.ncep, c.filterN, c.dctType, dct);
     p->d_dct.upload(dct);
     if (c.outDim > 0) p->d_lda.upload(lda, (size_t) c.outDim * (2 * c.delta + 1) * c.ncep);
@@ -507,6 +636,18 @@ dsr_status dsr_mfcc_run(dsr_mfcc* p, const float* y, const int32_t* nsamp, int U
     float* powOut = stage == 4 ? feat : nullptr; float* lmOut = stage == 3 ? feat : nullptr;
 #define LAUNCH(FN) { DSR_HIP(hipFuncSetAttribute((const void*) k_mfcc_frames<FN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds)); \
     hipLaunchKernelGGL(k_mfcc_frames<FN>, grid, dim3(64 * FPB), lds, st, P, y, nsamp, (long) sampStride, Tmax, cepOut, powOut, lmOut); }
+    // tables in LDS + wave-private frames when the lot fits beside three more workgroups on a CU; the plain kernel otherwise (and on request)
+    constexpr int FW = 8;
+    const size_t ldsW = (size_t) c.fftLen * sizeof(double2) * (1 + 4) + (size_t) c.blockLen * sizeof(double)
+                        + ((size_t) p->melCoefN + (size_t) c.ncep * c.filterN + 3 * (size_t) c.filterN) * sizeof(float);
+    static const bool plainOnly = getenv("DSR_MFCC_PLAIN") != nullptr;
+    if (!plainOnly && ldsW <= 52 * 1024 && (c.fftLen == 256 || c.fftLen == 512 || c.fftLen == 1024)) {
+      dim3 gridW(cdiv(Tmax, 4 * FW), U);
+#define LAUNCHW(FN) { DSR_HIP(hipFuncSetAttribute((const void*) k_mfcc_frames_w<FN, FW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) ldsW)); \
+    hipLaunchKernelGGL((k_mfcc_frames_w<FN, FW>), gridW, dim3(256), ldsW, st, P, p->melCoefN, y, nsamp, (long) sampStride, Tmax, cepOut, powOut, lmOut); }
+      if (c.fftLen == 256) LAUNCHW(256) else if (c.fftLen == 512) LAUNCHW(512) else LAUNCHW(1024)
+#undef LAUNCHW
+    } else
     switch (c.fftLen) { case 32: LAUNCH(32) break; case 64: LAUNCH(64) break; case 128: LAUNCH(128) break; case 256: LAUNCH(256) break;
       case 512: LAUNCH(512) break; case 1024: LAUNCH(1024) break; case 2048: LAUNCH(2048) break; case 4096: LAUNCH(4096) break;
       default: throw Error(DSR_E_DIMENSION, "unsupported fftLen"); }
