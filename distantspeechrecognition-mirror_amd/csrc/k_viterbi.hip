@@ -1512,7 +1512,6 @@ dsr_status dsr_decoder_decode_batch(dsr_decoder* d, const float* score, const in
 }
 
 // _Decoder::lattice() (decoder.h:805-860) for utterance u of the last decode (cfg.latticeTokens > 0)
-struct dsr_lattice : dsr::LatticeData {};
 // the placement log of utterance u of the last lattice-mode decode, copied to the host
 namespace {
 struct LatHost {
@@ -1599,7 +1598,7 @@ dsr_status dsr_lattice_get(const dsr_lattice* L, int32_t* nodeFinal, int32_t* fr
     if (ac && nE) memcpy(ac, L->ac.data(), 8 * nE); if (lm && nE) memcpy(lm, L->lm.data(), 8 * nE);
   });
 }
-dsr_status dsr_lattice_write(const dsr_lattice* L, const char* fileName, int writeData)
+dsr_status dsr_lattice_write(dsr_lattice* L, const char* fileName, int writeData)
 { return guard([&] { if (!L || !fileName) throw Error(DSR_E_PARAMETER, "null argument"); L->write(fileName, writeData != 0); }); }
 size_t dsr_lattice_pack_size(const dsr_lattice* L) { return L ? 16 + 4 * L->nodeFinal.size() + 40 * L->from.size() : 0; }
 dsr_status dsr_lattice_pack(const dsr_lattice* L, void* buf, size_t bufBytes)

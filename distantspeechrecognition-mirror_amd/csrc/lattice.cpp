@@ -18,7 +18,7 @@ namespace dsr {
 
 namespace {
 
-static constexpr uint32_t kNone = 0xFFFFFFFFu, kEndBit = 0x80000000u, kSelf = 0x7FFFFFFEu;
+static constexpr uint32_t kNone = 0xFFFFFFFFu, kSelf = 0x7FFFFFFEu;
 typedef long long Tok;                                     // placement index << 16 | (hop + 1); hop field 0 = the placed token itself; -1 = null
 
 struct Builder {
@@ -228,37 +228,6 @@ void build_lattice(const LatInput& in, LatticeData& out)
   out = LatticeData();
   if (in.T <= 0) { out.nodeFinal.assign(1, 0); return; }
   Builder b(in, out); b.run();
-}
-
-// Lattice::write(fileName, useSymbols = false, writeData) (lattice.cc:715-757): _topoSort (depth first from the initial node over each node's edge
-// list -- last added first, fsm.cc:541-545 -- finished nodes to the front, :858-887), edges of the non-final nodes, then per final node (index order)
-// its edges and its node line; formats fsm.cc:1171-1178, 553-559 and lattice.h:151-154
-void LatticeData::write(const char* file, bool writeData) const
-{
-  const int n = (int) nodeFinal.size();
-  std::vector<std::vector<int> > adj(n);
-  for (int e = (int) from.size() - 1; e >= 0; e--) adj[from[e]].push_back(e);     // iteration order: last added first
-  std::vector<int> color(n, 0), order; order.reserve(n);
-  struct Fr { int node; size_t k; };
-  std::vector<Fr> st; st.push_back(Fr{0, 0}); color[0] = 1;
-  while (!st.empty()) {
-    Fr& fr = st.back();
-    if (fr.k < adj[fr.node].size()) {
-      const int v = to[adj[fr.node][fr.k++]];
-      if (color[v] == 2) continue;
-      if (color[v] == 1) throw Error(DSR_E_CONSISTENCY, "Node %d is gray; graph is not acyclic.", v);     // lattice.cc:862-864
-      color[v] = 1; st.push_back(Fr{v, 0});
-    } else { color[fr.node] = 2; order.push_back(fr.node); st.pop_back(); }
-  }
-  FILE* fp = fopen(file, "w");
-  if (!fp) throw Error(DSR_E_IO, "Could not open file %s", file);
-  auto wedge = [&](int e) {
-    fprintf(fp, "%10d  %10d  %10d  %10d\n", from[e], to[e], (int) in[e], (int) out[e]);
-    if (writeData) fprintf(fp, "%4d  %4d  %8.4f  %8.4f  %8.4f\n", start[e], end[e], ac[e], lm[e], 0.0);
-  };
-  for (int i = (int) order.size() - 1; i >= 0; i--) { const int nd = order[i]; if (nodeFinal[nd] == 1) continue; for (size_t k = 0; k < adj[nd].size(); k++) wedge(adj[nd][k]); }
-  for (int nd = 0; nd < n; nd++) if (nodeFinal[nd] == 1) { for (size_t k = 0; k < adj[nd].size(); k++) wedge(adj[nd][k]); fprintf(fp, "%10d\n", nd); }
-  fclose(fp);
 }
 
 // flat image: [magic, nNodes, nEdges, finalStatesN] int32, nodeFinal[nNodes] int32, then per edge field arrays

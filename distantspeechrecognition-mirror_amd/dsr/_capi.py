@@ -21,6 +21,7 @@ vp, i32, i64, f32, f64, u32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_d
 ERROR_NAMES = ["OK", "JERROR", "JALLOCATION", "JARITHMETIC", "JCONSISTENCY", "JDIMENSION", "JINDEX", "JINITIALIZATION",
                "JIO", "JITERATOR", "JPYTHON", "JKEY", "JNUMERIC", "JPARAMETER", "JPARSE", "JTYPE"]
 E_ITERATOR, E_IO, E_INDEX, E_DIMENSION = 9, 8, 6, 5
+E_CONSISTENCY, E_KEY, E_PARAMETER, E_PARSE = 4, 11, 13, 14
 
 
 class DsrError(Exception):
@@ -765,6 +766,13 @@ class Decoder:
         return dict(frameOff=off, node=g(nd, np.int32), ac=g(ac, np.float32), lm=g(lm, np.float32), arc=g(arc, np.int32))
 
 
+def _lexh(lex):
+    """handle of a lexicon object (asr.dictionary.LexiconPtr keeps it in _h) or None"""
+    if lex is None:
+        return None
+    return getattr(lex, "_h", None) or getattr(lex, "h", None)
+
+
 class Lattice:
     """asr/lattice Lattice as the decoder builds it: nodes numbered as the reference numbers them (0 = initial), edges in creation order."""
 
@@ -785,6 +793,62 @@ class Lattice:
         if useSymbols:
             raise DsrError(13, "useSymbols: write the numeric form and map the symbols with the lexica")
         check(_lib.dsr_lattice_write(self.h, fileName.encode(), int(writeData)))
+
+    # ---- asr/lattice operations (lattice.i:79-123); symbols cross the boundary as indices, asr/lattice.py joins them with the lexica
+    @staticmethod
+    def read(fileName, noSelfLoops=False, readData=False, inlex=None, outlex=None):
+        """WFST::read(fileName, noSelfLoops, readData) (fsm.h:3787-3873); inlex/outlex: Lexicon objects (or None) for symbolic files"""
+        load(); h = vp()
+        check(_lib.dsr_lattice_read(fileName.encode(), int(noSelfLoops), int(readData), _lexh(inlex), _lexh(outlex), C.byref(h)))
+        return Lattice(h)
+
+    def rescore(self, lmScale=30.0, lmPenalty=0.0, silPenalty=0.0, silenceX=0):
+        sc = C.c_float(0.0)
+        check(_lib.dsr_lattice_rescore(self.h, float(lmScale), float(lmPenalty), float(silPenalty), int(silenceX), C.byref(sc)))
+        return np.float32(sc.value)
+
+    def bestHypo(self, useInputSymbols=False):
+        n = C.c_int(0); check(_lib.dsr_lattice_best_hypo(self.h, int(useInputSymbols), None, 0, C.byref(n)))
+        out = np.zeros(max(n.value, 1), np.uint32)
+        check(_lib.dsr_lattice_best_hypo(self.h, int(useInputSymbols), _ptr(out), out.size, C.byref(n)))
+        return out[:n.value].copy()
+
+    def gammaProbs(self, acScale=1.0, lmScale=12.0, lmPenalty=0.0, silPenalty=0.0, silenceX=0):
+        p = C.c_double(0.0)
+        check(_lib.dsr_lattice_gamma_probs(self.h, float(acScale), float(lmScale), float(lmPenalty), float(silPenalty), int(silenceX), C.byref(p)))
+        return p.value
+
+    def prune(self, threshold=100.0):
+        check(_lib.dsr_lattice_prune(self.h, float(threshold)))
+
+    def pruneEdges(self, edgesN=0):
+        check(_lib.dsr_lattice_prune_edges(self.h, int(edgesN)))
+
+    def purge(self):
+        check(_lib.dsr_lattice_purge(self.h))
+
+    def state(self):
+        """per link (creation order): gamma, still on its node's list; per node (creation order): printed index, still held, forward, backward"""
+        n, e = _lib.dsr_lattice_num_nodes(self.h), _lib.dsr_lattice_num_edges(self.h)
+        d = dict(gamma=np.zeros(e, np.float64), edgeLive=np.zeros(e, np.int32), nodeIndex=np.zeros(n, np.int32), nodeLive=np.zeros(n, np.int32),
+                 fwd=np.zeros(n, np.float64), bwd=np.zeros(n, np.float64))
+        check(_lib.dsr_lattice_get_state(self.h, *[_ptr(d[k]) for k in ("gamma", "edgeLive", "nodeIndex", "nodeLive", "fwd", "bwd")]))
+        return d
+
+    def writeCTM(self, outlex, conv, channel, spk, utt, cfrom, score, fileName="", frameInterval=0.01, endMarker="</s>"):
+        check(_lib.dsr_lattice_write_ctm(self.h, _lexh(outlex), conv.encode(), channel.encode(), spk.encode(), utt.encode(), float(cfrom), float(score),
+                                         fileName.encode(), float(frameInterval), endMarker.encode()))
+
+    def writePhoneCTM(self, inlex, conv, channel, spk, utt, cfrom, score, fileName="", frameInterval=0.01, endMarker="</s>"):
+        check(_lib.dsr_lattice_write_phone_ctm(self.h, _lexh(inlex), conv.encode(), channel.encode(), spk.encode(), utt.encode(), float(cfrom), float(score),
+                                               fileName.encode(), float(frameInterval), endMarker.encode()))
+
+    def writeHypoHTK(self, outlex, conv, channel, spk, utt, cfrom, score, fileName="", flag=0, frameInterval=0.01, endMarker="</s>"):
+        check(_lib.dsr_lattice_write_hypo_htk(self.h, _lexh(outlex), conv.encode(), channel.encode(), spk.encode(), utt.encode(), float(cfrom), float(score),
+                                              fileName.encode(), int(flag), float(frameInterval), endMarker.encode()))
+
+    def writeWordConfs(self, outlex, fileName, uttId, endMarker="</s>"):
+        check(_lib.dsr_lattice_write_word_confs(self.h, _lexh(outlex), fileName.encode(), uttId.encode(), endMarker.encode()))
 
     def pack(self):
         n = _lib.dsr_lattice_pack_size(self.h); b = np.zeros(n, np.uint8)

@@ -107,7 +107,10 @@ class DecoderFlyWeightPtr(object):
         ok = C.c_int(); K.check(K.load().dsr_decoder_trace_back_succeeded(self._dec.h, 0, C.byref(ok))); return bool(ok.value)
 
     def lattice(self):
-        return self._dec.lattice(0, K.load().dsr_decoder_eos_index(self._dec.h))
+        """_Decoder::lattice() (decoder.h:805-860): a LatticePtr over the transducer's input lexicon and the decoder's output lexicon"""
+        from .lattice import LatticePtr
+        lat = self._dec.lattice(0, K.load().dsr_decoder_eos_index(self._dec.h))
+        return LatticePtr(None, self._wfst.inputLexicon(), self._wfst.outputLexicon(), _lat=lat)
 
     def writeGMM(self, conv, channel, spk, utt, cfrom, score, fileName="", frameInterval=0.01):
         """decoder.i:177-178"""

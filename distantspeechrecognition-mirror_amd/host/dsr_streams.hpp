@@ -487,17 +487,67 @@ class WFSTFlyWeight {
 typedef std::shared_ptr<WFSTFlyWeight> WFSTFlyWeightPtr;
 
 typedef std::vector<String> DistribPath;                       // asr/path/distribPath.h:34-60: the distribution names along a path
-class Lattice {                                                // what _Decoder::lattice() returns (asr/lattice/lattice.h:188-330): write() and the raw arrays
+// asr/lattice Lattice(statelex, inlex, outlex) (lattice.i:79-135, lattice.h:188-330): what _Decoder::lattice() returns, or an object to read() into
+class Lattice {
  public:
+  Lattice(LexiconPtr statelex, LexiconPtr inlex, LexiconPtr outlex) : _stateLexicon(statelex), _inputLexicon(inlex), _outputLexicon(outlex), _h(0) {}
+  Lattice(dsr_lattice* h, LexiconPtr inlex, LexiconPtr outlex) : _inputLexicon(inlex), _outputLexicon(outlex), _h(h) {}
   explicit Lattice(dsr_lattice* h) : _h(h) {}
-  ~Lattice() { dsr_lattice_destroy(_h); }
-  void write(const String& fileName = "", bool useSymbols = false, bool writeData = false) { (void) useSymbols; dsr_throw(dsr_lattice_write(_h, fileName.c_str(), writeData)); }
-  unsigned nodesN() const { return (unsigned) dsr_lattice_num_nodes(_h); }
-  unsigned edgesN() const { return (unsigned) dsr_lattice_num_edges(_h); }
+  ~Lattice() { if (_h) dsr_lattice_destroy(_h); }
+  void read(const String& fileName, bool noSelfLoops = false, bool readData = false) {
+    dsr_lattice* n = 0;
+    dsr_throw(dsr_lattice_read(fileName.c_str(), noSelfLoops, readData, _inputLexicon ? _inputLexicon->handle() : 0, _outputLexicon ? _outputLexicon->handle() : 0, &n));
+    if (_h) dsr_lattice_destroy(_h);
+    _h = n;
+  }
+  void write(const String& fileName = "", bool useSymbols = false, bool writeData = false) {
+    if (useSymbols) throw jparameter_error("useSymbols: write the numeric form and map the symbols with the lexica");
+    dsr_throw(dsr_lattice_write(need(), fileName.c_str(), writeData));
+  }
+  float rescore(double lmScale = 30.0, double lmPenalty = 0.0, double silPenalty = 0.0, const String& silSymbol = "SIL-m") {
+    float s = 0.0f; dsr_throw(dsr_lattice_rescore(need(), lmScale, lmPenalty, silPenalty, silX(silSymbol), &s)); return s;
+  }
+  String bestHypo(bool useInputSymbols = false) {
+    int n = 0; dsr_throw(dsr_lattice_best_hypo(need(), useInputSymbols, 0, 0, &n));
+    std::vector<uint32_t> ids((size_t) (n > 0 ? n : 1)); dsr_throw(dsr_lattice_best_hypo(_h, useInputSymbols, ids.data(), (int) ids.size(), &n));
+    LexiconPtr& lex = useInputSymbols ? _inputLexicon : _outputLexicon;
+    if (!lex) throw jkey_error("no lexicon to name the symbols with");
+    String hypo; for (int i = 0; i < n; i++) hypo += lex->symbol(ids[(size_t) i]) + " ";           // "symbol " per link, as lattice.cc:292,298 build it
+    return hypo;
+  }
+  double gammaProbs(double acScale = 1.0, double lmScale = 12.0, double lmPenalty = 0.0, double silPenalty = 0.0, const String& silSymbol = "SIL-m") {
+    double p = 0.0; dsr_throw(dsr_lattice_gamma_probs(need(), acScale, lmScale, lmPenalty, silPenalty, silX(silSymbol), &p)); return p;
+  }
+  void prune(double threshold = 100.0) { dsr_throw(dsr_lattice_prune(need(), threshold)); }
+  void pruneEdges(unsigned edgesN = 0) { dsr_throw(dsr_lattice_prune_edges(need(), edgesN)); }
+  void purge() { dsr_throw(dsr_lattice_purge(need())); }
+  void writeCTM(const String& conv, const String& channel, const String& spk, const String& utt, double cfrom, double score, const String& fileName = "",
+                double frameInterval = 0.01, const String& endMarker = "</s>") {
+    dsr_throw(dsr_lattice_write_ctm(need(), lexh(_outputLexicon), conv.c_str(), channel.c_str(), spk.c_str(), utt.c_str(), cfrom, score, fileName.c_str(), frameInterval, endMarker.c_str()));
+  }
+  void writePhoneCTM(const String& conv, const String& channel, const String& spk, const String& utt, double cfrom, double score, const String& fileName = "",
+                     double frameInterval = 0.01, const String& endMarker = "</s>") {
+    dsr_throw(dsr_lattice_write_phone_ctm(need(), lexh(_inputLexicon), conv.c_str(), channel.c_str(), spk.c_str(), utt.c_str(), cfrom, score, fileName.c_str(), frameInterval, endMarker.c_str()));
+  }
+  void writeHypoHTK(const String& conv, const String& channel, const String& spk, const String& utt, double cfrom, double score, const String& fileName = "",
+                    int flag = 0, double frameInterval = 0.01, const String& endMarker = "</s>") {
+    dsr_throw(dsr_lattice_write_hypo_htk(need(), lexh(_outputLexicon), conv.c_str(), channel.c_str(), spk.c_str(), utt.c_str(), cfrom, score, fileName.c_str(), flag, frameInterval, endMarker.c_str()));
+  }
+  void writeWordConfs(const String& fileName, const String& uttId, const String& endMarker = "</s>") {
+    dsr_throw(dsr_lattice_write_word_confs(need(), lexh(_outputLexicon), fileName.c_str(), uttId.c_str(), endMarker.c_str()));
+  }
+  unsigned nodesN() const { return _h ? (unsigned) dsr_lattice_num_nodes(_h) : 0u; }
+  unsigned edgesN() const { return _h ? (unsigned) dsr_lattice_num_edges(_h) : 0u; }
+  LexiconPtr& stateLexicon() { return _stateLexicon; }
+  LexiconPtr& inputLexicon() { return _inputLexicon; }
+  LexiconPtr& outputLexicon() { return _outputLexicon; }
   dsr_lattice* handle() const { return _h; }
  private:
   Lattice(const Lattice&); Lattice& operator=(const Lattice&);
-  dsr_lattice* _h;
+  dsr_lattice* need() const { if (!_h) throw jconsistency_error("empty lattice: decode or read one first"); return _h; }
+  static dsr_lexicon* lexh(const LexiconPtr& l) { if (!l) throw jkey_error("no lexicon to name the symbols with"); return l->handle(); }
+  unsigned silX(const String& silSymbol) { if (!_inputLexicon) throw jkey_error("no input lexicon to look " + silSymbol + " up in"); return _inputLexicon->index(silSymbol); }
+  LexiconPtr _stateLexicon, _inputLexicon, _outputLexicon; dsr_lattice* _h;
 };
 typedef std::shared_ptr<Lattice> LatticePtr;
 
@@ -533,7 +583,10 @@ class DecoderFlyWeight {
   }
   unsigned finalStatesN() const { int n = 0; dsr_throw(dsr_decoder_final_states_n(_h, 0, &n)); return (unsigned) n; }
   bool traceBackSucceeded() const { int ok = 0; dsr_throw(dsr_decoder_trace_back_succeeded(_h, 0, &ok)); return ok != 0; }
-  LatticePtr lattice() { dsr_lattice* l = 0; dsr_throw(dsr_decoder_lattice(_h, 0, dsr_decoder_eos_index(_h), &l)); return LatticePtr(new Lattice(l)); }
+  LatticePtr lattice() {
+    dsr_lattice* l = 0; dsr_throw(dsr_decoder_lattice(_h, 0, dsr_decoder_eos_index(_h), &l));
+    return LatticePtr(_wfst ? new Lattice(l, _wfst->inputLexicon(), _wfst->outputLexicon()) : new Lattice(l));
+  }
   void writeGMM(const String& conv, const String& channel, const String& spk, const String& utt, double cfrom, double score, const String& fileName = "", double frameInterval = 0.01) {
     dsr_throw(dsr_decoder_write_gmm(_h, 0, conv.c_str(), channel.c_str(), spk.c_str(), utt.c_str(), cfrom, score, fileName.c_str(), frameInterval));
   }

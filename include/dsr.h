@@ -366,8 +366,49 @@ int        dsr_lattice_num_edges(const dsr_lattice*);
 int        dsr_lattice_final_states_n(const dsr_lattice*);      /* finalStatesN() (decoder.h:598-608) */
 dsr_status dsr_lattice_get(const dsr_lattice*, int32_t* nodeFinal, int32_t* from, int32_t* to, uint32_t* in, uint32_t* out, int32_t* start,
                            int32_t* end, double* ac, double* lm);   /* any pointer may be NULL */
-/* Lattice::write(fileName, useSymbols = false, writeData) (asr/lattice/lattice.cc:715-757); a cyclic lattice is DSR_E_CONSISTENCY (:862-864) */
-dsr_status dsr_lattice_write(const dsr_lattice*, const char* fileName, int writeData);
+/* Lattice::write(fileName, useSymbols = false, writeData) (asr/lattice/lattice.cc:715-757); a cyclic lattice is DSR_E_CONSISTENCY (:862-864).
+ * Links print under the nodes' current indices (prune/purge renumber them) with their cost when it is not zero (fsm.cc:1171-1178); the data line
+ * is "start end ac lm gamma" (lattice.h:151-154).  fileName "" = stdout. */
+dsr_status dsr_lattice_write(dsr_lattice*, const char* fileName, int writeData);
+/* The operations of asr/lattice's Lattice (lattice.i:79-123) on a lattice object -- the decoder's, an unpacked one or one read from a file.  Host
+ * work, as in the reference (a lattice is hundreds to thousands of links).  The object keeps what the reference's keeps between calls: rescoring
+ * tokens, probabilities, posteriors, the cached topological order, and _acScale/_lmScale/penalties of the last call.
+ *   read          WFST<..>::read(fileName, noSelfLoops, readData) (asr/fsm/fsm.h:3787-3873): the first state named is the initial node; symbols that
+ *                 are not numbers are looked up in the lexica (either may be NULL: DSR_E_KEY then)
+ *   rescore       Lattice::rescore(lmScale, lmPenalty, silPenalty, silSymbol) (lattice.cc:122-171): best-token pass in topological order with the
+ *                 acoustic scale of the last gammaProbs (1.0 before); silenceX = inputLexicon()->index(silSymbol), resolved by the caller
+ *   best_hypo     Lattice::bestHypo(useInputSymbols) (:281-306) as symbol indices, first symbol first (the reference joins them with " ")
+ *   gamma_probs   Lattice::gammaProbs(acScale, lmScale, lmPenalty, silPenalty, silSymbol) (:309-379): forward/backward over the sorted nodes,
+ *                 posterior (as a negative log) per link; returns the lattice's forward probability; the reference's consistency errors
+ *                 (forward != backward, negative posterior, a term above LogZero) come back as DSR_E_CONSISTENCY
+ *   prune         Lattice::prune(threshold) (:648-693): links with gamma > threshold leave the initial and intermediate nodes, unreachable
+ *                 nodes are dropped and the rest renumbered in topological order
+ *   prune_edges   Lattice::pruneEdges(edgesN) (:695-713): threshold = the edgesN-th smallest gamma over the links EdgeIterator sees
+ *   purge         Lattice::purge() (:776-841): nodes from which no final node can be reached are dropped (links into them stay, as in the reference)
+ *   get_state     per link: gamma, still on its node's list; per node: current index, still held by the lattice, forward and backward probability */
+dsr_status dsr_lattice_read(const char* fileName, int noSelfLoops, int readData, dsr_lexicon* inputLex, dsr_lexicon* outputLex, dsr_lattice** out);
+dsr_status dsr_lattice_rescore(dsr_lattice*, double lmScale, double lmPenalty, double silPenalty, unsigned silenceX, float* score);
+dsr_status dsr_lattice_best_hypo(const dsr_lattice*, int useInputSymbols, uint32_t* symbols, int cap, int* n);     /* symbols NULL: length only */
+dsr_status dsr_lattice_gamma_probs(dsr_lattice*, double acScale, double lmScale, double lmPenalty, double silPenalty, unsigned silenceX, double* logProb);
+dsr_status dsr_lattice_prune(dsr_lattice*, double threshold);
+dsr_status dsr_lattice_prune_edges(dsr_lattice*, unsigned edgesN);
+dsr_status dsr_lattice_purge(dsr_lattice*);
+dsr_status dsr_lattice_get_state(dsr_lattice*, double* gamma, int32_t* edgeLive, int32_t* nodeIndex, int32_t* nodeLive, double* forwardProb,
+                                 double* backwardProb);              /* any pointer may be NULL */
+/* 1-best writers over the rescoring tokens (call rescore first; DSR_E_CONSISTENCY when no final node holds a token -- the reference dereferences a
+ * null token there).  fileName NULL or "": stdout, otherwise appended to.  Rows whose symbol equals endMarker are skipped.
+ *   write_ctm        Lattice::writeCTM (lattice.cc:420-477): ";; utt cfrom score", "conv channel start duration word score" per output symbol
+ *   write_phone_ctm  Lattice::writePhoneCTM (:479-537): the same per link, input symbols
+ *   write_hypo_htk   Lattice::writeHypoHTK (:539-601): "utt.rec", a line per word (flag bit 0: times in 100 ns, bit 1: score), "."
+ *   write_word_confs Lattice::writeWordConfs (:603-646): "uttId { {word} conf} ..." with conf = exp(-gamma) of the word's link */
+dsr_status dsr_lattice_write_ctm(const dsr_lattice*, const dsr_lexicon* outputLex, const char* conv, const char* channel, const char* spk, const char* utt,
+                                 double cfrom, double score, const char* fileName, double frameInterval, const char* endMarker);
+dsr_status dsr_lattice_write_phone_ctm(const dsr_lattice*, const dsr_lexicon* inputLex, const char* conv, const char* channel, const char* spk,
+                                       const char* utt, double cfrom, double score, const char* fileName, double frameInterval, const char* endMarker);
+dsr_status dsr_lattice_write_hypo_htk(const dsr_lattice*, const dsr_lexicon* outputLex, const char* conv, const char* channel, const char* spk,
+                                      const char* utt, double cfrom, double score, const char* fileName, int flag, double frameInterval,
+                                      const char* endMarker);
+dsr_status dsr_lattice_write_word_confs(const dsr_lattice*, const dsr_lexicon* outputLex, const char* fileName, const char* uttId, const char* endMarker);
 /* flat image of a lattice for the gather across ranks (north star: "gather decoded lattices/1-best") */
 size_t     dsr_lattice_pack_size(const dsr_lattice*);
 dsr_status dsr_lattice_pack(const dsr_lattice*, void* buf, size_t bufBytes);

@@ -79,6 +79,69 @@ def test_lattice_matches_oracle(dsr, oracle, cuda, tmp_path, seed, S, nDist, T, 
         _same_lattice(L.data, L2.data)
 
 
+@pytest.mark.parametrize("seed,S,nDist,T,beam,kw", [
+    (2, 1000, 64, 80, 30.0, dict()),
+    (3, 2000, 128, 60, 12.0, dict(lmPenalty=0.7)),
+    (4, 2000, 128, 60, 8.0, dict(silPenalty=1.5, silenceX=3)),
+    (6, 300, 8, 40, 25.0, dict(eps_frac=0.35, out_frac=0.3)),
+])
+def test_lattice_operations_on_a_decoded_lattice(dsr, oracle, cuda, tmp_path, seed, S, nDist, T, beam, kw):
+    """asr/lattice on what the search hands over (lattice.cc:122-379, 648-757): rescoring the decoder's lattice with the decoder's own scale and
+    penalties finds the decoder's 1-best again (words and, within the float accumulation of two different sums, its score); posteriors, pruning and the
+    files agree with the object-graph restatement (oracle/oracle_lattice.py) run on the ORACLE decoder's lattice, bit for bit / byte for byte."""
+    import importlib, sys, os
+    import torch
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+    olat = importlib.import_module("oracle_lattice")
+    gkw = {k: kw[k] for k in ("ties", "eps_frac", "nFinal", "out_frac") if k in kw}
+    dkw = {k: kw[k] for k in ("lmPenalty", "silPenalty", "silenceX") if k in kw}
+    arcs, fin = synth.random_wfst(S, nDist, seed=seed, nWords=200, **gkw)
+    go, gd = _graphs(dsr, oracle, arcs, fin)
+    rng = np.random.default_rng(200 + seed)
+    sc = rng.uniform(0, 10, (2, T, nDist)).astype(np.float32)
+    nfr = [T, T - 9]
+    dec = dsr.Decoder(beam=beam, lmScale=12.0, maxActive=8192, streams=2, latticeTokens=400000, **dkw)
+    dec.set(gd)
+    out = dec.decode_batch(torch.from_numpy(sc).to(cuda), torch.tensor(nfr, dtype=torch.int32, device=cuda))
+    P = dict(lmScale=12.0, lmPenalty=dkw.get("lmPenalty", 0.0), silPenalty=dkw.get("silPenalty", 0.0), silenceX=dkw.get("silenceX", 0xFFFFFFFF) & 0xFFFFFFFF)
+    for u in range(2):
+        ro = go.decode(sc[u, :nfr[u]], beam=beam, lmScale=12.0, lattice=True, eosX=7, **dkw)
+        L = dec.lattice(u, eosX=7); O = olat.Lattice.from_arrays(ro["lattice"])
+        try:
+            s = L.rescore(**P)
+        except dsr.DsrError as e:                                          # the (state, frame) collision of the epsilon case: not a DAG, both sides refuse
+            assert e.status == 4
+            with pytest.raises(ValueError):
+                O.rescore(**P)
+            continue
+        so = O.rescore(**P)
+        assert np.float32(s).view(np.int32) == np.float32(so).view(np.int32)
+        hyp = list(L.bestHypo()); assert hyp == list(O.bestHypo()) and list(L.bestHypo(True)) == list(O.bestHypo(True))
+        if out[u]["reachedFinal"]:
+            # the search's own best path is in the lattice and wins the rescoring with the search's own parameters
+            assert hyp == [int(w) for w in out[u]["words"] if w != 0]
+            if not dkw.get("silPenalty"):
+                assert abs(float(s) - out[u]["score"]) <= 2e-4 * abs(out[u]["score"])
+        g = L.gammaProbs(acScale=1.0, **P); g2 = O.gammaProbs(acScale=1.0, **P)     # (acScale stays behind for the next rescore, lattice.cc:124)
+        assert g == g2
+        sa, sb = L.state(), O.state()
+        for k in ("gamma", "fwd", "bwd"):
+            assert np.array_equal(sa[k].view(np.int64), sb[k].view(np.int64)), k
+        live = sa["edgeLive"] == 1
+        assert np.all(sa["gamma"][live] >= 0.0) and np.any(sa["gamma"][live] < 1e-3)          # posteriors are probabilities; the best path's links are near 1
+        L.prune(3.0); O.prune(3.0)                                                                 # links below a posterior of e^-3 go
+        sa, sb = L.state(), O.state()
+        for k in ("edgeLive", "nodeIndex", "nodeLive"):
+            assert np.array_equal(sa[k], sb[k]), k
+        assert sa["edgeLive"].sum() <= live.sum()                                              # (a narrow beam leaves one path: nothing to prune)
+        s2 = L.rescore(**P); so2 = O.rescore(**P)
+        assert np.float32(s2).view(np.int32) == np.float32(so2).view(np.int32) and list(L.bestHypo()) == list(O.bestHypo())
+        assert np.float32(s2) == np.float32(s) and list(L.bestHypo()) == hyp                    # pruning by posterior keeps the best path
+        a, b = str(tmp_path / ("p%d.lat" % u)), str(tmp_path / ("o%d.lat" % u))
+        L.write(a, writeData=True); O.write(b, writeData=True)
+        assert open(a, "rb").read() == open(b, "rb").read()
+
+
 def test_lattice_epsilon_free_contains_the_best_path(dsr, oracle, cuda):
     """without epsilon arcs the lattice is exact: its best path has the decode score (property, no oracle needed)"""
     import torch
