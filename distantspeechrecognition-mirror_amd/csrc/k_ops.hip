@@ -150,6 +150,19 @@ __global__ void k_op_pack_bins(const double2* in, int T, int F, int M, float2* o
 }
 
 #define GRID(n) dim3((unsigned) (((n) + 255) / 256)), dim3(256), 0, st
+// Lattice::_updateAcNode (asr/lattice/lattice.cc:392-409): a link's acoustic score = the sum over its frames of its distribution's score, a double
+// accumulator over float scores in frame order.  One thread per link walking a column of the score matrix [T][K]: a gather, a few KB per lattice.
+__global__ void k_op_link_ac(const float* __restrict__ scores, int K, const int* __restrict__ dist, const int* __restrict__ start,
+                             const int* __restrict__ end, int n, double* __restrict__ out)
+{
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  double sum = 0.0;
+  const float* col = scores + dist[i];
+  for (int f = start[i]; f <= end[i]; f++) sum = __dadd_rn(sum, (double) col[(size_t) f * K]);
+  out[i] = sum;
+}
+
 void op_frames(const float* x, int nsamp, int T, int L, int shift, float* out, hipStream_t st) { if (T > 0) hipLaunchKernelGGL(k_op_frames, GRID((long) T * L), x, nsamp, T, L, shift, out); }
 void op_preemph(const float* in, int T, int L, double mu, float* out, hipStream_t st) { if (T > 0) hipLaunchKernelGGL(k_op_preemph, GRID((long) T * L), in, T, L, mu, out); }
 void op_hamming_f(const float* in, int T, int L, const double* w, float* out, hipStream_t st) { if (T > 0) hipLaunchKernelGGL(k_op_hamming_f, GRID((long) T * L), in, T, L, w, out); }
@@ -172,6 +185,8 @@ void op_adjacent(const float* in, int T, int N, int delta, float* out, hipStream
 void op_expand_bins(const float2* in, int T, int F, int M, double2* out, hipStream_t st) { if (T > 0) hipLaunchKernelGGL(k_op_expand_bins, GRID((long) T * M), in, T, F, M, out); }
 void op_highpass(const double2* in, int T, int M, int cutBin, double2* out, hipStream_t st) { if (T > 0) hipLaunchKernelGGL(k_op_highpass, GRID((long) T * M), in, T, M, cutBin, out); }
 void op_orth_assemble(const float2* low, const double2* full, int T, int F, int M, double2* out, hipStream_t st) { if (T > 0) hipLaunchKernelGGL(k_op_orth_assemble, GRID((long) T * M), low, full, T, F, M, out); }
+void op_link_ac(const float* scores, int K, const int* dist, const int* start, const int* end, int n, double* out, hipStream_t st)
+{ if (n > 0) hipLaunchKernelGGL(k_op_link_ac, GRID((long) n), scores, K, dist, start, end, n, out); }
 void op_pack_bins(const double2* in, int T, int F, int M, float2* out, hipStream_t st) { if (T > 0) hipLaunchKernelGGL(k_op_pack_bins, GRID((long) T * F), in, T, F, M, out); }
 #undef GRID
 

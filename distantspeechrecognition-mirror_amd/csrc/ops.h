@@ -17,6 +17,7 @@ void op_expand_bins(const float2* in, int T, int F, int M, double2* out, hipStre
 void op_pack_bins(const double2* in, int T, int F, int M, float2* out, hipStream_t st);
 void op_highpass(const double2* in, int T, int M, int cutBin, double2* out, hipStream_t st);
 void op_orth_assemble(const float2* low, const double2* full, int T, int F, int M, double2* out, hipStream_t st);
+void op_link_ac(const float* scores, int K, const int* dist, const int* start, const int* end, int n, double* out, hipStream_t st);
 void op_cmn(const float* in, int T, int N, int mode, double devNormFactor, float* out, hipStream_t st, const float* wgt = nullptr, int wStride = 0);   // k_mfcc.hip
 // host table builders (k_mfcc.hip), reference formulas of feature.cc:1726-1838,1954-2090 and gslmatrix.cc:108-132
 struct SparseRowsD { std::vector<int> start, count, off; std::vector<double> coef, div; int roundFloat = 0; };

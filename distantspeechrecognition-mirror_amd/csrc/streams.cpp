@@ -10,6 +10,7 @@
 // host-side output buffer.  Compute always runs on the GPU (k_ops.hip / k_filterbank.hip / k_beamform.hip).
 #include "common.h"
 #include "ops.h"
+#include "lattice.h"
 #include <cmath>
 
 using namespace dsr;
@@ -764,6 +765,52 @@ dsr_status dsr_decoder_decode_stream(dsr_decoder* dec, dsr_distribset* d, dsr_de
     s = dsr_decoder_decode_batch(dec, d->d_scores.p, d->d_T.p, 1, T, K, res, arcs_out, words_out, maxPath, S0); if (s) throw Error(s, "%s", dsr_last_error());
     d->feat->frameX = T - 1; d->feat->endOfSamples = true;                   // the reference has pulled the stream to its end
     if (res->status != DSR_OK) throw Error(res->status, "decode failed (status %d)", res->status);
+  });
+}
+
+// Lattice::gammaProbsDist(dss, acScale, lmScale, lmPenalty, silPenalty, silSymbol) (asr/lattice/lattice.cc:331-341): the links' acoustic scores are
+// recomputed from the distribution set (_updateAc, :381-409: links of the initial node and of the nodes in _nodes -- not of the final nodes -- with
+// an input symbol; score = sum over the link's frames), then gammaProbs.  The frames are scored once on the device, the per-link sums are a gather
+// kernel over the score matrix.  A sum above LogZero is the reference's consistency error.
+dsr_status dsr_lattice_gamma_probs_dist(dsr_lattice* L, dsr_distribset* d, double acScale, double lmScale, double lmPenalty, double silPenalty, unsigned silenceX,
+                                        double* logProb)
+{
+  return guard([&] {
+    if (!L || !d) throw Error(DSR_E_PARAMETER, "null argument");
+    d->cachedFrame = -1;                                                     // dss->resetCache()
+    L->ensure_ops(); L->sorted.clear();                                      // _clearSorted()
+    d->feat->materialize();
+    const int T = d->feat->nFrames, K = dsr_gmm_num_dists(d->gmm);
+    std::vector<int> link, dist, start, end;
+    auto take = [&](int node) {
+      for (size_t k = 0; k < L->adj[(size_t) node].size(); k++) {
+        const int e = L->adj[(size_t) node][k];
+        if (L->in[(size_t) e] == 0) continue;
+        const long dx = (long) L->in[(size_t) e] - 1;
+        if (dx >= K) throw Error(DSR_E_INDEX, "link %d names distribution %ld of %d", e, dx, K);
+        if (L->start[(size_t) e] <= L->end[(size_t) e] && (L->start[(size_t) e] < 0 || L->end[(size_t) e] >= T))
+          throw Error(DSR_E_INDEX, "link %d spans frames %d..%d of %d", e, L->start[(size_t) e], L->end[(size_t) e], T);
+        link.push_back(e); dist.push_back((int) dx); start.push_back(L->start[(size_t) e]); end.push_back(L->end[(size_t) e]);
+      }
+    };
+    take(0);
+    for (size_t p = 0; p < L->slots.size(); p++) if (L->slots[p] >= 0) take(L->slots[p]);
+    if (!link.empty()) {
+      if (T <= 0) throw Error(DSR_E_ITERATOR, "end of samples!");
+      d->d_scores.reserve((size_t) T * K);
+      const dsr_status s = dsr_gmm_score(d->gmm, reinterpret_cast<const float*>(d->feat->dev.p), (int64_t) T, d->mode, d->d_scores.p, nullptr, S0); if (s) throw Error(s, "%s", dsr_last_error());
+      DevBuf<int> dd, ds, de; DevBuf<double> dout; dd.upload(dist); ds.upload(start); de.upload(end); dout.reserve(link.size());
+      op_link_ac(d->d_scores.p, K, dd.p, ds.p, de.p, (int) link.size(), dout.p, S0);
+      DSR_HIP(hipGetLastError());
+      std::vector<double> sums(link.size());
+      DSR_HIP(hipMemcpy(sums.data(), dout.p, sizeof(double) * link.size(), hipMemcpyDeviceToHost));
+      for (size_t i = 0; i < link.size(); i++) {
+        if (sums[i] > 1.0E10) throw Error(DSR_E_CONSISTENCY, "Log-prob (%g) > LogZero (%g)", sums[i], 1.0E10);
+        L->ac[(size_t) link[i]] = sums[i];
+      }
+    }
+    const double p = L->gamma_probs(acScale, lmScale, lmPenalty, silPenalty, silenceX);
+    if (logProb) *logProb = p;
   });
 }
 

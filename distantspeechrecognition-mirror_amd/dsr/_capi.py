@@ -818,6 +818,12 @@ class Lattice:
         check(_lib.dsr_lattice_gamma_probs(self.h, float(acScale), float(lmScale), float(lmPenalty), float(silPenalty), int(silenceX), C.byref(p)))
         return p.value
 
+    def gammaProbsDist(self, distribset, acScale=1.0, lmScale=12.0, lmPenalty=0.0, silPenalty=0.0, silenceX=0):
+        """Lattice::gammaProbsDist (lattice.cc:331-341): distribset = a dsr_distribset handle (asr.gaussian.DistribSetBasicPtr keeps it in _ds)"""
+        p = C.c_double(0.0)
+        check(_lib.dsr_lattice_gamma_probs_dist(self.h, distribset, float(acScale), float(lmScale), float(lmPenalty), float(silPenalty), int(silenceX), C.byref(p)))
+        return p.value
+
     def prune(self, threshold=100.0):
         check(_lib.dsr_lattice_prune(self.h, float(threshold)))
 

@@ -80,8 +80,9 @@ class LatticePtr(object):
     def writeWordConfs(self, fileName, uttId, endMarker="</s>"):
         self._need().writeWordConfs(self._out, fileName, uttId, endMarker)
 
-    def gammaProbsDist(self, *a, **kw):
-        raise K.DsrError(K.E_PARAMETER, "gammaProbsDist: re-scoring the links against a distribution set is not built")
+    def gammaProbsDist(self, dss, acScale=1.0, lmScale=12.0, lmPenalty=0.0, silPenalty=0.0, silSymbol="SIL-m"):
+        """lattice.i:119-121: the links' acoustic scores recomputed from the distribution set (scored on the device), then gammaProbs"""
+        return self._need().gammaProbsDist(dss._ds, acScale, lmScale, lmPenalty, silPenalty, self._silX(silSymbol))
 
     def createPhoneLattice(self, *a, **kw):
         raise K.DsrError(K.E_PARAMETER, "createPhoneLattice is not built")

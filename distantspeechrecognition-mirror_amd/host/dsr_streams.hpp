@@ -518,6 +518,9 @@ class Lattice {
   double gammaProbs(double acScale = 1.0, double lmScale = 12.0, double lmPenalty = 0.0, double silPenalty = 0.0, const String& silSymbol = "SIL-m") {
     double p = 0.0; dsr_throw(dsr_lattice_gamma_probs(need(), acScale, lmScale, lmPenalty, silPenalty, silX(silSymbol), &p)); return p;
   }
+  double gammaProbsDist(DistribSetBasicPtr& dss, double acScale = 1.0, double lmScale = 12.0, double lmPenalty = 0.0, double silPenalty = 0.0, const String& silSymbol = "SIL-m") {
+    double p = 0.0; dsr_throw(dsr_lattice_gamma_probs_dist(need(), dss->handle(), acScale, lmScale, lmPenalty, silPenalty, silX(silSymbol), &p)); return p;
+  }
   void prune(double threshold = 100.0) { dsr_throw(dsr_lattice_prune(need(), threshold)); }
   void pruneEdges(unsigned edgesN = 0) { dsr_throw(dsr_lattice_prune_edges(need(), edgesN)); }
   void purge() { dsr_throw(dsr_lattice_purge(need())); }

@@ -693,6 +693,12 @@ dsr_status dsr_distribset_score(dsr_distribset*, int distX, int frameX, float* s
 dsr_status dsr_distribset_reset_cache(dsr_distribset*);
 dsr_status dsr_distribset_reset_feature(dsr_distribset*);
 dsr_status dsr_decoder_decode_stream(dsr_decoder*, dsr_distribset*, dsr_decode_result* res, int32_t* arcs_out, uint32_t* words_out, int maxPath);
+/* Lattice::gammaProbsDist(dss, acScale, lmScale, lmPenalty, silPenalty, silSymbol) (asr/lattice/lattice.cc:331-341, 381-409): the acoustic score of
+ * every link with an input symbol that leaves the initial node or a node of _nodes becomes the sum of its distribution's scores over the link's
+ * frames (double accumulator, frame order; the frames of the bound feature stream are scored on the device, the sums are one gather kernel), then
+ * gammaProbs.  DSR_E_INDEX: a link names a distribution or a frame the set / the stream does not have. */
+dsr_status dsr_lattice_gamma_probs_dist(dsr_lattice*, dsr_distribset*, double acScale, double lmScale, double lmPenalty, double silPenalty,
+                                        unsigned silenceX, double* logProb);
 
 #ifdef __cplusplus
 }

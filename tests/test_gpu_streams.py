@@ -213,6 +213,33 @@ def test_decode_like_decodeTest(dsr, oracle, cuda, headset, tmp_path):
     for k in ("nodeFinal", "from", "to", "in", "out", "start", "end"):
         assert np.array_equal(Ld[k], ro2["lattice"][k]), k
     assert np.array_equal(Ld["ac"].view(np.int64), ro2["lattice"]["ac"].view(np.int64)) and np.array_equal(Ld["lm"].view(np.int64), ro2["lattice"]["lm"].view(np.int64))
+    # ---- asr.lattice.LatticePtr on that lattice (lattice.i:79-123): rescore with the search's own parameters finds the search's hypothesis again;
+    #      gammaProbsDist recomputes every link's acoustic score from the distribution set (frames scored on the device, one gather kernel for the sums)
+    import importlib, os, sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+    olat = importlib.import_module("oracle_lattice")
+    lat = d.lattice(); O = olat.Lattice.from_arrays(ro2["lattice"])
+    s1 = lat.rescore(12.0, 0.0, 0.5, "SIL-m"); o1 = O.rescore(12.0, 0.0, 0.5, 4)
+    assert np.float32(s1).view(np.int32) == np.float32(o1).view(np.int32)
+    assert lat.bestHypo() == hyp and lat.bestHypo(True) == "".join(inlex[i] + " " for i in O.bestHypo(True))
+    for ed in O.allEdges:                                                                            # _updateAcNode (lattice.cc:392-409) on the oracle's scores
+        if ed.input != 0 and not ed.prev.final:
+            acc = 0.0
+            for t in range(ed.start, ed.end + 1):
+                acc += float(so[t, ed.input - 1])
+            ed.ac = acc
+    g1 = lat.gammaProbsDist(dss, 1.0 / 12.0, 12.0, 0.0, 0.5, "SIL-m"); O._clearSorted(); g0 = O.gammaProbs(1.0 / 12.0, 12.0, 0.0, 0.5, 4)
+    assert g1 == g0
+    sa, sb = lat.state(), O.state()
+    for k in ("gamma", "fwd", "bwd"):
+        assert np.array_equal(sa[k].view(np.int64), sb[k].view(np.int64)), k
+    lat.write(str(tmp_path / "p.lat"), writeData=True); O.write(str(tmp_path / "o.lat"), writeData=True)
+    assert open(tmp_path / "p.lat", "rb").read() == open(tmp_path / "o.lat", "rb").read()          # the recomputed ac column and the posteriors, byte for byte
+    lat.writeCTM("conv", "1", "spk", "utt", 0.0, float(score), str(tmp_path / "p.ctm")); O.writeCTM(outlex, "conv", "1", "spk", "utt", 0.0, float(score), str(tmp_path / "o.ctm"))
+    assert open(tmp_path / "p.ctm", "rb").read() == open(tmp_path / "o.ctm", "rb").read() and " w" in open(tmp_path / "p.ctm").read()
+    with pytest.raises(dsr.DsrError) as e:
+        lat.rescore(12.0, 0.0, 0.0, "NOPE")
+    assert e.value.status == 11                                                                      # inputLexicon()->index(silSymbol): jkey_error
     # ---- topN (decoder.h:571-581): the 6 best tokens of every list expanded in score order, no beam
     dn = DecoderFlyWeightPtr(dss, beam=80.0, lmScale=12.0, silPenalty=0.5, topN=6, generateLattice=False); dn.set(wfst)
     sn = dn.decode()
