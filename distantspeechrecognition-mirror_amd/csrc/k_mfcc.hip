@@ -364,6 +364,45 @@ __global__ void k_cmn(const float* __restrict__ cep, const int* __restrict__ Tar
   for (int t = T; t < Tmax; t++) o[(long) t * N] = 0.0f;
 }
 
+// Batch mean/variance normalisation of one utterance per workgroup: the cepstra are read once, coalesced, into LDS; N threads run the reference's
+// sequential fp32 sums from there (the thread-per-(utterance, coefficient) kernel above puts fewer wavefronts on the chip than it has CUs and
+// walks memory with a stride); every thread then normalises and writes coalesced.  Same operations in the same order: the same bits.
+__global__ __launch_bounds__(256) void k_cmn_lds(const float* __restrict__ cep, const int* __restrict__ Tarr, int Tmax, int N, double devNormFactor,
+                                                 float* __restrict__ out)
+{
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  float* xs = reinterpret_cast<float*>(smem);
+  __shared__ float s_m[64], s_d[64];
+  const int u = blockIdx.x;
+  const int Tu = Tarr ? Tarr[u] : Tmax;
+  const int T = Tu < Tmax ? Tu : Tmax;
+  const float* x = cep + (long) u * Tmax * N; float* o = out + (long) u * Tmax * N;
+  const int n = T * N;
+  for (int j = threadIdx.x; j < n; j += 256) xs[j] = x[j];
+  __syncthreads();
+  if ((int) threadIdx.x < N) {
+    const int i = threadIdx.x;
+    float m = 0.0f; double ttl = 0.0;
+    for (int t = 0; t < T; t++) { m = __fadd_rn(m, __fmul_rn(1.0f, xs[t * N + i])); ttl += 1.0; }
+    m = (float) ((double) m / ttl);
+    float v = 0.0f;
+    if (devNormFactor > 0.0) {
+      for (int t = 0; t < T; t++) { const float f = xs[t * N + i]; v = __fadd_rn(v, __fmul_rn(__fmul_rn(1.0f, f), f)); }
+      v = (float) __dsub_rn((double) v / ttl, (double) __fmul_rn(m, m));
+    }
+    float va = v; if (va < 0.0001f) va = 0.0001f;
+    s_m[i] = m; s_d[i] = va;
+  }
+  __syncthreads();
+  for (int j = threadIdx.x; j < n; j += 256) {
+    const int i = j % N;
+    float r = __fsub_rn(xs[j], s_m[i]);
+    if (devNormFactor > 0.0) r = (float) ((double) r / __dmul_rn(devNormFactor, (double) __fsqrt_rn(s_d[i])));
+    o[j] = r;
+  }
+  for (int j = n + threadIdx.x; j < Tmax * N; j += 256) o[j] = 0.0f;
+}
+
 // out[u][t][i] = sum_j A[i][j] * splice(t)[j], splice slot s = frame clamp(t+s-delta, 0, T-1)
 // A workgroup owns FB consecutive frames of one utterance.  LDS holds the transform as [outDim][2 delta + 1][Np] (rows of N coefficients padded
 // to Np = multiple of 4) and the FB + 2 delta (clamped) input rows, padded the same way: every LDS read is an aligned 16-byte read, the
@@ -415,6 +454,70 @@ __global__ __launch_bounds__(256) void k_splice_lda(const float* __restrict__ in
       r = __fadd_rn(0.0f, temp);
     }
     o[(long) t * od + i] = r;
+  }
+}
+
+// The same product with register blocking: a thread owns one output coefficient for FT consecutive frames, so a row of the transform is read from LDS
+// once per FT frames (the kernel above reads it once per frame and is bound by those reads), the input rows are wave-wide broadcasts, and the rows
+// of the transform are pitched so that 16 lanes' 16-byte reads fall on 16 different bank groups.  A workgroup (nG groups of outDim threads) walks NB
+// blocks of nG * FT frames with the transform staged once.  Order of every sum as above: the same bits.
+template <int FT>
+__global__ __launch_bounds__(256) void k_splice_lda_b(const float* __restrict__ in, const int* __restrict__ Tarr, int Tmax, int N, int delta, int outDim,
+                                                      const float* __restrict__ A, float* __restrict__ out, int nG, int NB)
+{
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int S = 2 * delta + 1, W = S * N, Np = (N + 3) & ~3, pitch = S * Np + 4, FB = nG * FT;
+  const int u = blockIdx.y;
+  int T = Tarr[u] < Tmax ? Tarr[u] : Tmax;
+  if (delta > 0 && T < delta) T = 0;                 // AdjacentFeature cannot be primed (feature.cc:2861-2866)
+  const float* x = in + (long) u * Tmax * N;
+  float* o = out + (long) u * Tmax * outDim;
+  float* a = reinterpret_cast<float*>(smem);                         // [outDim][pitch]
+  float* xs = a + (size_t) outDim * pitch;                           // [FB + 2 delta][Np]
+  for (int i = threadIdx.x; i < outDim * S * Np; i += blockDim.x) {
+    const int k = i % Np, q = i / Np, row = q / S, sl = q - row * S;
+    a[(size_t) row * pitch + sl * Np + k] = (k < N) ? A[(long) row * W + sl * N + k] : 0.0f;
+  }
+  const int g = threadIdx.x / outDim, i = threadIdx.x - g * outDim;
+  const bool worker = g < nG;
+  for (int b = 0; b < NB; b++) {
+    const int t0 = (blockIdx.x * NB + b) * FB;
+    if (t0 >= Tmax) break;
+    __syncthreads();                                                 // (the transform is in place / the rows of the block before are no longer read)
+    if (T > 0)
+      for (int j = threadIdx.x; j < (FB + 2 * delta) * Np; j += blockDim.x) {
+        const int k = j % Np, rr = j / Np; int src = t0 - delta + rr; if (src < 0) src = 0; if (src > T - 1) src = T - 1;
+        xs[j] = (k < N) ? x[(long) src * N + k] : 0.0f;
+      }
+    __syncthreads();
+    if (!worker) continue;
+    float temp[FT];
+#pragma unroll
+    for (int f = 0; f < FT; f++) temp[f] = 0.0f;
+    if (t0 + g * FT < T) {
+      const float* ar = a + (size_t) i * pitch;
+      for (int s = 0; s < S; s++) {
+        const float* xr = xs + (size_t) (g * FT + s) * Np;
+        for (int k4 = 0; k4 < Np; k4 += 4) {
+          const float4 av = *reinterpret_cast<const float4*>(ar + s * Np + k4);
+          const bool h1 = k4 + 1 < N, h2 = k4 + 2 < N, h3 = k4 + 3 < N;
+#pragma unroll
+          for (int f = 0; f < FT; f++) {
+            const float4 xv = *reinterpret_cast<const float4*>(xr + f * Np + k4);
+            float tt = __fadd_rn(temp[f], __fmul_rn(xv.x, av.x));
+            if (h1) tt = __fadd_rn(tt, __fmul_rn(xv.y, av.y));
+            if (h2) tt = __fadd_rn(tt, __fmul_rn(xv.z, av.z));
+            if (h3) tt = __fadd_rn(tt, __fmul_rn(xv.w, av.w));
+            temp[f] = tt;
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int f = 0; f < FT; f++) {
+      const int t = t0 + g * FT + f;
+      if (t < Tmax) o[(long) t * outDim + i] = (t < T) ? __fadd_rn(0.0f, temp[f]) : 0.0f;
+    }
   }
 }
 
@@ -657,6 +760,12 @@ dsr_status dsr_mfcc_run(dsr_mfcc* p, const float* y, const int32_t* nsamp, int U
     float* cmnOut = cepOut;
     if (c.cmnMode != 0) {
       cmnOut = (stage == 2) ? feat : (p->w_cmn.reserve(nT * c.ncep), p->w_cmn.p);
+      const size_t ldsC = sizeof(float) * (size_t) Tmax * c.ncep;
+      static const bool plainCmn = getenv("DSR_CMN_PLAIN") != nullptr;
+      if (c.cmnMode == 1 && c.ncep <= 64 && ldsC <= 64 * 1024 && !plainCmn) {
+        DSR_HIP(hipFuncSetAttribute((const void*) k_cmn_lds, hipFuncAttributeMaxDynamicSharedMemorySize, (int) ldsC));
+        hipLaunchKernelGGL(k_cmn_lds, dim3(U), dim3(256), ldsC, st, cepOut, p->d_T.p, Tmax, c.ncep, c.devNormFactor, cmnOut);
+      } else
       hipLaunchKernelGGL(k_cmn, dim3(cdiv((long) U * c.ncep, 64)), dim3(64), 0, st, cepOut, p->d_T.p, U, Tmax, c.ncep, c.cmnMode, c.devNormFactor, cmnOut, (const float*) nullptr, 0);
       DSR_HIP(hipGetLastError());
     } else if (stage == 2) { DSR_HIP(hipMemcpyAsync(feat, cepOut, nT * c.ncep * sizeof(float), hipMemcpyDeviceToDevice, st)); }
@@ -665,9 +774,20 @@ dsr_status dsr_mfcc_run(dsr_mfcc* p, const float* y, const int32_t* nsamp, int U
     const int FB = getenv("DSR_LDA_FB") ? atoi(getenv("DSR_LDA_FB")) : 64;           // frames per workgroup (the transform is staged once per workgroup)
     const size_t lds2 = c.outDim > 0 ? sizeof(float) * ((size_t) c.outDim * S2 * Np + (size_t) (FB + 2 * c.delta) * Np) : 16;
     if (lds2 > 160 * 1024) throw Error(DSR_E_DIMENSION, "linear transform needs %zu bytes of LDS", lds2);
-    DSR_HIP(hipFuncSetAttribute((const void*) k_splice_lda, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds2));
-    hipLaunchKernelGGL(k_splice_lda, dim3(cdiv(Tmax, FB), U), dim3(256), lds2, st, cmnOut, p->d_T.p, Tmax, c.ncep, c.delta, c.outDim,
-                       c.outDim > 0 ? p->d_lda.p : nullptr, feat, FB);
+    // register-blocked product when a group of outDim threads fits the workgroup and the pitched transform fits LDS beside two more workgroups
+    constexpr int FT = 8;
+    const int nG = c.outDim > 0 ? 256 / c.outDim : 0;
+    const size_t ldsB = c.outDim > 0 ? sizeof(float) * ((size_t) c.outDim * (S2 * Np + 4) + (size_t) (nG * FT + 2 * c.delta) * Np) : 0;
+    static const bool plainLda = getenv("DSR_LDA_PLAIN") != nullptr;
+    if (c.outDim > 0 && nG >= 1 && ldsB <= 52 * 1024 && !plainLda) {
+      const int FBb = nG * FT; const int NB = 4;
+      DSR_HIP(hipFuncSetAttribute((const void*) k_splice_lda_b<FT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) ldsB));
+      hipLaunchKernelGGL(k_splice_lda_b<FT>, dim3(cdiv(Tmax, FBb * NB), U), dim3(256), ldsB, st, cmnOut, p->d_T.p, Tmax, c.ncep, c.delta, c.outDim, p->d_lda.p, feat, nG, NB);
+    } else {
+      DSR_HIP(hipFuncSetAttribute((const void*) k_splice_lda, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds2));
+      hipLaunchKernelGGL(k_splice_lda, dim3(cdiv(Tmax, FB), U), dim3(256), lds2, st, cmnOut, p->d_T.p, Tmax, c.ncep, c.delta, c.outDim,
+                         c.outDim > 0 ? p->d_lda.p : nullptr, feat, FB);
+    }
     DSR_HIP(hipGetLastError());
   });
 }
