@@ -257,7 +257,7 @@ __global__ __launch_bounds__(256) void k_gmm_mfma_reg(const float* __restrict__ 
   // closes one codebook for one frame: score from the best candidate; a near tie goes to the list
   auto finish = [&](const long nme, const int fr, const int kcb, const float m1, const int a1, const float m2, const int a2) __attribute__((always_inline)) {
     float best = m1; int ba = a1;
-    if (m2 - m1 <= 1e-4f * (fabsf(m1) + 1.0f) && nme < N) {
+    if (!(dbg & 2) && m2 - m1 <= 1e-4f * (fabsf(m1) + 1.0f) && nme < N) {
       const unsigned slot = atomicAdd(&s_tie, 1u);
       if (slot < tieCap) myList[slot] = ((unsigned long long) nme << 32) | ((unsigned long long) kcb << 16) | ((unsigned long long) a1 << 8) | (unsigned long long) a2;
       else {                                                     // list full: settle it here (cold)
@@ -287,7 +287,8 @@ __global__ __launch_bounds__(256) void k_gmm_mfma_reg(const float* __restrict__ 
         m2 = lt1 ? m1 : (lt2 ? v : m2); a2 = lt1 ? a1 : (lt2 ? j : a2);
         m1 = lt1 ? v : m1; a1 = lt1 ? j : a1;
       }
-      if (kcb < K) finish(nme, fr, kcb, m1, a1, m2, a2);
+      if (dbg & 8) { if (m1 + m2 == 123.456f) sbuf[fr] = (float) (a1 + a2); }
+      else if (kcb < K) finish(nme, fr, kcb, m1, a1, m2, a2);
     } else {
       constexpr int RH = R / 2;                                  // registers of a codebook in this lane
       const int c = q;                                           // q counts the chunk's codebooks here
@@ -316,7 +317,7 @@ __global__ __launch_bounds__(256) void k_gmm_mfma_reg(const float* __restrict__ 
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
       const int staged = (ch + 1) * CPC - kFlush0;
       const int cnt = (kFlush0 + staged < K ? staged : K - kFlush0);
-      for (int f = kh; f < 64; f += 2) {
+      if (!(dbg & 4)) for (int f = kh; f < 64; f += 2) {
         const long n = n0 + f;
         if (n < N && col < cnt) { score[n * K + kFlush0 + col] = sbuf[f * SCP + col]; if (argmin) argmin[n * K + kFlush0 + col] = abuf[f * 32 + col]; }
       }

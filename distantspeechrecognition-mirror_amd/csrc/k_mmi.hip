@@ -11,9 +11,11 @@
 // when useBinaryMask's fwidth > 1: those frames take a workgroup barrier and one thread does the bins in order, as the reference's loop).
 // fp64 arithmetic in the reference's order on the pipe's complex64 snapshots (-ffp-contract=off).
 //
-// Not carried over: the TYPE_APAB post-filter (beamformer.cc:2047-2049) -- its output vector is not conjugate-symmetric (postfilter.cc:317-336
-// filters the bins below fftLen/2 only) and this library hands the half spectrum on; refused with DSR_E_PARAMETER.  For the same reason the
-// mask's averaged value lands in bin k only (the reference also writes it, unconjugated, to bin fftLen-k, :2302-2304).
+// The TYPE_APAB post-filter (beamformer.cc:2047-2049, 2177-2179; ApabFilter / ApabFilter_f postfilter.cc:225-340, always called with channelX =
+// chanN/2) filters the bins below fftLen/2 only (with halfBandShift it mirrors the weights onto fftLen-1-k): without halfBandShift its output vector
+// is not conjugate-symmetric, so in that configuration the kernel writes all fftLen bins of a frame (dsr_mmi_out_bins) -- the upper ones as the
+// reference leaves them: the conjugate of the UNFILTERED lower bin, or, where the mask struck, the mask's value itself, unconjugated (:2302-2304).
+// In every other configuration the half spectrum is handed on and the mask's averaged value lands in bin k only.
 #include "common.h"
 #include "svd_linpack.h"
 #include <complex>
@@ -107,26 +109,30 @@ template <int CT>
 __global__ __launch_bounds__(256) void k_mmi(const float2* __restrict__ X, const int* __restrict__ nframesArr, const double2* __restrict__ weff,
                                              const double2* __restrict__ wup, const double2* __restrict__ mani, double2* __restrict__ csd,
                                              double2* __restrict__ taScr, float2* __restrict__ Y, int U, int C, int Tmax, int F, int S, int target,
-                                             int hbs, int pfType, double alphaCfg, int useMask, int maskType, double avgFactor, int fwidth, int M)
+                                             int hbs, int pfType, double alphaCfg, int useMask, int maskType, double avgFactor, int fwidth, int M, int Fout)
 {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   double2* avgOut = reinterpret_cast<double2*>(smem);             // [F] _avgOutput
   double2* outS = avgOut + F;                                     // [F] this frame's output (fwidth > 1 only)
-  int* maskS = reinterpret_cast<int*>(outS + F);                  // [F] target weaker than an interferer
+  double2* mirS = outS + F;                                       // [F] what bin M - f of a full output frame holds unless the mask strikes (fwidth > 1 only)
+  int* maskS = reinterpret_cast<int*>(mirS + F);                  // [F] target weaker than an interferer
   const int u = blockIdx.x, tid = threadIdx.x, nthr = blockDim.x;
   const int T = nframesArr[u] < Tmax ? nframesArr[u] : Tmax;
   const float2* Xu = X + (size_t) u * C * Tmax * F;
-  float2* Yu = Y + (size_t) u * Tmax * F;
+  float2* Yu = Y + (size_t) u * Tmax * Fout;
   for (int f = tid; f < F; f += nthr) avgOut[f] = make_double2(0.0, 0.0);
   __syncthreads();
-  const bool zel = (pfType & 0x01) || (pfType & 0x02);
+  const bool apab = (pfType & 0x04) != 0;                         // tested first (beamformer.cc:2047)
+  const bool zel = !apab && ((pfType & 0x01) || (pfType & 0x02));
+  const bool fullOut = Fout > F;                                  // APAB without halfBandShift: all M bins of a frame are written
+  const int M2 = M / 2;
   const bool wide = useMask && avgFactor >= 0.0 && fwidth > 1;
   const int NE = C * C;
   double2 taR[CT > 0 ? CT : 1];
 
 
   for (int t = 0; t < Tmax; t++) {
-    if (t >= T) { for (int f = tid; f < F; f += nthr) Yu[(size_t) t * F + f] = make_float2(0.f, 0.f); continue; }   // (uniform: T is per utterance)
+    if (t >= T) { for (int f = tid; f < Fout; f += nthr) Yu[(size_t) t * Fout + f] = make_float2(0.f, 0.f); continue; }   // (uniform: T is per utterance)
     const int frameX = t - 1;                                      // _frameX when next() runs (FrameResetX = -1)
     const double alpha = (frameX > 0) ? alphaCfg : 0.0;            // beamformer.cc:2042-2045
     const int type = (frameX < 0) ? 0 : pfType;                    // MINFRAMES 0 (:1136): the first frame only updates the densities
@@ -135,12 +141,36 @@ __global__ __launch_bounds__(256) void k_mmi(const float2* __restrict__ X, const
       double2* ta = CT > 0 ? taR : taScr + ((size_t) u * F + f) * C;
       double tr = 0.0, ti = 0.0;                                   // target output
       double tgtPow = 0.0, maxPow = 0.0;
-      auto dot = [&](const double2* w, double& yr, double& yi) {   // sum_c conj(w_c) x_c, products as gsl_complex_mul
+      auto dotAt = [&](const double2* w, const int fb, double& yr, double& yi) {   // sum_c conj(w_c) x_c at bin fb, products as gsl_complex_mul
         yr = 0.0; yi = 0.0;
         for (int c = 0; c < C; c++) {
-          const float2 x = Xu[((size_t) c * Tmax + t) * F + f]; const double wr = w[c].x, wi = -w[c].y;
+          const float2 x = Xu[((size_t) c * Tmax + t) * F + fb]; const double wr = w[c].x, wi = -w[c].y;
           yr += wr * (double) x.x - wi * (double) x.y; yi += wr * (double) x.y + wi * (double) x.x;
         }
+      };
+      auto dot = [&](const double2* w, double& yr, double& yi) { dotAt(w, f, yr, yi); };
+      // ApabFilter_f (postfilter.cc:225-264) for source s at bin fb, whose beamformed value there is (yr, yi): |y|^2 over the power of the
+      // time-aligned channel chanN/2, cut at 1
+      auto apabW = [&](const int s, const int fb, const double yr, const double yi) -> double {
+        const int ch = C / 2;
+        const double2 d = mani[((size_t) s * F + fb) * C + ch]; const float2 x = Xu[((size_t) ch * Tmax + t) * F + fb];
+        const double dr = d.x, di = -d.y;
+        const double pr = dr * (double) x.x - di * (double) x.y, pi = dr * (double) x.y + di * (double) x.x;
+        const double pxx = pr * pr + pi * pi, pyy = yr * yr + yi * yi;
+        double W = pyy / pxx;
+        if (W >= 1.0) W = 1.0;
+        if (W <= -1.0) W = -1.0;
+        return W;
+      };
+      // ApabFilter (postfilter.cc:275-340) on bin f of source s's vector (computed with the weights wsel [S][F][C]): bins below M/2 take their own
+      // weight; with halfBandShift bin f >= M/2 takes the weight of bin M-1-f (from that bin's snapshot, manifold and beamformed value); without it
+      // bins >= M/2 are left alone
+      auto apabApply = [&](const int s, const double2* wsel, double& yr, double& yi) {
+        double W;
+        if (f < M2) W = apabW(s, f, yr, yi);
+        else if (hbs) { const int fb = M - 1 - f; double br, bi; dotAt(wsel + ((size_t) s * F + fb) * C, fb, br, bi); W = apabW(s, fb, br, bi); }
+        else return;
+        const double a = W * yr - 0.0 * yi, b = W * yi + 0.0 * yr; yr = a; yi = b;
       };
       auto pfw = [&](int s) -> double {                            // ZelinskiFilter for source s at this bin: returns the weight (1 when unused)
         if (!zel) return 1.0;
@@ -176,8 +206,10 @@ __global__ __launch_bounds__(256) void k_mmi(const float2* __restrict__ X, const
         return W;                                                  // (type 0 = NO_USE_POST_FILTER: the densities are updated, the caller does not filter)
       };
       dot(weff + ((size_t) target * F + f) * C, tr, ti);
+      const double ur = tr, ui = ti;                               // before the post-filter: what the mirror bin of a full frame keeps
       const bool filt = zel && type != 0;
-      { const double W = pfw(target); if (filt) { const double a = W * tr - 0.0 * ti, b = W * ti + 0.0 * tr; tr = a; ti = b; } }   // polar(W, 0) * y
+      if (apab) apabApply(target, weff, tr, ti);
+      else { const double W = pfw(target); if (filt) { const double a = W * tr - 0.0 * ti, b = W * ti + 0.0 * tr; tr = a; ti = b; } }   // polar(W, 0) * y
       bool masked = false;
       const bool maskBin = useMask && (hbs || f >= 1);             // bin 0 is never masked (:2283), but calcInterferenceOutputs runs its post-filters too:
       if (useMask) {                                               // with mask type 1 that is the second update of the target's densities in this frame
@@ -185,22 +217,25 @@ __global__ __launch_bounds__(256) void k_mmi(const float2* __restrict__ X, const
           if (maskType == 0 && s == target) continue;
           double yr, yi;
           dot((maskType == 0 ? weff : wup) + ((size_t) s * F + f) * C, yr, yi);
-          { const double W = pfw(s); if (filt) { const double a = W * yr - 0.0 * yi, b = W * yi + 0.0 * yr; yr = a; yi = b; } }
+          if (apab) apabApply(s, maskType == 0 ? weff : wup, yr, yi);
+          else { const double W = pfw(s); if (filt) { const double a = W * yr - 0.0 * yi, b = W * yi + 0.0 * yr; yr = a; yi = b; } }
           const double p = yr * yr + yi * yi;
           if (s == target) tgtPow = p; else if (p > maxPow) maxPow = p;
         }
         if (maskType == 0) tgtPow = tr * tr + ti * ti;             // _interferenceOutputs[target] = the post-filtered output (:2064-2065)
         masked = maskBin && tgtPow < maxPow;
       }
-      if (!maskBin) { Yu[(size_t) t * F + f] = make_float2((float) tr, (float) ti); }
+      const bool mir = fullOut && f >= 1 && f < M2;                // bin M - f of a full frame: conj of the unfiltered value (:2026-2027) unless the mask strikes
+      if (!maskBin) { Yu[(size_t) t * Fout + f] = make_float2((float) tr, (float) ti); if (mir) Yu[(size_t) t * Fout + (M - f)] = make_float2((float) ur, (float) -ui); }
       else if (!wide) {
         // binaryMasking (:2241-2319) for one bin: the averaged output is this bin's own recursion
         double nr = 0.0, ni = 0.0;
         if (avgFactor >= 0.0) { nr = avgOut[f].x * avgFactor; ni = avgOut[f].y * avgFactor; }
         if (masked) { tr = nr; ti = ni; if (avgFactor >= 0.0) avgOut[f] = make_double2(nr, ni); }
         else if (avgFactor >= 0.0) avgOut[f] = make_double2(avgOut[f].x * avgFactor + tr * (1.0 - avgFactor), avgOut[f].y * avgFactor + ti * (1.0 - avgFactor));
-        Yu[(size_t) t * F + f] = make_float2((float) tr, (float) ti);
-      } else { outS[f] = make_double2(tr, ti); maskS[f] = masked ? 1 : 0; }
+        Yu[(size_t) t * Fout + f] = make_float2((float) tr, (float) ti);
+        if (mir) Yu[(size_t) t * Fout + (M - f)] = masked ? make_float2((float) tr, (float) ti) : make_float2((float) ur, (float) -ui);
+      } else { outS[f] = make_double2(tr, ti); maskS[f] = masked ? 1 : 0; mirS[f] = make_double2(ur, -ui); }
     }
     if (wide) {
       // the mean over neighbouring bins reads values this frame's loop has already replaced below the bin and last frame's above it
@@ -219,7 +254,10 @@ __global__ __launch_bounds__(256) void k_mmi(const float2* __restrict__ X, const
         }
       }
       __syncthreads();
-      for (int f = tid; f < F; f += nthr) if (hbs || f >= 1) Yu[(size_t) t * F + f] = make_float2((float) outS[f].x, (float) outS[f].y);
+      for (int f = tid; f < F; f += nthr) if (hbs || f >= 1) {
+        Yu[(size_t) t * Fout + f] = make_float2((float) outS[f].x, (float) outS[f].y);
+        if (fullOut && f < M2) { const double2 v = maskS[f] ? outS[f] : mirS[f]; Yu[(size_t) t * Fout + (M - f)] = make_float2((float) v.x, (float) v.y); }
+      }
     }
   }
 }
@@ -320,7 +358,6 @@ dsr_status dsr_mmi_create(int fftLen, int chanN, int halfBandShift, int targetSo
   return guard([&] {
     if (!out) throw Error(DSR_E_PARAMETER, "null argument");
     if (fftLen < 4 || (fftLen & 1) || chanN < 2 || nSource < 1 || targetSourceX < 0 || targetSourceX >= nSource) throw Error(DSR_E_PARAMETER, "SubbandMMI: fftLen %d, %d channels, source %d of %d", fftLen, chanN, targetSourceX, nSource);
-    if (pfType & 0x04) throw Error(DSR_E_PARAMETER, "SubbandMMI: the APAB post-filter is not supported (its output is not conjugate-symmetric)");
     auto* m = new dsr_mmi(); m->M = fftLen; m->C = chanN; m->hbs = halfBandShift ? 1 : 0; m->target = targetSourceX; m->S = nSource; m->pfType = pfType; m->alpha = alpha;
     *out = m;
   });
@@ -329,6 +366,7 @@ void dsr_mmi_destroy(dsr_mmi* m) { delete m; }
 int dsr_mmi_chan_n(const dsr_mmi* m) { return m ? m->C : 0; }
 int dsr_mmi_fft_len(const dsr_mmi* m) { return m ? m->M : 0; }
 int dsr_mmi_bins(const dsr_mmi* m) { return m ? (m->hbs ? m->M : m->M / 2 + 1) : 0; }
+int dsr_mmi_out_bins(const dsr_mmi* m) { return m ? ((m->hbs || (m->pfType & 0x04)) ? m->M : m->M / 2 + 1) : 0; }
 
 dsr_status dsr_mmi_use_binary_mask(dsr_mmi* m, double avgFactor, unsigned fwidth, unsigned type)
 {
@@ -445,18 +483,18 @@ dsr_status dsr_mmi_apply(dsr_mmi* m, const float* X, const int32_t* nframes_dev,
             const size_t k = ((size_t) s * F + f) * C + c; const zc wq = m->src[s].wq[(size_t) f * C + c], wl = m->src[s].wl[(size_t) f * C + c];
             const zc e = (!m->hbs && f == 0) ? wq : wq - wl;                            // bin 0: the quiescent vector alone (:2012-2016)
             weff[k] = make_double2(e.real(), e.imag()); wup[k] = make_double2(wq.real(), wq.imag());
-            const zc d = (m->pfType & 0x08) ? wq : m->src[s].ta[(size_t) f * C + c];     // TYPE_ZELINSKI2: the beamformer's own vector (:2052-2053)
+            const zc d = ((m->pfType & 0x08) && !(m->pfType & 0x04)) ? wq : m->src[s].ta[(size_t) f * C + c];     // TYPE_ZELINSKI2: the beamformer's own vector (:2052-2053); APAB: always the manifold
             mani[k] = make_double2(d.real(), d.imag());
           }
       m->d_weff.upload(weff); m->d_wup.upload(wup); m->d_mani.upload(mani); m->dirty = false;
     }
-    const bool zel = (m->pfType & 0x01) || (m->pfType & 0x02);
+    const bool zel = !(m->pfType & 0x04) && ((m->pfType & 0x01) || (m->pfType & 0x02));
     m->d_csd.reserve(zel ? (size_t) S * U * C * C * F : 1);
     if (C > 16) m->d_ta.reserve((size_t) U * F * C);
-    const size_t lds = (size_t) F * (2 * sizeof(double2) + sizeof(int));
+    const size_t lds = (size_t) F * (3 * sizeof(double2) + sizeof(int));
     if (lds > 150 * 1024) throw Error(DSR_E_DIMENSION, "SubbandMMI: %d bins need %zu bytes of LDS", F, lds);
 #define MMI_ARGS (const float2*) X, nframes_dev, m->d_weff.p, m->d_wup.p, m->d_mani.p, m->d_csd.p, m->d_ta.p, (float2*) Y, U, C, Tmax, F, S, m->target, m->hbs, \
-                 m->pfType, m->alpha, m->useMask ? 1 : 0, (int) m->maskType, m->avgFactor, (int) m->fwidth, M
+                 m->pfType, m->alpha, m->useMask ? 1 : 0, (int) m->maskType, m->avgFactor, (int) m->fwidth, M, dsr_mmi_out_bins(m)
     if (C <= 16) {
       DSR_HIP(hipFuncSetAttribute((const void*) k_mmi<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
       hipLaunchKernelGGL(k_mmi<16>, dim3(U), dim3(256), lds, st, MMI_ARGS);

@@ -218,11 +218,11 @@ struct MmiOp : BfOp {                // SubbandMMI as a stream (beamformer.cc:19
     if (C == 0 || C != dsr_mmi_chan_n(mm)) throw Error(DSR_E_DIMENSION, "Number of channels (%d) does not match the weights (%d)", C, dsr_mmi_chan_n(mm));
     int T = ups[0]->nFrames; for (int c = 1; c < C; c++) if (ups[c]->nFrames < T) T = ups[c]->nFrames;
     alloc(T); if (T <= 0) return;
-    const int F = dsr_mmi_bins(mm); X.reserve((size_t) C * T * F); Y.reserve((size_t) T * F);
+    const int F = dsr_mmi_bins(mm), Fo = dsr_mmi_out_bins(mm); X.reserve((size_t) C * T * F); Y.reserve((size_t) T * Fo);   // Fo = M: halfBandShift, or APAB's full frames
     for (int c = 0; c < C; c++) op_pack_bins(ups[c]->d<double2>(), T, F, M, X.p + (size_t) c * T * F, S0);
     nf.upload(&T, 1);
     dsr_status s = dsr_mmi_apply(mm, (const float*) X.p, nf.p, 1, T, (float*) Y.p, S0); if (s) throw Error(s, "%s", dsr_last_error());
-    op_expand_bins(Y.p, T, F, M, d<double2>(), S0);
+    op_expand_bins(Y.p, T, Fo, M, d<double2>(), S0);
   }
 };
 

@@ -499,6 +499,10 @@ class SubbandMMI:
     def bins(self):
         return _lib.dsr_mmi_bins(self.h)
 
+    def outBins(self):
+        """bins per output frame: bins(), or fftLen with the APAB post-filter (whose frames are not conjugate-symmetric)"""
+        return _lib.dsr_mmi_out_bins(self.h)
+
     def useBinaryMask(self, avgFactor=-1.0, fwidth=1, type=0):
         check(_lib.dsr_mmi_use_binary_mask(self.h, avgFactor, fwidth, type))
 
@@ -533,14 +537,14 @@ class SubbandMMI:
         return out
 
     def apply(self, X, nframes=None):
-        """X: cuda complex64 [U][C][T][bins] -> [U][T][bins]"""
+        """X: cuda complex64 [U][C][T][bins] -> [U][T][outBins]"""
         import torch
         U, Cn, T, F = X.shape
         if Cn != self.C or F != self.bins():
             raise DsrError(5, "snapshots must be [U][%d][T][%d]" % (self.C, self.bins()))
         if nframes is None:
             nframes = torch.full((U,), T, dtype=torch.int32, device=X.device)
-        out = torch.zeros((U, T, F), dtype=torch.complex64, device=X.device)
+        out = torch.zeros((U, T, self.outBins()), dtype=torch.complex64, device=X.device)
         check(_lib.dsr_mmi_apply(self.h, _dev(X.contiguous()), _dev(nframes), U, T, _dev(out), cur_stream()))
         return out
 

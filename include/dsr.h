@@ -513,14 +513,19 @@ dsr_status dsr_zelinski_reset_state(dsr_zelinski*);
  *                             resolves the scaling of the demixing matrix through its pseudo-inverse (:1821-1880)
  *   set_hi_active_weights_f = setHiActiveWeights_f(fbinX, pkdWa, pkdwb, option)    (:1891-1968)
  *   get: kind 0 wq [M][C], 1 wl [M][C], 2 B [M][C][C-NC], 3 array manifold [M][C], 4 wa [M][C-NC] of one source, complex128
- *   apply = next() for a batch: X_dev [U][chanN][Tmax][bins] complex64 snapshots -> Y_dev [U][Tmax][bins], bins = dsr_mmi_bins()
+ *   apply = next() for a batch: X_dev [U][chanN][Tmax][bins] complex64 snapshots -> Y_dev [U][Tmax][out_bins], bins = dsr_mmi_bins()
  *           (fftLen/2+1, or fftLen with halfBandShift); every utterance starts like a fresh object (frame counter, densities, average).
+ *   pfType bit 0x04 = TYPE_APAB (beamformer.cc:2047-2049,2177-2179; ApabFilter postfilter.cc:225-340, channelX = chanN/2; it takes precedence
+ *           over the Zelinski bits): the filter touches the bins below fftLen/2 only, so without halfBandShift the output frame is not
+ *           conjugate-symmetric and ALL fftLen bins are handed over: out_bins = dsr_mmi_out_bins() = fftLen then (bins above fftLen/2 as the
+ *           reference leaves them: conj of the unfiltered lower bin, or the mask's value); otherwise out_bins = bins.
  * Errors as the reference raises them: DSR_E_ERROR "call calcWeightsX() once" / wrong number of rows, DSR_E_DIMENSION for packed sizes and
- * bins.  The TYPE_APAB bit (0x04) is refused (DSR_E_PARAMETER): that filter leaves a spectrum that is not conjugate-symmetric. */
+ * bins. */
 typedef struct dsr_mmi dsr_mmi;
 dsr_status dsr_mmi_create(int fftLen, int chanN, int halfBandShift, int targetSourceX, int nSource, int pfType, double alpha, dsr_mmi** out);
 void       dsr_mmi_destroy(dsr_mmi*);
 int        dsr_mmi_bins(const dsr_mmi*);
+int        dsr_mmi_out_bins(const dsr_mmi*);
 int        dsr_mmi_chan_n(const dsr_mmi*);
 int        dsr_mmi_fft_len(const dsr_mmi*);
 dsr_status dsr_mmi_use_binary_mask(dsr_mmi*, double avgFactor, unsigned fwidth, unsigned type);

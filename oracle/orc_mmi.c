@@ -7,9 +7,9 @@
  *   calcOutputOfGSC            :1251-1287                  ZelinskiFilter(_f)        btk/postfilter/postfilter.cc:59-221
  * Quirks of the shipped code are kept and marked "as shipped".  Complex arithmetic follows GSL's formulas (gsl_complex_mul / _div /
  * _abs); the BLAS level-1/2/3 calls are plain sums in index order (which BLAS the reference links against is not fixed, so parity with
- * the product is asserted to 1e-9 relative, not bitwise).  The TYPE_APAB post-filter branch (:2047-2049) is not restated: its output
- * vector is not conjugate-symmetric (postfilter.cc:317-336 filters bins < fftLen/2 only), which the half-spectrum product cannot hold; both
- * sides refuse it.
+ * the product is asserted to 1e-9 relative, not bitwise).  The TYPE_APAB post-filter branch (:2047-2049, 2177-2179) is ApabFilter /
+ * ApabFilter_f of postfilter.cc:225-340 with channelX = chanN/2: it filters bins < fftLen/2 only, so its output vector is not
+ * conjugate-symmetric without halfBandShift (the product hands over all fftLen bins in that configuration).
  */
 #include "orc.h"
 #include <math.h>
@@ -377,11 +377,45 @@ static void zelinski_filter(orc_mmi* m, const zc* manifold /*[M][C]*/, const zc*
   }
 }
 
+/* ApabFilter_f (postfilter.cc:225-264), channelX >= 0 branch */
+static double apab_f(const zc* propagation, const zc* snapShot, int nChan, zc y, int channelX)
+{
+  (void) nChan;
+  const double phi_yy = gabs2(y);
+  const zc dsf = conj(propagation[channelX]);
+  const zc xsf = snapShot[channelX];
+  const zc ysf = gmul(dsf, xsf);
+  const double phi_xx = gabs2(ysf);
+  double Wf = phi_yy / phi_xx;
+  if (Wf >= 1.0) Wf = 1.0;
+  if (Wf <= -1.0) Wf = -1.0;
+  return Wf;
+}
+
+/* ApabFilter (postfilter.cc:275-340) */
+static void apab_filter(orc_mmi* m, const zc* manifold /*[M][C]*/, const zc* X, int Fin, zc* sig, int channelX)
+{
+  const int M = m->M, C = m->C, M2 = M / 2;
+  zc x[C]; zc windowV[M];
+  if (channelX < 0) channelX = C / 2;
+  for (int f = 0; f < M; f++) windowV[f] = 0.0;
+  for (int f = 0; f < M2; f++) {
+    for (int c = 0; c < C; c++) x[c] = X[(size_t) c * Fin + f];
+    const double r = apab_f(&manifold[(size_t) f * C], x, C, sig[f], channelX);
+    const zc wf = gpolar(r, 0);
+    windowV[f] = wf;
+    if (m->hbs) windowV[M - 1 - f] = conj(wf);
+  }
+  const int length = m->hbs ? M : M2;
+  for (int f = 0; f < length; f++) sig[f] = gmul(windowV[f], sig[f]);
+}
+
 static void post_filter(orc_mmi* m, int srcX, const zc* X, int Fin, zc* sig)
 {
   /* :2036-2060 and :2163-2190 */
   const double alpha = (m->frameX > 0) ? m->alpha : 0.0;
-  if (0x01 & m->pfType || 0x02 & m->pfType) {
+  if (0x04 & m->pfType) apab_filter(m, m->src[srcX].ta, X, Fin, sig, m->C / 2);
+  else if (0x01 & m->pfType || 0x02 & m->pfType) {
     const zc* wq = (0x08 & m->pfType) ? m->src[srcX].wq : m->src[srcX].ta;
     if (m->frameX < 0) zelinski_filter(m, wq, X, Fin, sig, m->src[srcX].csd, alpha, 0);        /* MINFRAMES 0 (:1136) */
     else zelinski_filter(m, wq, X, Fin, sig, m->src[srcX].csd, alpha, m->pfType);
@@ -461,7 +495,6 @@ int orc_mmi_next(orc_mmi* m, const double* Xd, int Fin, double* out)
 {
   /* :1973-2072; Xd: [C][Fin] complex, Fin = M (halfBandShift) or >= M/2+1; out: [M] complex */
   if (!m->haveW) return -1;
-  if ((0x04 & m->pfType)) return -3;                                         /* TYPE_APAB: see the header */
   const int M = m->M, C = m->C, M2 = M / 2;
   const zc* X = (const zc*) Xd;
   const src_t* w = &m->src[m->target];

@@ -46,6 +46,13 @@ CASES = [
     (32, 4, False, 0, 2, 0x00, 0.7, 1, (-1.0, 1, 1)),
     (16, 4, True, 0, 2, 0x02, 0.7, 1, (0.6, 3, 0)),              # halfBandShift: all fftLen bins on their own
     (32, 20, False, 0, 2, 0x02, 0.7, 1, (0.6, 1, 0)),            # more than 16 channels (time-aligned channels in scratch memory)
+    (32, 4, False, 0, 2, 0x04, 0.7, 1, None),                    # TYPE_APAB: bins below fftLen/2 filtered, all fftLen bins handed over
+    (32, 5, False, 1, 2, 0x06, 0.7, 2, (-1.0, 1, 0)),            # APAB wins over the Zelinski bit; mask to zero: the mirror bins take the mask's value
+    (32, 4, False, 0, 3, 0x04, 0.7, 1, (0.6, 1, 1)),             # APAB on every source's upper branch, averaged output
+    (32, 4, False, 0, 2, 0x04, 0.7, 1, (0.6, 3, 0)),             # APAB + mean over neighbouring bins
+    (16, 4, True, 0, 2, 0x04, 0.7, 1, None),                     # APAB with halfBandShift: weights mirrored onto fftLen-1-k
+    (16, 4, True, 1, 2, 0x04, 0.7, 1, (0.6, 1, 0)),
+    (32, 20, False, 0, 2, 0x04, 0.7, 1, (0.6, 1, 0)),
 ]
 
 
@@ -56,17 +63,20 @@ def test_subband_mmi_apply(case):
     seed = 100 + M + Cn + pfType
     a = _make("dsr", M, Cn, hbs, target, nSource, pfType, alpha, NC, seed, mask)
     F = M if hbs else M // 2 + 1
-    assert a.bins() == F
+    Fo = M if (hbs or (pfType & 0x04)) else F                                  # APAB: frames are not conjugate-symmetric, all bins come back
+    assert a.bins() == F and a.outBins() == Fo
     U, T = 3, 24
     nfr = np.array([T, T - 7, 1], np.int32)
     rng = np.random.default_rng(seed + 1)
     X = (rng.standard_normal((U, Cn, T, F)) + 1j * rng.standard_normal((U, Cn, T, F))).astype(np.complex64)
     X *= (0.2 + rng.random((U, 1, T, F)) * 2.0).astype(np.float32)
+    if pfType & 0x04:                                                          # APAB: the reference channel loud in half of the points, so that weights below 1 occur
+        X[:, Cn // 2] *= np.where(rng.random((U, T, F)) < 0.5, 8.0, 1.0).astype(np.float32)
     dev = torch.device("cuda:0")
     Y = a.apply(torch.from_numpy(X).to(dev), torch.from_numpy(nfr).to(dev)).cpu().numpy()
     for u in range(U):
         b = _make("orc", M, Cn, hbs, target, nSource, pfType, alpha, NC, seed, mask)      # every utterance of a batch: a fresh object
-        ref = b.run(X[u, :, :nfr[u], :].astype(np.complex128))[:, :F]
+        ref = b.run(X[u, :, :nfr[u], :].astype(np.complex128))[:, :Fo]
         got = Y[u, :nfr[u]]
         scale = np.maximum(1e-30, np.abs(ref).max(axis=1, keepdims=True))
         assert (np.abs(got - ref) / scale).max() <= TOL, (u, (np.abs(got - ref) / scale).max())

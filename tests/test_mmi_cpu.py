@@ -74,8 +74,39 @@ def test_mmi_errors():
     with pytest.raises(K.DsrError) as e:
         m.calcWeightsN(16000.0, np.zeros((2, 4)), 1)
     assert e.value.status == 5                                                   # calcMainlobeN: 1 < NC <= chanN (:633-635)
-    with pytest.raises(K.DsrError):
-        K.SubbandMMI(16, 4, False, 0, 2, 0x04, 0.9)                              # APAB: refused, see csrc/k_mmi.hip
+    a = K.SubbandMMI(16, 4, False, 0, 2, 0x04, 0.9)                              # APAB: frames are not conjugate-symmetric -> all fftLen bins go out
+    assert a.bins() == 9 and a.outBins() == 16
+    assert K.SubbandMMI(16, 4, False, 0, 2, 0x02, 0.9).outBins() == 9 and K.SubbandMMI(16, 4, True, 0, 2, 0x04, 0.9).outBins() == 16
+
+
+@pytest.mark.parametrize("hbs", [False, True])
+def test_apab_oracle_against_numpy(hbs):
+    """TYPE_APAB (postfilter.cc:225-340 as SubbandMMI calls it, channelX = chanN/2): weight = |y|^2 / |conj(d_ch) x_ch|^2 cut at 1 on the bins below
+    fftLen/2 (mirrored onto fftLen-1-k with halfBandShift), nothing else touched -- the restatement against the formula on the unfiltered output."""
+    M, Cn, T = 16, 5, 6
+    rng = np.random.default_rng(41)
+    d = rng.uniform(0.0, 4e-4, (2, Cn))
+    def make(pf):
+        m = O.SubbandMMI(M, hbs, 1, 2, pf, 0.7, chanN=Cn); m.calcWeights(16000.0, d)
+        r = np.random.default_rng(42)
+        for f in range(M):
+            m.setActiveWeights_f(f, 0.3 * r.standard_normal((2, 2 * (Cn - 1))), 0)
+        return m
+    Fin = M if hbs else M // 2 + 1
+    X = rng.standard_normal((Cn, T, Fin)) + 1j * rng.standard_normal((Cn, T, Fin))
+    X[Cn // 2] *= np.where(rng.random((T, Fin)) < 0.5, 8.0, 1.0)                 # the reference channel loud in half of the points: weights below 1 there, cut at 1 elsewhere
+    y0 = make(0x00).run(X); m = make(0x06); y = m.run(X)                        # 0x06: the APAB bit wins over the Zelinski bit (beamformer.cc:2047-2050)
+    ta = m.get(1, "ta")
+    ch = Cn // 2; M2 = M // 2
+    W = np.abs(y0[:, :M2]) ** 2 / np.abs(np.conj(ta[None, :M2, ch]) * X[ch, :, :M2]) ** 2
+    assert (W < 1).any() and (W > 1).any()
+    W = np.minimum(W, 1.0)
+    exp = y0.copy(); exp[:, :M2] = W * y0[:, :M2]
+    if hbs:
+        exp[:, M - 1 - np.arange(M2)] = W * y0[:, M - 1 - np.arange(M2)]
+    assert np.abs(y - exp).max() <= 1e-12 * np.abs(exp).max()
+    if not hbs:
+        assert np.array_equal(y[:, M2 + 1:], np.conj(y0[:, 1:M2][:, ::-1]))     # the mirror bins keep the unfiltered values
 
 
 def test_pseudoinverse_wide_matrix():
