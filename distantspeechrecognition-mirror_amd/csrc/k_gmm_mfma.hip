@@ -180,6 +180,10 @@ __global__ __launch_bounds__(256) void k_gmm_mfma(const float* __restrict__ x, l
 // around every call: measured 24 ms of 33).  The lane appends (frame, codebook, the two candidates) to a list in memory and moves on;
 // k_gmm_ties settles the list afterwards in the reference's own arithmetic, one thread per entry, and overwrites score and argmin.  A list that
 // is full sends the lane through the exact computation on the spot (cold code, never reached at the list size the launcher picks).
+// DSR_GMM_DBG (measurement only): bit 0 contraction alone, bit 1 no tie test, bit 2 no score stores, bit 3 no codebook close.  1 M frames x 1024 x 4:
+// 9.2 ms whole, 5.3 contraction alone, 7.9 without the tie test, 8.0 without the stores, 6.7 without both, 6.1 without close and stores.  Tried on top and
+// dropped (tools/ab_gmm.sh): near ties staged in LDS (+-0: the cost of the tie branch is its divergence, not its store), the strip flushed at the top of the
+// next chunk behind a pinned operand prefetch with 16-byte stores (+8 %).
 // Scores wait in an LDS strip [frame][64 codebooks] (pitch 65: conflict free) and leave as 128-byte runs.  One wave owns two 32-frame tiles (B
 // fragments in registers); the Gaussian operand is read from LDS four contraction steps at a time (one ds_read_b128 per four MFMA pairs).
 __device__ __forceinline__ float exact_dist_inl(const float* __restrict__ xr, const float* __restrict__ mu, const float* __restrict__ iv, float cst, int D)
@@ -333,9 +337,10 @@ __global__ __launch_bounds__(256) void k_gmm_mfma_reg(const float* __restrict__ 
   for (int q = 0; q < S4; q++) acur[q] = Ap4[q * 64];
   for (int ch = 0; ch < nChunks; ch++) {
     float4 anext[S4];
-    if (ch + 1 < nChunks) {
+    {                                                            // unconditional (the last chunk re-reads itself): with the loads under a branch the
+      const int cn = (ch + 1 < nChunks) ? ch + 1 : ch;           // compiler waits for them at the merge point, before the first MFMA (-3 %)
 #pragma unroll
-      for (int q = 0; q < S4; q++) anext[q] = Ap4[((size_t) (ch + 1) * S4 + q) * 64];
+      for (int q = 0; q < S4; q++) anext[q] = Ap4[((size_t) cn * S4 + q) * 64];
     }
     f32x16 acc[2];
 #pragma unroll

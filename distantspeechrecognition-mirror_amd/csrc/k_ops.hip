@@ -148,6 +148,18 @@ __global__ void k_op_pack_bins(const double2* in, int T, int F, int M, float2* o
   const long idx = (long) blockIdx.x * blockDim.x + threadIdx.x; if (idx >= (long) T * F) return;
   const int t = (int) (idx / F), f = (int) (idx - (long) t * F); const double2 v = in[(long) t * M + f]; out[idx] = make_float2((float) v.x, (float) v.y);
 }
+// complex128 [T][M] -> complex64 [T][M/2+1] for the synthesis bank, which keeps the real part of the transform of ALL M bins (modulated.cc:598-610):
+// that is the transform of the frame's Hermitian part (in[k] + conj(in[M-k])) / 2.  For a conjugate-symmetric frame (every analysis bank, every
+// beamformer but SubbandMMI with the APAB post-filter) the sum is exact and the value is in[k] itself.
+__global__ void k_op_pack_hermitian(const double2* in, int T, int M, float2* out)
+{
+  const int F = M / 2 + 1;
+  const long idx = (long) blockIdx.x * blockDim.x + threadIdx.x; if (idx >= (long) T * F) return;
+  const int t = (int) (idx / F), f = (int) (idx - (long) t * F); const double2 a = in[(long) t * M + f];
+  if (f == 0 || 2 * f == M) { out[idx] = make_float2((float) a.x, (float) a.y); return; }
+  const double2 b = in[(long) t * M + (M - f)];
+  out[idx] = make_float2((float) ((a.x + b.x) * 0.5), (float) ((a.y - b.y) * 0.5));
+}
 
 #define GRID(n) dim3((unsigned) (((n) + 255) / 256)), dim3(256), 0, st
 // Lattice::_updateAcNode (asr/lattice/lattice.cc:392-409): a link's acoustic score = the sum over its frames of its distribution's score, a double
@@ -187,6 +199,7 @@ void op_highpass(const double2* in, int T, int M, int cutBin, double2* out, hipS
 void op_orth_assemble(const float2* low, const double2* full, int T, int F, int M, double2* out, hipStream_t st) { if (T > 0) hipLaunchKernelGGL(k_op_orth_assemble, GRID((long) T * M), low, full, T, F, M, out); }
 void op_link_ac(const float* scores, int K, const int* dist, const int* start, const int* end, int n, double* out, hipStream_t st)
 { if (n > 0) hipLaunchKernelGGL(k_op_link_ac, GRID((long) n), scores, K, dist, start, end, n, out); }
+void op_pack_hermitian(const double2* in, int T, int M, float2* out, hipStream_t st) { if (T > 0) hipLaunchKernelGGL(k_op_pack_hermitian, GRID((long) T * (M / 2 + 1)), in, T, M, out); }
 void op_pack_bins(const double2* in, int T, int F, int M, float2* out, hipStream_t st) { if (T > 0) hipLaunchKernelGGL(k_op_pack_bins, GRID((long) T * F), in, T, F, M, out); }
 #undef GRID
 

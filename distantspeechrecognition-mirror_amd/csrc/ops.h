@@ -15,6 +15,7 @@ void op_sgemv(const float* in, int T, int cols, int rows, const float* A, float*
 void op_adjacent(const float* in, int T, int N, int delta, float* out, hipStream_t st);
 void op_expand_bins(const float2* in, int T, int F, int M, double2* out, hipStream_t st);
 void op_pack_bins(const double2* in, int T, int F, int M, float2* out, hipStream_t st);
+void op_pack_hermitian(const double2* in, int T, int M, float2* out, hipStream_t st);
 void op_highpass(const double2* in, int T, int M, int cutBin, double2* out, hipStream_t st);
 void op_orth_assemble(const float2* low, const double2* full, int T, int F, int M, double2* out, hipStream_t st);
 void op_link_ac(const float* scores, int K, const int* dist, const int* start, const int* end, int n, double* out, hipStream_t st);

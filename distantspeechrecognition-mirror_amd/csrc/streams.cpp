@@ -169,7 +169,7 @@ struct SynthesisOp : dsr_stream {    // OverSampledDFTSynthesisBank
   void compute() override {
     dsr_stream* u = ups[0]; const int Tin = u->nFrames; const int nb = dsr_fb_synthesis_blocks(fb, Tin); alloc(nb);
     if (nb <= 0) return;
-    Y.reserve((size_t) Tin * (M / 2 + 1)); op_pack_bins(u->d<double2>(), Tin, M / 2 + 1, M, Y.p, S0);
+    Y.reserve((size_t) Tin * (M / 2 + 1)); op_pack_hermitian(u->d<double2>(), Tin, M, Y.p, S0);      // frames need not be conjugate-symmetric (SubbandMMI + APAB)
     nf.upload(&Tin, 1);
     dsr_status s = dsr_fb_synthesis(fb, (const float*) Y.p, nf.p, 1, Tin, (int64_t) nb * D, d<float>(), S0); if (s) throw Error(s, "%s", dsr_last_error());
   }

@@ -115,6 +115,27 @@ def test_filterbank_roundtrip_like_testNyquistFilterBankDesign(dsr, oracle, cuda
     assert e.value.status == 5                                   # jdimension_error "Input block length != _D"
 
 
+def test_synthesis_of_frames_that_are_not_conjugate_symmetric(dsr, oracle, cuda, protos):
+    """OverSampledDFTSynthesisBank transforms all M bins of a frame and keeps the real part (modulated.cc:598-610): SubbandMMI with the APAB post-filter
+    hands over frames that are not conjugate-symmetric, and the operator has to synthesise their Hermitian part, not their lower half."""
+    from dsr.btk.modulated import OverSampledDFTSynthesisBankPtr
+    from dsr.btk.stream import PyVectorComplexFeatureStreamPtr
+    M, m, r, h, g = protos["M256-m4-r1"]
+    T = 40
+    rng = np.random.default_rng(77)
+    rows = rng.standard_normal((T, M)) + 1j * rng.standard_normal((T, M))
+
+    class Frames:
+        def size(self): return M
+        def reset(self): pass
+        def __iter__(self): return iter(rows)
+    out = np.concatenate([np.array(b) for b in OverSampledDFTSynthesisBankPtr(PyVectorComplexFeatureStreamPtr(Frames()), prototype=g, M=M, m=m, r=r)])
+    ref = oracle.synthesis_bank(rows, g, M, m, r, 0)
+    lower = rows.copy(); lower[:, M // 2 + 1:] = np.conj(rows[:, 1:M // 2][:, ::-1])
+    assert np.abs(oracle.synthesis_bank(lower, g, M, m, r, 0) - ref).max() > 0.1 * np.abs(ref).max()      # the two readings differ by far
+    assert out.shape == ref.shape and np.abs(out - ref).max() / np.sqrt(np.mean(ref ** 2)) < 5e-5
+
+
 def test_mvdr_driver_like_superdirectiveBeamformer(dsr, oracle, cuda, protos):
     from dsr.btk.feature import SampleFeaturePtr
     from dsr.btk.modulated import OverSampledDFTAnalysisBankPtr, OverSampledDFTSynthesisBankPtr
