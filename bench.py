@@ -186,6 +186,8 @@ def main():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--overlap", action="store_true", help="two pipes on two streams: the ragged end of a step's decode runs under the next step's front end "
                     "(+2 %% throughput; the per-kernel event intervals then include waiting for CUs, so the default keeps steps strictly one after the other)")
+    ap.add_argument("--no-fuse", action="store_true", help="analysis bank and beamformer as two kernels with the channel snapshots in HBM between them "
+                    "(default: one kernel, dsr_fb_analysis_beamform)")
     ap.add_argument("--serial", action="store_true", help="(default) one pipe, steps strictly one after the other")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend of the multi-rank run: nccl (= RCCL, the default) or gloo -- gloo with "
                     "DSR_BENCH_DEVICE=0 rehearses the multi-rank control flow with several ranks on ONE GPU (collectives on host tensors)")
@@ -246,7 +248,7 @@ def main():
     for i in range(npipes):
         dec = dsr.Decoder(beam=beam, lmScale=12.0, maxActive=65536); dec.set(mdl["gd"])
         mf_i = mdl["mf"] if i == 0 else dsr.Mfcc(lda=mdl["lda"])          # the MFCC plan owns scratch memory: one per pipe
-        pipes.append(dsr.Pipe(mdl["ana"], mdl["syn"], mdl["bf"], mf_i, mdl["gm"], dec, gmmMode=args.gmm_mode))
+        pipes.append(dsr.Pipe(mdl["ana"], mdl["syn"], mdl["bf"], mf_i, mdl["gm"], dec, gmmMode=args.gmm_mode, fused=not args.no_fuse))
         streams.append(torch.cuda.Stream(device=dev))
     inflight = [False] * npipes
 
@@ -318,9 +320,12 @@ def main():
         names = ["analysis", "beamform", "synthesis", "mfcc", "gmm", "viterbi"]
         T_ana = mdl["ana"].frames(nsamp)
         # algorithmic bytes / flops per launch (DESIGN.md "Measurement")
+        fusedFE = (not args.no_fuse) and mdl["ana"].analysis_beamform_supported(mdl["bf"])
         alg = {
-            "analysis": ("hbm", U * Cn * T_ana * 1544.0),                       # 512 B in + 1032 B out per channel-frame
-            "beamform": ("hbm", U * T_ana * (Cn + 1) * 129 * 8.0),
+            # 512 B in + 1032 B out per channel-frame.  Fused with the beamformer the snapshots stay on the chip: the bytes that
+            # still have to move are the samples in (tiles re-read the 7 blocks of history they share: x 23/16) and one beamformed row out per frame
+            "analysis": ("hbm", U * T_ana * (Cn * 512.0 * 23 / 16 + 1032.0)) if fusedFE else ("hbm", U * Cn * T_ana * 1544.0),
+            "beamform": ("hbm", 0.0) if fusedFE else ("hbm", U * T_ana * (Cn + 1) * 129 * 8.0),
             "synthesis": ("lds", U * T_ana * (129 * 8.0 + 128 * 4.0)),          # bytes quoted for reference: bound by the LDS traffic of its FFT + overlap-add
             "mfcc": ("fp64", U * Tm * (160 * 4.0 + 39 * 4.0)),                  # bytes quoted for reference: bound by its fp64 FFT through LDS (feature.cc is double)
             "gmm": ("mfma" if args.gmm_mode == 2 else "valu", U * Tm * 4.0 * 39 * 4096),
@@ -390,6 +395,8 @@ def main():
                                 xRT=audio_s / (dt / args.steps), beam=beam,
                                 mean_active_tokens=active / max(1, frames), failed_utts=bad, gmm_mode=args.gmm_mode,
                                 parallelism="utterance-sharded x%d, RCCL gather of 1-best" % world,
+                                front_end="analysis bank + MVDR in one kernel (channel snapshots never written; stage 'analysis' covers both, bytes = samples in x 23/16 + beamformed rows out)" if fusedFE
+                                else "analysis bank and beamformer as two kernels",
                                 step_overlap="two pipes on two streams (decode tail of a step under the next step's front end)" if npipes > 1 else "none"),
                     roofline=roof, stages=stages, cpu_baseline=cpu)
         print(json.dumps(line))

@@ -30,7 +30,7 @@ struct dsr_pipe {
   std::vector<int> h_T, h_ny, h_Tm;
   hipEvent_t ev[7]; bool evInit = false; float ms[6] = {0, 0, 0, 0, 0, 0};
   int64_t bytes[5] = {0, 0, 0, 0, 0};
-  bool pending = false;
+  bool pending = false, fused = false, ranFused = false;
 };
 
 extern "C" {
@@ -98,7 +98,8 @@ dsr_status dsr_pipe_submit(dsr_pipe* p, const float* x, const int32_t* nsamp_dev
     if (dsr_bf_chan_n(p->bf) != C) throw Error(DSR_E_DIMENSION, "beamformer has %d channels, input has %d", dsr_bf_chan_n(p->bf), C);
     const int nDist = dsr_gmm_num_dists(p->gmm), dim = dsr_gmm_dim(p->gmm);
     const size_t F = (size_t) dsr_bf_fft_len(p->bf) / 2 + 1;
-    p->X.reserve((size_t) U * C * Tmax * F * 2); p->Y.reserve((size_t) U * Tmax * F * 2); p->y.reserve((size_t) U * nyMax);
+    if (!(p->fused && dsr_fb_analysis_beamform_supported(p->ana, p->bf))) p->X.reserve((size_t) U * C * Tmax * F * 2);
+    p->Y.reserve((size_t) U * Tmax * F * 2); p->y.reserve((size_t) U * nyMax);
     p->feat.reserve((size_t) U * TmMax * dim); p->scores.reserve((size_t) U * TmMax * nDist);
     p->bytes[0] = (int64_t) U * C * Tmax * F * 8; p->bytes[1] = (int64_t) U * Tmax * F * 8; p->bytes[2] = (int64_t) U * nyMax * 4;
     p->bytes[3] = (int64_t) U * TmMax * dim * 4; p->bytes[4] = (int64_t) U * TmMax * nDist * 4;
@@ -108,9 +109,15 @@ dsr_status dsr_pipe_submit(dsr_pipe* p, const float* x, const int32_t* nsamp_dev
     DSR_HIP(hipMemcpyAsync(p->d_Tm.p, p->h_Tm.data(), sizeof(int) * U, hipMemcpyHostToDevice, st));
 
     DSR_HIP(hipEventRecord(p->ev[0], st));
-    check(dsr_fb_analysis(p->ana, x, nsamp_dev, U, C, sampStride, Tmax, p->X.p, st));
-    DSR_HIP(hipEventRecord(p->ev[1], st));
-    check(dsr_bf_apply_frames(p->bf, p->X.p, p->d_T.p, U, Tmax, p->Y.p, st));     // an adapting beamformer stops at each utterance's last frame
+    p->ranFused = p->fused && dsr_fb_analysis_beamform_supported(p->ana, p->bf);
+    if (p->ranFused) {
+      check(dsr_fb_analysis_beamform(p->ana, p->bf, x, nsamp_dev, U, C, sampStride, Tmax, p->Y.p, st));   // the snapshots X stay on the chip
+      DSR_HIP(hipEventRecord(p->ev[1], st));
+    } else {
+      check(dsr_fb_analysis(p->ana, x, nsamp_dev, U, C, sampStride, Tmax, p->X.p, st));
+      DSR_HIP(hipEventRecord(p->ev[1], st));
+      check(dsr_bf_apply_frames(p->bf, p->X.p, p->d_T.p, U, Tmax, p->Y.p, st));     // an adapting beamformer stops at each utterance's last frame
+    }
     DSR_HIP(hipEventRecord(p->ev[2], st));
     check(dsr_fb_synthesis(p->syn, p->Y.p, p->d_T.p, U, Tmax, nyMax, p->y.p, st));
     DSR_HIP(hipEventRecord(p->ev[3], st));
@@ -146,6 +153,9 @@ dsr_status dsr_pipe_run(dsr_pipe* p, const float* x, const int32_t* nsamp_dev, c
   return dsr_pipe_collect(p, res, arcs_out, words_out);
 }
 
+dsr_status dsr_pipe_set_fused(dsr_pipe* p, int fused)
+{ return guard([&] { if (!p) throw Error(DSR_E_PARAMETER, "null argument"); if (p->pending) throw Error(DSR_E_CONSISTENCY, "a batch is in flight"); p->fused = fused != 0; }); }
+
 dsr_status dsr_pipe_stage_ms(const dsr_pipe* p, float ms[6])
 { return guard([&] { if (!p || !ms) throw Error(DSR_E_PARAMETER, "null argument"); for (int i = 0; i < 6; i++) ms[i] = p->ms[i]; }); }
 
@@ -153,6 +163,7 @@ dsr_status dsr_pipe_intermediate(const dsr_pipe* p, int which, void** dev, int64
 {
   return guard([&] {
     if (!p || !dev) throw Error(DSR_E_PARAMETER, "null argument");
+    if (which == 0 && p->ranFused) throw Error(DSR_E_CONSISTENCY, "the last run was fused: the channel snapshots were not written");
     void* q = which == 0 ? (void*) p->X.p : which == 1 ? (void*) p->Y.p : which == 2 ? (void*) p->y.p : which == 3 ? (void*) p->feat.p : which == 4 ? (void*) p->scores.p : nullptr;
     if (!q) throw Error(DSR_E_PARAMETER, "bad intermediate index %d", which);
     *dev = q; if (bytes) *bytes = p->bytes[which];

@@ -330,6 +330,7 @@ void dsr_bf_destroy(dsr_bf* s) { delete s; }
 int dsr_bf_fft_len(const dsr_bf* s) { return s->M; }
 int dsr_bf_chan_n(const dsr_bf* s) { return s->C; }
 int dsr_bf_half_band_shift(const dsr_bf* s) { return s->halfBandShift ? 1 : 0; }
+int dsr_bf_is_adaptive(const dsr_bf* s) { return (s && s->rlsOn) ? 1 : 0; }
 int dsr_bf_bins(const dsr_bf* s) { return s->halfBandShift ? s->M : s->M / 2 + 1; }
 
 dsr_status dsr_bf_calc_array_manifold(dsr_bf* s, double fs, const double* delays)
@@ -479,6 +480,10 @@ dsr_status dsr_bf_get(const dsr_bf* cs, int kind, double* out, size_t nd)
     for (size_t i = 0; i < v->size(); i++) { out[2 * i] = (*v)[i].real(); out[2 * i + 1] = (*v)[i].imag(); }
   });
 }
+
+// the weights k_bf_apply would use, [M/2+1][C] on the device, for the fused analysis + beamformer kernel (k_filterbank.hip); null when the output is
+// not a fixed linear combination of the channels (SubbandGSCRLS adapting) or when all M bins are computed (halfBandShift)
+namespace dsr { const float2* bf_fixed_weights_dev(dsr_bf* s) { if (!s || s->rlsOn || s->halfBandShift) return nullptr; if (s->dirty) refresh_effective(*s); return s->d_w.p; } }
 
 dsr_status dsr_bf_apply(dsr_bf* s, const float* X, int U, int Tmax, float* Y, void* stream)
 {

@@ -596,6 +596,159 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// The same bank with the fixed-weight subband beamformer applied on the way out (SubbandDS / SubbandMVDR / SubbandGSC::next with weights that do
+// not change from frame to frame: Y[t][f] = sum_c conj(w[f][c]) X_c[t][f], beamformer.cc:1137-1200,1297-1363,2583-2635): the channel snapshots
+// X_c -- 2 x 10.4 GB of HBM traffic at 1000 utterances x 8 channels, written by one kernel and read back by the next -- never leave the chip.
+// A workgroup owns 16 frames of one utterance (4 waves x 4 frames, the shape of k_analysis_q256) and walks the channels: a channel's window (the
+// 16 frames' 2944 samples; consecutive tiles re-read the 896 they share) comes in through registers while the channel before is transformed,
+// passes and even/odd split are those of k_analysis_q256 operation for operation, and what that kernel stores as row t of channel c is weighted
+// and added, channel after channel in the order of k_bf_apply's loop, to accumulators of the lane's two bins (bin N: every lane, redundantly).
+// The weights come transposed, WT[c][N + 2] (k_transpose_w below), straight from memory: a 16-byte load per lane and channel, issued a whole transform
+// ahead of its use (in LDS they cost the fourth workgroup per CU).
+// LDS: [tw: M float2][win][hT][strip: waves x 576 float2]
+__global__ void k_transpose_w(const float2* __restrict__ W, float2* __restrict__ WT, int C, int F)
+{
+  const int i = blockIdx.x * blockDim.x + threadIdx.x; if (i >= C * (F + 1)) return;
+  const int c = i / (F + 1), f = i - c * (F + 1);
+  WT[i] = (f < F) ? W[f * C + c] : make_float2(0.f, 0.f);
+}
+template <int MT>
+__global__ __launch_bounds__(256) void k_analysis_bf_q256(const float* __restrict__ x, const int* __restrict__ nsampArr,
+                                                          const float* __restrict__ proto, const float2* __restrict__ twG, const float2* __restrict__ WT,
+                                                          float2* __restrict__ Y, int C, long sampStride, int Tmax, int pd, int laN, int gain)
+{
+  constexpr int M = 256, N = 128, D = 128, TF = 16;
+  constexpr int SQ = 146, SK = 18, SZ = 4 * SQ;
+  constexpr int BR[8] = {0, 4, 2, 6, 1, 5, 3, 7};
+  constexpr int winLen = (TF - 1) * D + MT * M;                // logical samples of a tile's window
+  constexpr int winPhys = winLen + 32 * ((winLen + 127) >> 7);
+  constexpr int NL = (winLen / 4 + 255) / 256;                 // float4 per thread that bring a window in
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  float2* tw = reinterpret_cast<float2*>(smem);
+  float* win = reinterpret_cast<float*>(tw + M);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  float2* hT = reinterpret_cast<float2*>(win + ((winPhys + 3) & ~3));
+  float2* strip = hT + (M / 2) * MT + wave * SZ;
+  const int u = blockIdx.y, t0 = blockIdx.x * TF;
+  const int nsamp = nsampArr[u];
+  const int nblk = (nsamp + D - 1) / D;
+  const int Tu = (nblk < laN) ? 0 : (nblk - laN + pd);
+  const long lo = (long) (laN + 1) * D - (long) MT * M + (long) t0 * D;      // first sample of this tile's window (negative: zeros)
+  const bool vec = ((((uintptr_t) x) | (uintptr_t) (sampStride * 4)) & 15) == 0;
+
+  auto fetch = [&](const int c, float4 (&pf)[NL]) __attribute__((always_inline)) {
+    const float* xs = x + ((long) u * C + c) * sampStride;
+#pragma unroll
+    for (int j = 0; j < NL; j++) {
+      const int i4 = (j * 256 + tid) * 4; const long n = lo + i4;
+      float4 v4 = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (i4 < winLen) {
+        if (vec && n >= 0 && n + 3 < nsamp) v4 = *reinterpret_cast<const float4*>(xs + n);
+        else { v4.x = (n >= 0 && n < nsamp) ? xs[n] : 0.f; v4.y = (n + 1 >= 0 && n + 1 < nsamp) ? xs[n + 1] : 0.f;
+               v4.z = (n + 2 >= 0 && n + 2 < nsamp) ? xs[n + 2] : 0.f; v4.w = (n + 3 >= 0 && n + 3 < nsamp) ? xs[n + 3] : 0.f; }
+      }
+      pf[j] = v4;
+    }
+  };
+  float4 pf[NL];
+  fetch(0, pf);
+  for (int i = tid; i < M; i += 256) tw[i] = twG[i];
+  for (int i = tid; i < (M / 2) * MT; i += 256) hT[i] = *reinterpret_cast<const float2*>(proto + 2 * i);
+  __syncthreads();
+  const int l = lane & 15, q = lane >> 4;
+  const int k1p = l >> 1, rr = l & 1;
+  const int l2 = 2 * l, rr16 = rr ? 16 : 0;
+  const float sgn = rr ? -1.f : 1.f;
+  const float2 wf0 = tw[2 * lane], wf1 = tw[2 * lane + 1];
+  const int fc0 = (N - 2 * lane) & (N - 1), fc1 = (N - 2 * lane - 1) & (N - 1);
+  const int ic0 = fc0 + 8 * (fc0 >> 6), ic1 = fc1 + 8 * (fc1 >> 6);
+  const int iz = 2 * lane + 8 * (lane >> 5);
+  const float g = (gain > 0) ? (float) gain : 1.0f;
+  const int tl = 4 * wave;
+
+  float4 acc[4]; float2 accN[4];
+#pragma unroll
+  for (int fq = 0; fq < 4; fq++) { acc[fq] = make_float4(0.f, 0.f, 0.f, 0.f); accN[fq] = make_float2(0.f, 0.f); }
+
+  for (int c = 0; c < C; c++) {
+    if (c > 0) __syncthreads();                                // every wave is done with the window of the channel before
+#pragma unroll
+    for (int j = 0; j < NL; j++) { const int i4 = (j * 256 + tid) * 4; if (i4 < winLen) *reinterpret_cast<float4*>(win + i4 + 32 * (i4 >> 7)) = pf[j]; }
+    __syncthreads();
+    if (c + 1 < C) fetch(c + 1, pf);                           // in flight while this channel is transformed
+    const float4 w4 = *reinterpret_cast<const float4*>(WT + c * (N + 2) + 2 * lane);         // w[2 lane][c], w[2 lane + 1][c]
+    const float2 wN = WT[c * (N + 2) + N];
+    if (t0 + tl < Tmax) {
+      // ---- pass 1: polyphase sums + 8-point DFT over e + turn (k_analysis_q256)
+      float2 v[8];
+      {
+        const float* wp = win + (tl + q) * 160 - 2 * l;
+#pragma unroll
+        for (int e = 0; e < 8; e++) {
+          float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+          for (int qq = 0; qq < MT; qq++) {
+            const int A = MT * M - 2 - 32 * e - 256 * qq;
+            const float2 pr = *reinterpret_cast<const float2*>(wp + (A + 32 * (A >> 7)));
+            const float2 hp = hT[l + 16 * e + (M / 2) * qq];
+            s0 += hp.x * pr.y; s1 += hp.y * pr.x;
+          }
+          v[e] = make_float2(s0, s1);
+        }
+      }
+      fft8_pos(v);
+#pragma unroll
+      for (int k = 0; k < 8; k++) strip[q * SQ + k * SK + l] = (k == 0) ? v[0] : cmulf(v[BR[k]], tw[(l2 * k) & (M - 1)]);
+      wave_lds_sync();
+#pragma unroll
+      for (int m2 = 0; m2 < 8; m2++) v[m2] = strip[q * SQ + k1p * SK + 2 * m2 + rr];
+      fft8_pos(v);
+      wave_lds_sync();
+#pragma unroll
+      for (int k = 0; k < 8; k++) {
+        const float2 b = (k == 0) ? v[0] : cmulf(v[BR[k]], tw[rr16 * k]);
+        const float ox = dpp_f<0xB1>(b.x), oy = dpp_f<0xB1>(b.y);
+        const int f = k1p + 8 * k + 64 * rr;
+        strip[q * 144 + f + 8 * rr] = make_float2(ox + sgn * b.x, oy + sgn * b.y);
+      }
+      wave_lds_sync();
+      // ---- even/odd split of one frame at a time, then conj(w) x as k_bf_apply adds it
+#pragma unroll
+      for (int fq = 0; fq < 4; fq++) {
+        const int t = t0 + tl + fq;
+        const float gh = (t < Tu) ? 0.5f * g : 0.0f;
+        const float2* Z = strip + fq * 144;
+        const float4 zz = *reinterpret_cast<const float4*>(Z + iz);
+        const float2 zf0 = make_float2(zz.x, zz.y), zf1 = make_float2(zz.z, zz.w), zc0 = Z[ic0], zc1 = Z[ic1];
+        const float2 s0 = make_float2(zf0.x + zc0.x, zf0.y - zc0.y), d0 = make_float2(zf0.x - zc0.x, zf0.y + zc0.y);
+        const float2 s1 = make_float2(zf1.x + zc1.x, zf1.y - zc1.y), d1 = make_float2(zf1.x - zc1.x, zf1.y + zc1.y);
+        float4 o4;
+        o4.x = (s0.x + wf0.x * d0.y + wf0.y * d0.x) * gh; o4.y = (s0.y - wf0.x * d0.x + wf0.y * d0.y) * gh;
+        o4.z = (s1.x + wf1.x * d1.y + wf1.y * d1.x) * gh; o4.w = (s1.y - wf1.x * d1.x + wf1.y * d1.y) * gh;
+        const float2 Z0 = Z[0];
+        const float xN = (Z0.x - Z0.y) * 2.0f * gh;                                           // bin N: X = Re(Z0) - Im(Z0), imaginary part 0
+        acc[fq].x += w4.x * o4.x + w4.y * o4.y; acc[fq].y += w4.x * o4.y - w4.y * o4.x;
+        acc[fq].z += w4.z * o4.z + w4.w * o4.w; acc[fq].w += w4.z * o4.w - w4.w * o4.z;
+        accN[fq].x += wN.x * xN + wN.y * 0.f; accN[fq].y += wN.x * 0.f - wN.y * xN;
+      }
+      wave_lds_sync();
+    }
+  }
+  float2* Yo = Y + (long) u * Tmax * (N + 1);
+#pragma unroll
+  for (int fq = 0; fq < 4; fq++) {
+    const int t = t0 + tl + fq;
+    if (t < Tmax) {
+      float2* row = Yo + (long) t * (N + 1);
+      typedef float f4a8 __attribute__((ext_vector_type(4), aligned(8)));
+      f4a8 ov = {acc[fq].x, acc[fq].y, acc[fq].z, acc[fq].w};
+      *reinterpret_cast<f4a8*>(reinterpret_cast<char*>(row) + 16 * lane) = ov;
+      if (lane == 0) row[N] = accN[fq];
+    }
+  }
+}
+
 template <int M> static void launch_synthesis(const FbPlan& p, const FbCall& k, const float* Y, const int* nframes, int U, int Tmax,
                                               long outStride, float* y, hipStream_t st)
 {
@@ -1002,6 +1155,45 @@ dsr_status dsr_fb_analysis(const dsr_fb* p, const float* x, const int32_t* nsamp
     if (C > 65535 || U > 65535) throw Error(DSR_E_DIMENSION, "U and C must be <= 65535 per call");
     const FbCall k = { p->pd, p->laN, nullptr, 0, 0 };
     fb_analysis(*p, k, x, nsamp, U, C, (long) sampStride, Tmax, X, (hipStream_t) stream);
+  });
+}
+namespace dsr { const float2* bf_fixed_weights_dev(dsr_bf* s); }
+int dsr_fb_analysis_beamform_supported(const dsr_fb* p, const dsr_bf* bf)
+{
+  if (!p || !bf || p->synthesis || getenv("DSR_FB_GENERIC") || getenv("DSR_FB_WAVE") || getenv("DSR_FB_NOFUSE")) return 0;
+  if (!(p->M == 256 && p->r == 1 && (p->m == 2 || p->m == 4))) return 0;
+  const int C = dsr_bf_chan_n(bf);
+  return (dsr_bf_fft_len(bf) == p->M && !dsr_bf_half_band_shift(bf) && !dsr_bf_is_adaptive(bf) && C >= 1 && C <= 16) ? 1 : 0;
+}
+dsr_status dsr_fb_analysis_beamform(const dsr_fb* p, dsr_bf* bf, const float* x, const int32_t* nsamp, int U, int C, int64_t sampStride,
+                                    int Tmax, float* Y, void* stream)
+{
+  return guard([&] {
+    if (!p || !bf || !x || !nsamp || !Y) throw Error(DSR_E_PARAMETER, "null argument");
+    if (!dsr_fb_analysis_beamform_supported(p, bf)) throw Error(DSR_E_PARAMETER, "analysis + beamformer in one pass needs M = 256, r = 1, m in {2, 4}, at most 16 channels and fixed weights");
+    if (C != dsr_bf_chan_n(bf)) throw Error(DSR_E_DIMENSION, "beamformer has %d channels, input has %d", dsr_bf_chan_n(bf), C);
+    if (U <= 0 || Tmax <= 0) return;
+    if (U > 65535) throw Error(DSR_E_DIMENSION, "U must be <= 65535 per call");
+    const float2* W = bf_fixed_weights_dev(bf);
+    if (!W) throw Error(DSR_E_CONSISTENCY, "the beamformer has no fixed weights");
+    hipStream_t st = (hipStream_t) stream;
+    constexpr int M = 256, TF = 16;
+    const int MT = p->m;
+    const int winLen = (TF - 1) * p->D + MT * M, winPhys = winLen + 32 * ((winLen + 127) >> 7);
+    const size_t lds = sizeof(float2) * M + sizeof(float) * ((winPhys + 3) & ~3) + sizeof(float2) * (size_t) (M / 2) * MT + sizeof(float2) * (size_t) 4 * 4 * 146;
+    dim3 grid((unsigned) cdiv(Tmax, TF), (unsigned) U);
+    static thread_local DevBuf<float2> wT;                      // [C][M/2 + 2]
+    wT.reserve((size_t) C * (M / 2 + 2));
+    hipLaunchKernelGGL(k_transpose_w, dim3(cdiv(C * (M / 2 + 2), 256)), dim3(256), 0, st, W, wT.p, C, M / 2 + 1);
+    W = wT.p;
+    if (MT == 4) {
+      DSR_HIP(hipFuncSetAttribute((const void*) k_analysis_bf_q256<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
+      hipLaunchKernelGGL((k_analysis_bf_q256<4>), grid, dim3(256), lds, st, x, nsamp, p->d_proto.p, p->d_tw.p, W, (float2*) Y, C, (long) sampStride, Tmax, p->pd, p->laN, p->gain);
+    } else {
+      DSR_HIP(hipFuncSetAttribute((const void*) k_analysis_bf_q256<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
+      hipLaunchKernelGGL((k_analysis_bf_q256<2>), grid, dim3(256), lds, st, x, nsamp, p->d_proto.p, p->d_tw.p, W, (float2*) Y, C, (long) sampStride, Tmax, p->pd, p->laN, p->gain);
+    }
+    DSR_HIP(hipGetLastError());
   });
 }
 dsr_status dsr_fb_synthesis(const dsr_fb* p, const float* Y, const int32_t* nframes, int U, int Tmax,

@@ -167,6 +167,20 @@ class FilterBank:
         check(_lib.dsr_fb_analysis(self.h, _dev(x), _dev(nsamp), U, Cn, N, Tmax, _dev(X), cur_stream()))
         return torch.view_as_complex(X)
 
+    def analysis_beamform(self, bf, x, nsamp=None):
+        """analysis bank + fixed-weight beamformer in one pass (dsr_fb_analysis_beamform): x cuda float32 [U][C][N] -> complex64 [U][Tmax][M/2+1]"""
+        import torch
+        U, Cn, N = x.shape
+        if nsamp is None:
+            nsamp = torch.full((U,), N, dtype=torch.int32, device=x.device)
+        Tmax = max(1, max(self.frames(int(n)) for n in nsamp.tolist()))
+        Y = torch.empty((U, Tmax, self.M // 2 + 1, 2), dtype=torch.float32, device=x.device)
+        check(_lib.dsr_fb_analysis_beamform(self.h, bf.h, _dev(x), _dev(nsamp), U, Cn, N, Tmax, _dev(Y), cur_stream()))
+        return torch.view_as_complex(Y)
+
+    def analysis_beamform_supported(self, bf):
+        return bool(_lib.dsr_fb_analysis_beamform_supported(self.h, bf.h))
+
     def synthesis_run(self, Y, nframes=None):
         """Y: cuda complex64 [U][Tmax][M/2+1] -> float32 [U][nblocks*D]"""
         import torch
@@ -871,9 +885,12 @@ class Lattice:
 
 
 class Pipe:
-    def __init__(self, ana, syn, bf, mfcc, gmm, dec, gmmMode=0):
+    def __init__(self, ana, syn, bf, mfcc, gmm, dec, gmmMode=0, fused=False):
+        """fused: analysis bank and fixed-weight beamformer as one kernel where supported (the channel snapshots are then never written)"""
         L = load(); self.h = vp(); self._keep = (ana, syn, bf, mfcc, gmm, dec)
         check(L.dsr_pipe_create(ana.h, syn.h, bf.h, mfcc.h, gmm.h, dec.h, gmmMode, C.byref(self.h)))
+        if fused:
+            check(L.dsr_pipe_set_fused(self.h, 1))
 
     def __del__(self):
         if _lib is not None and getattr(self, "h", None):

@@ -84,6 +84,14 @@ dsr_status dsr_fb_analysis(const dsr_fb*, const float* x_dev, const int32_t* nsa
  *   y_dev      [U][outStride] fp32: blocks 0..nframes-pd-1 of D samples; the rest zero filled */
 dsr_status dsr_fb_synthesis(const dsr_fb*, const float* Y_dev, const int32_t* nframes_dev, int U,
                             int Tmax, int64_t outStride, float* y_dev, void* stream);
+/* Analysis bank and fixed-weight subband beamformer in one pass: Y_dev [U][Tmax][M/2+1] = dsr_bf_apply(dsr_fb_analysis(x)) without the channel
+ * snapshots X ever being written (OverSampledDFTAnalysisBank::next per channel, modulated.cc:461-516, feeding SubbandDS / SubbandMVDR / SubbandGSC::next,
+ * beamformer.cc:1137-1200,1297-1363,2583-2635, whose output is sum_c conj(w[f][c]) X_c[f] with weights that do not change from frame to frame).
+ * supported(): M = 256, r = 1, m in {2, 4}, at most 16 channels, no halfBandShift, not the adapting SubbandGSCRLS; otherwise call the two steps. */
+struct dsr_bf;
+int        dsr_fb_analysis_beamform_supported(const dsr_fb*, const struct dsr_bf*);
+dsr_status dsr_fb_analysis_beamform(const dsr_fb*, struct dsr_bf*, const float* x_dev, const int32_t* nsamp_dev, int U, int C, int64_t sampStride,
+                                    int Tmax, float* Y_dev, void* stream);
 
 /* Block-wise processing of long streams (BASELINE configs[4]: 10-minute streams handed over in 10-second blocks).  The reference operators are
  * streaming by construction: they keep ring buffers of the last m*M samples (analysis: _RealBuffer, modulated.h:79-163, modulated.cc:400-452)
@@ -122,6 +130,7 @@ int        dsr_bf_chan_n(const dsr_bf*);
    bin 0; the snapshot and output arrays of dsr_bf_apply then carry dsr_bf_bins() = fftLen bins per frame instead of fftLen/2+1.  Delay-and-sum and
    GSC only: SubbandMVDR refuses the flag (:2324-2327), SubbandGSCRLS::next says "not yet implemented" (:1580-1583) -- both kept. */
 int        dsr_bf_half_band_shift(const dsr_bf*);
+int        dsr_bf_is_adaptive(const dsr_bf*);      /* 1 after dsr_bf_rls_config: the output depends on the frames before (SubbandGSCRLS) */
 int        dsr_bf_bins(const dsr_bf*);
 /* calcArrayManifoldVectors (beamformer.cc:531-594): delays[chanN] seconds */
 dsr_status dsr_bf_calc_array_manifold(dsr_bf*, double sampleRate, const double* delays);
@@ -438,6 +447,9 @@ dsr_status dsr_pipe_run(dsr_pipe*, const float* x_dev, const int32_t* nsamp_dev,
 dsr_status dsr_pipe_submit(dsr_pipe*, const float* x_dev, const int32_t* nsamp_dev, const int32_t* nsamp_host,
                            int U, int C, int64_t sampStride, int maxPath, int want_paths, void* stream);
 dsr_status dsr_pipe_collect(dsr_pipe*, dsr_decode_result* res, int32_t* arcs_out, uint32_t* words_out);
+/* fused = 1: analysis bank and beamformer run as one kernel when dsr_fb_analysis_beamform_supported() -- the channel snapshots are then never
+ * written (intermediate 0 is not available, stage time 1 is zero and stage time 0 covers both); default 0 */
+dsr_status dsr_pipe_set_fused(dsr_pipe*, int fused);
 /* per-stage device time of the last run in milliseconds: [analysis, beamform, synthesis, mfcc, gmm, viterbi] */
 dsr_status dsr_pipe_stage_ms(const dsr_pipe*, float ms[6]);
 /* device pointers to the intermediates of the last run (borrowed): 0 X, 1 Y, 2 y, 3 feat, 4 scores */

@@ -135,6 +135,48 @@ def test_beamformer_weights(dsr, oracle, cuda):
     assert np.abs(resp - 1.0 / 8).max() < 1e-4
 
 
+@pytest.mark.parametrize("mode,Cn,dct", [("mvdr", 8, 0), ("ds", 8, 2), ("gsc", 8, 0), ("mvdr", 3, 1), ("ds", 16, 0)])
+def test_analysis_beamform_in_one_pass(dsr, oracle, cuda, headset, protos, mode, Cn, dct):
+    """dsr_fb_analysis_beamform (the pipe's fused front end: the channel snapshots never reach memory) against the two-step product path on the same
+    input (same arithmetic per channel, same channel order: 5e-6 of the RMS) and against the oracle's analysis bank + beamformer (the tolerance of
+    the two steps); ragged batch incl. an utterance without frames, rows past an utterance's end zero, a batch of many tiles."""
+    import torch
+    M, m, r, h, g = protos["M256-m4-r1"]
+    bf, delays, wq, R, w = _mvdr_setup(dsr, oracle, M, Cn)
+    rng = np.random.default_rng(17)
+    if mode == "gsc":
+        bf.calcGSCWeights(16000.0, delays)
+        wa = (rng.standard_normal((M, Cn - 1)) + 1j * rng.standard_normal((M, Cn - 1))) * 0.05
+        for f in range(M):
+            bf.setActiveWeights_f(f, np.stack([wa[f].real, wa[f].imag], -1).reshape(-1))
+    bf.select(mode)
+    lens = [20000, 12345, 5000, 777, 1, 16384]
+    U, N = len(lens), max(lens)
+    x = np.zeros((U, Cn, N), np.float32)
+    for u, n in enumerate(lens):
+        x[u, :, :n] = synth.array_signal(n, Cn, seed=40 + u) * (1000.0 if u % 2 else 1.0)
+    fb = dsr.FilterBank(h, M, m, r, False, dct)
+    assert fb.analysis_beamform_supported(bf)
+    xd = torch.from_numpy(x).to(cuda); nd = torch.tensor(lens, dtype=torch.int32, device=cuda)
+    Y = fb.analysis_beamform(bf, xd, nd).cpu().numpy()
+    Y2 = bf.apply(fb.analysis(xd, nd)).cpu().numpy()
+    W = bf.get(4)
+    assert Y.shape == Y2.shape
+    for u, n in enumerate(lens):
+        T = fb.frames(n)
+        assert np.all(Y[u, T:] == 0)
+        if T == 0:
+            continue
+        rms = np.sqrt(np.mean(np.abs(Y2[u, :T]) ** 2)) + 1e-30
+        assert np.abs(Y[u, :T] - Y2[u, :T]).max() / rms < 5e-6, (u, np.abs(Y[u, :T] - Y2[u, :T]).max() / rms)
+        Xc = np.stack([oracle.analysis_bank(x[u, c, :n], h, M, m, r, dct) for c in range(Cn)])
+        ref = oracle.beamform_apply(Xc, W)[:, :M // 2 + 1]
+        assert np.abs(Y[u, :T] - ref).max() / (np.sqrt(np.mean(np.abs(ref) ** 2)) + 1e-30) < 4e-5, u
+    # not for an adapting beamformer, nor for another bank
+    M5, m5, r5, h5, g5 = protos["M512-m2-r2"]
+    assert not dsr.FilterBank(h5, M5, m5, r5, False, 0).analysis_beamform_supported(bf)
+
+
 @pytest.mark.parametrize("mode", ["ds", "mvdr", "gsc", "gsc_norm"])
 def test_beamformer_apply(dsr, oracle, cuda, mode):
     import torch
@@ -430,7 +472,8 @@ def test_viterbi_errors(dsr, oracle, cuda):
 
 
 # ------------------------------------------------------------------------------------------- whole pipe
-def test_full_pipe_small(dsr, oracle, cuda, protos):
+@pytest.mark.parametrize("fused", [False, True])
+def test_full_pipe_small(dsr, oracle, cuda, protos, fused):
     """8-ch analysis -> MVDR -> synthesis -> MFCC -> GMM -> Viterbi for 3 ragged utterances against the chained oracle.
     GMM+WFST are fed the device features on both sides (bit-exact check); the front end is checked to tolerance."""
     import torch
@@ -452,9 +495,12 @@ def test_full_pipe_small(dsr, oracle, cuda, protos):
     arcs, fin = synth.random_wfst(3000, K, seed=21)
     go, gd = _graphs(dsr, oracle, arcs, fin)
     dec = dsr.Decoder(beam=60.0, lmScale=12.0, maxActive=16384, streams=4); dec.set(gd)
-    pipe = dsr.Pipe(ana, syn, bf, mf, gm, dec, gmmMode=0)
+    pipe = dsr.Pipe(ana, syn, bf, mf, gm, dec, gmmMode=0, fused=fused)          # fused: analysis bank + beamformer as one kernel
     xd = torch.from_numpy(x).to(cuda); nd = torch.tensor(lens, dtype=torch.int32, device=cuda)
     res, arcsO, wordsO = pipe.run(xd, nd, lens, maxPath=2048)
+    if fused:
+        with pytest.raises(dsr.DsrError):
+            pipe.intermediate(0)                                                 # the channel snapshots were never written
     W = bf.get(4)
     cfg = oracle.mfcc_cfg(lda=lda)
     cb = oracle.Codebooks(gm_m["refN"], gm_m["mean"], gm_m["ivar"], gm_m["det"])
@@ -475,7 +521,8 @@ def test_full_pipe_small(dsr, oracle, cuda, protos):
         assert np.array_equal(wordsO[u, :res[u].nWords], ro["words"])
 
 
-def test_full_pipe_batch_invariance(dsr, cuda, protos):
+@pytest.mark.parametrize("fused", [False, True])
+def test_full_pipe_batch_invariance(dsr, cuda, protos, fused):
     """Every stage with far more workgroups than compute units (co-resident workgroups, several rounds, more utterances than
     decoder slots): each utterance's intermediates and 1-best are bit-identical to those it gets in a batch of its own."""
     import torch
@@ -505,10 +552,10 @@ def test_full_pipe_batch_invariance(dsr, cuda, protos):
     def run(idx):
         mf = dsr.Mfcc(lda=lda)
         dec = dsr.Decoder(beam=60.0, lmScale=12.0, maxActive=16384); dec.set(gd)
-        pipe = dsr.Pipe(ana, syn, bf, mf, gm, dec, gmmMode=0)
+        pipe = dsr.Pipe(ana, syn, bf, mf, gm, dec, gmmMode=0, fused=fused)
         xs = torch.from_numpy(np.ascontiguousarray(x[idx])).to(cuda); ls = [lens[i] for i in idx]
         res, arcsO, wordsO = pipe.run(xs, torch.tensor(ls, dtype=torch.int32, device=cuda), ls, maxPath=512)
-        inter = [pipe.intermediate_host(k).copy() for k in range(5)]
+        inter = [pipe.intermediate_host(k).copy() if not (fused and k == 0) else np.zeros(0, np.float32) for k in range(5)]
         return res, arcsO, wordsO, inter
 
     allidx = list(range(U))
