@@ -301,7 +301,7 @@ __global__ __launch_bounds__(256) void k_analysis_w(const float* __restrict__ x,
 
 // LDS layout: [tw: M float2][proto g: m*M float][v: NV*M float][bufA: FB*M float][bufB: FB*M float]
 template <int M>
-__global__ __launch_bounds__(256) void k_synthesis(const float2* __restrict__ Y, const int* __restrict__ nframesArr,
+__global__ __launch_bounds__(1024) void k_synthesis(const float2* __restrict__ Y, const int* __restrict__ nframesArr,
                                                    const float* __restrict__ proto, const float2* __restrict__ twG,
                                                    float* __restrict__ y, int Tmax, long outStride,
                                                    int m, int r, int pd, int gain, int TO, int FB, const float2* __restrict__ hist, int histN, int tsMin)
@@ -754,13 +754,18 @@ template <int M> static void launch_synthesis(const FbPlan& p, const FbCall& k, 
 {
   int FB = 4096 / M; if (FB < 1) FB = 1;
   int TO = 32; while (TO > 1 && (size_t) (TO + p.R * p.m - 1) * M * 4 > 48 * 1024) TO >>= 1;
+  if (const char* e = getenv("DSR_SYN_TO")) { const int v = atoi(e); if (v >= 4 && v <= 64) { TO = v; } }
+  if (const char* e = getenv("DSR_SYN_FB")) { const int v = atoi(e); if (v >= 1 && v <= 64) FB = v; }
   const int NV = TO + p.R * p.m - 1;
   size_t lds = sizeof(float2) * M + sizeof(float) * ((size_t) p.m * M + (size_t) NV * M + 2 * (size_t) FB * M);
   if (lds > 160 * 1024) throw Error(DSR_E_DIMENSION, "synthesis bank M=%d m=%d needs %zu bytes of LDS", M, p.m, lds);
   DSR_HIP(hipFuncSetAttribute((const void*) k_synthesis<M>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
   const int nblkMax = (int) (outStride / p.D);
   dim3 grid(cdiv(nblkMax > 0 ? nblkMax : 1, TO), U);
-  hipLaunchKernelGGL(k_synthesis<M>, grid, dim3(256), lds, st, (const float2*) Y, nframes, p.d_proto.p, p.d_tw.p, y,
+  // 1024 threads: the kernel is a chain of barrier-separated LDS phases (build, four FFT stages, copy, per batch of FB frames) and two workgroups of
+  // four waves per CU left it latency-bound -- 512 utterances: 1.59 ms at 256 threads, 1.08 at 512, 0.92 at 1024 (TO 32 / FB 16 stay the best shape)
+  int synThr = 1024; if (const char* e = getenv("DSR_SYN_THREADS")) { const int v = atoi(e); if (v == 256 || v == 512 || v == 1024) synThr = v; }
+  hipLaunchKernelGGL(k_synthesis<M>, grid, dim3(synThr), lds, st, (const float2*) Y, nframes, p.d_proto.p, p.d_tw.p, y,
                      Tmax, outStride, p.m, p.r, k.pd, p.gain, TO, FB, (const float2*) k.hist, k.histN, k.tsMin);
   DSR_HIP(hipGetLastError());
 }
