@@ -40,10 +40,11 @@ tj = {"config": "bench.py --steps 1 --warmup 1 --no-cpu --beam 53.787 (1000 utt 
       "collection": "rocprofv3 --kernel-trace --pmc FETCH_SIZE and, in a separate pass, --pmc WRITE_SIZE (tools/round_profiles.sh); unit KB", "kernels": {}}
 notes = {"k_viterbi": "FETCH_SIZE is RDREQ x 64 B; 128-B requests are tallied at 64 B on gfx950 and this kernel's mixed 4/8/16/32-B gathers are not a calibrated pattern: the read part is a lower bound (true value between 1x and 2x)",
          "k_analysis_q256<4, 2>": "16-B/lane streaming reads: FETCH_SIZE doubled (guide, HBM section)",
+         "k_analysis_bf_q256<4>": "the pipe's fused analysis bank + beamformer: 16-B/lane streaming reads of the samples (each tile re-reads the 7 blocks it shares with the tile before), FETCH_SIZE doubled (guide, HBM section); the channel snapshots are not written",
          "k_bf_apply": "8-B/lane streaming reads, whole 128-B requests: FETCH_SIZE doubled (guide, HBM section)"}
 for k, v in acc.items():
     if "FETCH_SIZE" in v and "WRITE_SIZE" in v:
-        fetch = v["FETCH_SIZE"] * (2.0 if (k.startswith("k_analysis_q256") or k.startswith("k_bf_apply")) else 1.0)
+        fetch = v["FETCH_SIZE"] * (2.0 if (k.startswith("k_analysis_q256") or k.startswith("k_analysis_bf_q256") or k.startswith("k_bf_apply")) else 1.0)
         name = k.split("<")[0]
         tj["kernels"][name] = {"FETCH_SIZE_KB": v["FETCH_SIZE"], "WRITE_SIZE_KB": v["WRITE_SIZE"], "bytes_per_launch": (fetch + v["WRITE_SIZE"]) * 1024.0 / 2.0}
         if k in notes:
