@@ -30,6 +30,7 @@ struct BfState {
   std::vector<zc> wl;      // [M][C]  B wa as of the last setActiveWeights_f / zeroActiveWeights (SubbandMVDRGSC reads this cached product)
   std::vector<zc> eff;     // [M/2+1][C] weights in use
   DevBuf<float2> d_w;      // [M/2+1][C]
+  DevBuf<float2> d_wT;     // [C][M/2+2] the same weights channel-major (the fused analysis + beamformer kernel reads a channel's row coalesced)
   bool dirty = true;
   // SubbandGSCRLS (beamformer.h:213-262): recursive-least-squares adaptation of the active weights
   bool rlsOn = false, rlsAdapt = true, haveP0 = false; double rlsMyu = 0.9, rlsAlpha = -1.0; int rlsQc = 0;
@@ -134,6 +135,11 @@ static void refresh_effective(BfState& s)
   std::vector<float2> w((size_t) F * C);
   for (size_t i = 0; i < w.size(); i++) w[i] = make_float2((float) s.eff[i].real(), (float) s.eff[i].imag());
   s.d_w.upload(w);
+  if (!s.halfBandShift) {
+    std::vector<float2> wT((size_t) C * (F + 1), make_float2(0.f, 0.f));
+    for (int f = 0; f < F; f++) for (int c = 0; c < C; c++) wT[(size_t) c * (F + 1) + f] = w[(size_t) f * C + c];
+    s.d_wT.upload(wT);
+  }
   s.dirty = false;
 }
 
@@ -481,9 +487,9 @@ dsr_status dsr_bf_get(const dsr_bf* cs, int kind, double* out, size_t nd)
   });
 }
 
-// the weights k_bf_apply would use, [M/2+1][C] on the device, for the fused analysis + beamformer kernel (k_filterbank.hip); null when the output is
+// the weights k_bf_apply would use, channel-major [C][M/2+2] on the device, for the fused analysis + beamformer kernel (k_filterbank.hip); null when the output is
 // not a fixed linear combination of the channels (SubbandGSCRLS adapting) or when all M bins are computed (halfBandShift)
-namespace dsr { const float2* bf_fixed_weights_dev(dsr_bf* s) { if (!s || s->rlsOn || s->halfBandShift) return nullptr; if (s->dirty) refresh_effective(*s); return s->d_w.p; } }
+namespace dsr { const float2* bf_fixed_weights_dev(dsr_bf* s) { if (!s || s->rlsOn || s->halfBandShift) return nullptr; if (s->dirty) refresh_effective(*s); return s->d_wT.p; } }
 
 dsr_status dsr_bf_apply(dsr_bf* s, const float* X, int U, int Tmax, float* Y, void* stream)
 {

@@ -604,15 +604,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 // 16 frames' 2944 samples; consecutive tiles re-read the 896 they share) comes in through registers while the channel before is transformed,
 // passes and even/odd split are those of k_analysis_q256 operation for operation, and what that kernel stores as row t of channel c is weighted
 // and added, channel after channel in the order of k_bf_apply's loop, to accumulators of the lane's two bins (bin N: every lane, redundantly).
-// The weights come transposed, WT[c][N + 2] (k_transpose_w below), straight from memory: a 16-byte load per lane and channel, issued a whole transform
+// The weights come channel-major, WT[c][N + 2] (the beamformer object keeps that copy), straight from memory: a 16-byte load per lane and channel, issued a whole transform
 // ahead of its use (in LDS they cost the fourth workgroup per CU).
 // LDS: [tw: M float2][win][hT][strip: waves x 576 float2]
-__global__ void k_transpose_w(const float2* __restrict__ W, float2* __restrict__ WT, int C, int F)
-{
-  const int i = blockIdx.x * blockDim.x + threadIdx.x; if (i >= C * (F + 1)) return;
-  const int c = i / (F + 1), f = i - c * (F + 1);
-  WT[i] = (f < F) ? W[f * C + c] : make_float2(0.f, 0.f);
-}
 template <int MT>
 __global__ __launch_bounds__(256) void k_analysis_bf_q256(const float* __restrict__ x, const int* __restrict__ nsampArr,
                                                           const float* __restrict__ proto, const float2* __restrict__ twG, const float2* __restrict__ WT,
@@ -1187,10 +1181,7 @@ dsr_status dsr_fb_analysis_beamform(const dsr_fb* p, dsr_bf* bf, const float* x,
     const int winLen = (TF - 1) * p->D + MT * M, winPhys = winLen + 32 * ((winLen + 127) >> 7);
     const size_t lds = sizeof(float2) * M + sizeof(float) * ((winPhys + 3) & ~3) + sizeof(float2) * (size_t) (M / 2) * MT + sizeof(float2) * (size_t) 4 * 4 * 146;
     dim3 grid((unsigned) cdiv(Tmax, TF), (unsigned) U);
-    static thread_local DevBuf<float2> wT;                      // [C][M/2 + 2]
-    wT.reserve((size_t) C * (M / 2 + 2));
-    hipLaunchKernelGGL(k_transpose_w, dim3(cdiv(C * (M / 2 + 2), 256)), dim3(256), 0, st, W, wT.p, C, M / 2 + 1);
-    W = wT.p;
+
     if (MT == 4) {
       DSR_HIP(hipFuncSetAttribute((const void*) k_analysis_bf_q256<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
       hipLaunchKernelGGL((k_analysis_bf_q256<4>), grid, dim3(256), lds, st, x, nsamp, p->d_proto.p, p->d_tw.p, W, (float2*) Y, C, (long) sampStride, Tmax, p->pd, p->laN, p->gain);
