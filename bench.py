@@ -253,7 +253,7 @@ def main():
     inflight = [False] * npipes
 
     def finish(i):
-        res, arcs, words = pipes[i].collect(); inflight[i] = False
+        res, arcs, words = pipes[i].collect(reuse=True); inflight[i] = False          # (the host arrays of a pipe are reused step after step)
         # the path's only exchange: gather the 1-best word sequences on rank 0 (RCCL over xGMI)
         if world > 1:
             from dsr.dist import gather_one_best
