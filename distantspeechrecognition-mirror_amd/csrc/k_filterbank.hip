@@ -607,17 +607,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 // The weights come channel-major, WT[c][N + 2] (the beamformer object keeps that copy), straight from memory: a 16-byte load per lane and channel, issued a whole transform
 // ahead of its use (in LDS they cost the fourth workgroup per CU).
 // LDS: [tw: M float2][win][hT][strip: waves x 576 float2]
-template <int MT>
-__global__ __launch_bounds__(256) void k_analysis_bf_q256(const float* __restrict__ x, const int* __restrict__ nsampArr,
+template <int MT, int NW>
+__global__ __launch_bounds__(64 * NW) void k_analysis_bf_q256(const float* __restrict__ x, const int* __restrict__ nsampArr,
                                                           const float* __restrict__ proto, const float2* __restrict__ twG, const float2* __restrict__ WT,
                                                           float2* __restrict__ Y, int C, long sampStride, int Tmax, int pd, int laN, int gain)
 {
-  constexpr int M = 256, N = 128, D = 128, TF = 16;
+  constexpr int M = 256, N = 128, D = 128, TF = 4 * NW, NT = 64 * NW;
   constexpr int SQ = 146, SK = 18, SZ = 4 * SQ;
   constexpr int BR[8] = {0, 4, 2, 6, 1, 5, 3, 7};
   constexpr int winLen = (TF - 1) * D + MT * M;                // logical samples of a tile's window
   constexpr int winPhys = winLen + 32 * ((winLen + 127) >> 7);
-  constexpr int NL = (winLen / 4 + 255) / 256;                 // float4 per thread that bring a window in
+  constexpr int NL = (winLen / 4 + NT - 1) / NT;                 // float4 per thread that bring a window in
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   float2* tw = reinterpret_cast<float2*>(smem);
   float* win = reinterpret_cast<float*>(tw + M);
@@ -635,7 +635,7 @@ __global__ __launch_bounds__(256) void k_analysis_bf_q256(const float* __restric
     const float* xs = x + ((long) u * C + c) * sampStride;
 #pragma unroll
     for (int j = 0; j < NL; j++) {
-      const int i4 = (j * 256 + tid) * 4; const long n = lo + i4;
+      const int i4 = (j * NT + tid) * 4; const long n = lo + i4;
       float4 v4 = make_float4(0.f, 0.f, 0.f, 0.f);
       if (i4 < winLen) {
         if (vec && n >= 0 && n + 3 < nsamp) v4 = *reinterpret_cast<const float4*>(xs + n);
@@ -647,8 +647,8 @@ __global__ __launch_bounds__(256) void k_analysis_bf_q256(const float* __restric
   };
   float4 pf[NL];
   fetch(0, pf);
-  for (int i = tid; i < M; i += 256) tw[i] = twG[i];
-  for (int i = tid; i < (M / 2) * MT; i += 256) hT[i] = *reinterpret_cast<const float2*>(proto + 2 * i);
+  for (int i = tid; i < M; i += NT) tw[i] = twG[i];
+  for (int i = tid; i < (M / 2) * MT; i += NT) hT[i] = *reinterpret_cast<const float2*>(proto + 2 * i);
   __syncthreads();
   const int l = lane & 15, q = lane >> 4;
   const int k1p = l >> 1, rr = l & 1;
@@ -668,7 +668,7 @@ __global__ __launch_bounds__(256) void k_analysis_bf_q256(const float* __restric
   for (int c = 0; c < C; c++) {
     if (c > 0) __syncthreads();                                // every wave is done with the window of the channel before
 #pragma unroll
-    for (int j = 0; j < NL; j++) { const int i4 = (j * 256 + tid) * 4; if (i4 < winLen) *reinterpret_cast<float4*>(win + i4 + 32 * (i4 >> 7)) = pf[j]; }
+    for (int j = 0; j < NL; j++) { const int i4 = (j * NT + tid) * 4; if (i4 < winLen) *reinterpret_cast<float4*>(win + i4 + 32 * (i4 >> 7)) = pf[j]; }
     __syncthreads();
     if (c + 1 < C) fetch(c + 1, pf);                           // in flight while this channel is transformed
     const float4 w4 = *reinterpret_cast<const float4*>(WT + c * (N + 2) + 2 * lane);         // w[2 lane][c], w[2 lane + 1][c]
@@ -1176,19 +1176,17 @@ dsr_status dsr_fb_analysis_beamform(const dsr_fb* p, dsr_bf* bf, const float* x,
     const float2* W = bf_fixed_weights_dev(bf);
     if (!W) throw Error(DSR_E_CONSISTENCY, "the beamformer has no fixed weights");
     hipStream_t st = (hipStream_t) stream;
-    constexpr int M = 256, TF = 16;
+    constexpr int M = 256;
     const int MT = p->m;
+    int NW = 4; if (const char* e = getenv("DSR_FB_FUSED_WAVES")) { const int v = atoi(e); if (v == 4 || v == 8) NW = v; }
+    const int TF = 4 * NW;
     const int winLen = (TF - 1) * p->D + MT * M, winPhys = winLen + 32 * ((winLen + 127) >> 7);
-    const size_t lds = sizeof(float2) * M + sizeof(float) * ((winPhys + 3) & ~3) + sizeof(float2) * (size_t) (M / 2) * MT + sizeof(float2) * (size_t) 4 * 4 * 146;
+    const size_t lds = sizeof(float2) * M + sizeof(float) * ((winPhys + 3) & ~3) + sizeof(float2) * (size_t) (M / 2) * MT + sizeof(float2) * (size_t) NW * 4 * 146;
     dim3 grid((unsigned) cdiv(Tmax, TF), (unsigned) U);
-
-    if (MT == 4) {
-      DSR_HIP(hipFuncSetAttribute((const void*) k_analysis_bf_q256<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
-      hipLaunchKernelGGL((k_analysis_bf_q256<4>), grid, dim3(256), lds, st, x, nsamp, p->d_proto.p, p->d_tw.p, W, (float2*) Y, C, (long) sampStride, Tmax, p->pd, p->laN, p->gain);
-    } else {
-      DSR_HIP(hipFuncSetAttribute((const void*) k_analysis_bf_q256<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
-      hipLaunchKernelGGL((k_analysis_bf_q256<2>), grid, dim3(256), lds, st, x, nsamp, p->d_proto.p, p->d_tw.p, W, (float2*) Y, C, (long) sampStride, Tmax, p->pd, p->laN, p->gain);
-    }
+#define LFB(MT_, NW_) { DSR_HIP(hipFuncSetAttribute((const void*) k_analysis_bf_q256<MT_, NW_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds)); \
+      hipLaunchKernelGGL((k_analysis_bf_q256<MT_, NW_>), grid, dim3(64 * NW_), lds, st, x, nsamp, p->d_proto.p, p->d_tw.p, W, (float2*) Y, C, (long) sampStride, Tmax, p->pd, p->laN, p->gain); }
+    if (MT == 4) { if (NW == 8) LFB(4, 8) else LFB(4, 4) } else { if (NW == 8) LFB(2, 8) else LFB(2, 4) }
+#undef LFB
     DSR_HIP(hipGetLastError());
   });
 }
