@@ -6,6 +6,8 @@ WFST 50k states / ~200k arcs, lmScale 12, beam tuned to ~5k active tokens).
 
 One process per GPU; every rank decodes its own shard of utterances (weak scaling: --utts per GPU); the only
 exchange is the gather of the 1-best word sequences to rank 0 over RCCL.  Rank 0 prints ONE JSON line.
+Steps are independent batches and are pipelined over two pipe objects on two HIP streams (step k+1's front end under the
+tail of step k's decode); all K timed steps are enqueued and collected between the two barriers.  --serial: one after the other.
 
   python bench.py --gpus 1 --steps 3 --warmup 1
   python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port P bench.py --gpus 8 ...
@@ -184,11 +186,13 @@ def main():
     ap.add_argument("--beam", type=float, default=0.0, help="0 = tune to ~5k active tokens")
     ap.add_argument("--gmm-mode", type=int, default=2, help="2: MFMA contraction + candidate search in the accumulator layout + exact re-score (the bits of mode 0); 0: exact VALU kernel")
     ap.add_argument("--no-cpu", action="store_true")
-    ap.add_argument("--overlap", action="store_true", help="two pipes on two streams: the ragged end of a step's decode runs under the next step's front end "
-                    "(+2 %% throughput; the per-kernel event intervals then include waiting for CUs, so the default keeps steps strictly one after the other)")
+    ap.add_argument("--overlap", action="store_true", help="(default) two pipe objects on two HIP streams: a step is enqueued whole while the step before is still decoding, "
+                    "so the front end of step k+1 runs on the CUs the persistent decode workgroups of step k free as its utterances finish (+8 %% throughput; every step "
+                    "still does all of its work, and everything is collected before the clock stops)")
     ap.add_argument("--no-fuse", action="store_true", help="analysis bank and beamformer as two kernels with the channel snapshots in HBM between them "
                     "(default: one kernel, dsr_fb_analysis_beamform)")
-    ap.add_argument("--serial", action="store_true", help="(default) one pipe, steps strictly one after the other")
+    ap.add_argument("--serial", action="store_true", help="one pipe, steps strictly one after the other (clean per-kernel event intervals: what the counter passes of "
+                    "tools/round_profiles.sh use)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend of the multi-rank run: nccl (= RCCL, the default) or gloo -- gloo with "
                     "DSR_BENCH_DEVICE=0 rehearses the multi-rank control flow with several ranks on ONE GPU (collectives on host tensors)")
     args = ap.parse_args()
@@ -243,7 +247,7 @@ def main():
     # (utterances finish at different times) overlaps the front end of the next step; every step still does all of its work
     # and everything is collected before the clock stops.
     maxPath = 2 * Tm + 64
-    npipes = 2 if (args.overlap and not args.serial) else 1
+    npipes = 1 if args.serial else 2
     pipes, streams = [], []
     for i in range(npipes):
         dec = dsr.Decoder(beam=beam, lmScale=12.0, maxActive=65536); dec.set(mdl["gd"])
@@ -297,9 +301,9 @@ def main():
     # stage table: one more step, untimed and alone on the GPU (in the timed region the front end of a step shares the GPU with
     # the end of the previous step's decode, so its event intervals include waiting); the roofline entry of the dominant
     # kernel below uses the event intervals of the timed steps themselves
-    serial_ms = None
+    serial_ms = None; serial_step_ms = None
     if npipes > 1:
-        submit(0); serial_ms = finish(0)[2]; sync()
+        sync(); ts = time.time(); submit(0); serial_ms = finish(0)[2]; sync(); serial_step_ms = 1000.0 * (time.time() - ts)
     stage = np.zeros(6); placements = 0; active = 0; bad = 0; frames = 0
     for res, words, sms in done:
         stage += np.array(sms)
@@ -397,7 +401,10 @@ def main():
                                 parallelism="utterance-sharded x%d, RCCL gather of 1-best" % world,
                                 front_end="analysis bank + MVDR in one kernel (channel snapshots never written; stage 'analysis' covers both, bytes = samples in x 23/16 + beamformed rows out)" if fusedFE
                                 else "analysis bank and beamformer as two kernels",
-                                step_overlap="two pipes on two streams (decode tail of a step under the next step's front end)" if npipes > 1 else "none"),
+                                step_overlap=("two pipe objects on two HIP streams: step k+1 is enqueued while step k decodes, its front end runs on the CUs step k's persistent "
+                                              "decode workgroups free as utterances finish; `stages` and serial_step_ms are one extra, untimed step alone on the GPU "
+                                              "(their sum exceeds ms_per_step by what the overlap hides); --serial runs the steps one after the other") if npipes > 1 else "none",
+                                serial_step_ms=serial_step_ms),
                     roofline=roof, stages=stages, cpu_baseline=cpu)
         print(json.dumps(line))
     if world > 1:

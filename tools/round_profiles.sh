@@ -16,7 +16,7 @@ with open(d + "/bench_viterbi_launches.txt", "w") as o:
 PY
 rm -rf $O/trace
 cd $R
-ARGS="$R/bench.py --steps 1 --warmup 1 --no-cpu --beam 53.787"
+ARGS="$R/bench.py --serial --steps 1 --warmup 1 --no-cpu --beam 53.787"     # one pipe: probe + two full-batch launches of every kernel
 for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS" "SQ_ACTIVE_INST_VALU SQ_BUSY_CU_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES"; do
   tag=r02_$(echo $set | cut -d' ' -f1)
   bash tools/pmc.sh $tag "$set" $ARGS > $O/pmc_$tag.txt 2>&1 || echo "pmc pass $tag failed"

@@ -23,7 +23,7 @@ for fn in sorted(glob.glob(os.path.join(src, "pmc_*.txt"))):
         d = ast.literal_eval(m.group(2))
         acc.setdefault(k, {"launches": int(m.group(3))}).update({c: float(v) for c, v in d.items()})
 with open(os.path.join(dst, "r02_pmc_summary.txt"), "w") as f:
-    f.write("# rocprofv3 --kernel-trace --pmc <one set per pass> -- python3 bench.py --steps 1 --warmup 1 --no-cpu --beam 53.787 (tools/round_profiles.sh)\n")
+    f.write("# rocprofv3 --kernel-trace --pmc <one set per pass> -- python3 bench.py --serial --steps 1 --warmup 1 --no-cpu --beam 53.787 (tools/round_profiles.sh)\n")
     f.write("# counters summed over the launches of the run (decoder: 4-utterance probe + 2 full batches; other kernels: probe + 2)\n")
     for k in sorted(acc):
         f.write(k + " " + json.dumps(acc[k], sort_keys=True) + "\n")
@@ -36,7 +36,7 @@ with open(os.path.join(dst, "r02_pmc_summary.txt"), "w") as f:
     g = acc.get("k_gmm_mfma_reg<10, 4>")
     if g:
         f.write("# k_gmm_mfma_reg: MFMA busy %.0f %% of the SIMD cycles (SQ_VALU_MFMA_BUSY_CYCLES / 4 / SQ_BUSY_CU_CYCLES)\n" % (100 * g["SQ_VALU_MFMA_BUSY_CYCLES"] / 4 / g["SQ_BUSY_CU_CYCLES"]))
-tj = {"config": "bench.py --steps 1 --warmup 1 --no-cpu --beam 53.787 (1000 utt x 10 s x 8 ch per GPU); counters summed over the probe (4 utterances) and two full-batch launches; per-launch = sum / 2",
+tj = {"config": "bench.py --serial --steps 1 --warmup 1 --no-cpu --beam 53.787 (1000 utt x 10 s x 8 ch per GPU); counters summed over the probe (4 utterances) and two full-batch launches; per-launch = sum / 2",
       "collection": "rocprofv3 --kernel-trace --pmc FETCH_SIZE and, in a separate pass, --pmc WRITE_SIZE (tools/round_profiles.sh); unit KB", "kernels": {}}
 notes = {"k_viterbi": "FETCH_SIZE is RDREQ x 64 B; 128-B requests are tallied at 64 B on gfx950 and this kernel's mixed 4/8/16/32-B gathers are not a calibrated pattern: the read part is a lower bound (true value between 1x and 2x)",
          "k_analysis_q256<4, 2>": "16-B/lane streaming reads: FETCH_SIZE doubled (guide, HBM section)",
