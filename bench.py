@@ -256,13 +256,20 @@ def main():
         streams.append(torch.cuda.Stream(device=dev))
     inflight = [False] * npipes
 
-    def finish(i):
+    def collect(i):
         res, arcs, words = pipes[i].collect(reuse=True); inflight[i] = False          # (the host arrays of a pipe are reused step after step)
+        return res, words, pipes[i].stage_ms()
+
+    def gather(r):
         # the path's only exchange: gather the 1-best word sequences on rank 0 (RCCL over xGMI)
         if world > 1:
             from dsr.dist import gather_one_best
-            gather_one_best(words, np.array([r.nWords for r in res], np.int32), world, rank, cdev, dist)
-        return res, words, pipes[i].stage_ms()
+            res, words = r[0], r[1]
+            gather_one_best(words, np.array([q.nWords for q in res], np.int32), world, rank, cdev, dist)
+        return r
+
+    def finish(i):
+        return gather(collect(i))
 
     def submit(i):
         with torch.cuda.stream(streams[i]):
@@ -270,13 +277,16 @@ def main():
         inflight[i] = True
 
     def run_steps(n):
-        """n steps; returns the collected results in step order."""
+        """n steps; returns the collected results in step order.  A pipe object is collected (host wait + copy) before its next step is enqueued;
+        the gather of what it held runs after that enqueue: the collective's kernel needs CUs, which the decode of the step in flight holds until
+        its tail, and the next step's front end should already be queued for that same tail."""
         done = []
         for k in range(n):
             i = k % npipes
-            if inflight[i]:
-                done.append(finish(i))
+            pend = collect(i) if inflight[i] else None
             submit(i)
+            if pend is not None:
+                done.append(gather(pend))
         for k in range(n, n + npipes):                                      # drain in submission order
             i = k % npipes
             if inflight[i]:
