@@ -375,7 +375,7 @@ def main():
                               achieved=round(a / s / (1e9 if byteq else 1e12), 3) if s > 0 else None,
                               unit=("GB/s" if k == "hbm" else "GB/s of HBM bytes (not the bound)") if byteq else "TFLOP/s")
         cpu = None
-        if not args.no_cpu:
+        if not args.no_cpu and world == 1:                               # the CPU baseline is a 1-GPU-run item (rank 0 at N = 1 only)
             try:
                 ncores = len(os.sched_getaffinity(0))
             except AttributeError:
