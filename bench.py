@@ -21,6 +21,8 @@ import time
 
 import numpy as np
 
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # the host driver supports dmabuf IPC only: RCCL across processes needs this (already exported on the pool)
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 PKG = os.path.join(ROOT, "distantspeechrecognition-mirror_amd")
 for p in (ROOT, PKG):
