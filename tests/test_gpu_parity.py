@@ -570,6 +570,60 @@ def test_full_pipe_batch_invariance(dsr, cuda, protos, fused):
         assert nW == resS[0].nWords and np.array_equal(arcsA[u, :nA], arcsS[0, :nA]) and np.array_equal(wordsA[u, :nW], wordsS[0, :nW])
 
 
+def test_pipelined_steps_equal_serial_steps(dsr, cuda, protos):
+    """bench.py's default: two pipe objects on two streams, step k+1 enqueued while step k decodes, results collected later with reused host arrays.
+    Every step's results -- scores, arcs, words, the features -- are those of the same batch run alone on one pipe."""
+    import torch
+    M, m, r, h, g = protos["M256-m4-r1"]
+    Cn, U, n = 8, 40, 6000
+    rng = np.random.default_rng(91)
+    ana = dsr.FilterBank(h, M, m, r, False, 0); syn = dsr.FilterBank(g, M, m, r, True, 0)
+    mp = synth.linear_array(Cn)
+    delays = dsr.calcDelaysPolar2(np.float32(np.deg2rad(30.0)), np.float32(np.pi / 2), mp)
+    bf = dsr.Beamformer(M, Cn); bf.calcArrayManifoldVectors(16000.0, delays); bf.setDiffuseNoiseModel(mp, 16000.0, 343740.0)
+    bf.divideAllNonDiagonalElements(0.01); bf.calcMVDRWeights(16000.0, 1e-8); bf.select("mvdr")
+    lda = (rng.standard_normal((39, 195)) / np.sqrt(195)).astype(np.float32)
+    K = 64
+    gm_m = synth.gmm_model(K, 16, 39, seed=12); gm_m["mean"] *= 3.0
+    gm = dsr.Gmm(**gm_m)
+    arcs, fin = synth.random_wfst(3000, K, seed=21)
+    gd = dsr.Wfst()
+    for a in arcs:
+        gd.add_arc(*a)
+    for st, c in fin:
+        gd.add_final(st, c)
+    batches = [(rng.standard_normal((U, Cn, n)) * 2000.0).astype(np.float32) for _ in range(4)]
+    lens = [n - 5 * (u % 7) for u in range(U)]
+    nd = torch.tensor(lens, dtype=torch.int32, device=cuda)
+
+    def make():
+        dec = dsr.Decoder(beam=60.0, lmScale=12.0, maxActive=16384); dec.set(gd)
+        return dsr.Pipe(ana, syn, bf, dsr.Mfcc(lda=lda), gm, dec, gmmMode=2, fused=True)
+    ref = []
+    p0 = make()
+    for xb in batches:
+        res, arcsO, wordsO = p0.run(torch.from_numpy(xb).to(cuda), nd, lens, maxPath=512)
+        ref.append(([(q.status, q.score, q.nArcs, q.nWords) for q in res], arcsO.copy(), wordsO.copy()))
+    pipes = [make(), make()]; streams = [torch.cuda.Stream(device=cuda), torch.cuda.Stream(device=cuda)]
+    xs = [torch.from_numpy(xb).to(cuda) for xb in batches]
+    torch.cuda.synchronize()
+    got = [None] * len(batches); inflight = [None, None]
+    for k in range(len(batches) + 2):
+        i = k % 2
+        if inflight[i] is not None:
+            res, arcsO, wordsO = pipes[i].collect(reuse=True)
+            got[inflight[i]] = ([(q.status, q.score, q.nArcs, q.nWords) for q in res], arcsO.copy(), wordsO.copy()); inflight[i] = None
+        if k < len(batches):
+            with torch.cuda.stream(streams[i]):
+                pipes[i].submit(xs[k], nd, lens, maxPath=512, want_paths=True)
+            inflight[i] = k
+    for k in range(len(batches)):
+        assert got[k][0] == ref[k][0], k
+        for u in range(U):
+            st, sc, nA, nW = ref[k][0][u]
+            assert st == 0 and np.array_equal(got[k][1][u, :nA], ref[k][1][u, :nA]) and np.array_equal(got[k][2][u, :nW], ref[k][2][u, :nW]), (k, u)
+
+
 @pytest.mark.parametrize("K,R,D", [(256, 16, 39), (1024, 4, 39), (5, 7, 13), (3, 256, 39), (40, 33, 20)])
 def test_gmm_mfma_mode(dsr, oracle, cuda, K, R, D):
     """mode 2 (fp32 MFMA, expanded quadratic): stated tolerance rel 1e-5 on the cost; the nearest Gaussian is the
