@@ -376,6 +376,11 @@ def main():
             stages[nm] = dict(ms=round(tbl_ms[i], 3), bound=k,
                               achieved=round(a / s / (1e9 if byteq else 1e12), 3) if s > 0 else None,
                               unit=("GB/s" if k == "hbm" else "GB/s of HBM bytes (not the bound)") if byteq else "TFLOP/s")
+            if nm == "analysis" and fusedFE and s > 0:
+                # the two stages this kernel replaces, in SURVEY 8d's algorithmic bytes (1544 B per channel-frame + the beamformer's (C + 1) rows per frame)
+                alg2 = U * Cn * T_ana * 1544.0 + U * T_ana * (Cn + 1) * 129 * 8.0
+                stages[nm]["algorithmic_GBs_of_the_two_stages"] = round(alg2 / s / 1e9, 1)
+                stages[nm]["algorithmic_frac_of_hbm"] = round(alg2 / s / 1e9 / HBM_PEAK_GBS, 3)
         cpu = None
         if not args.no_cpu and world == 1:                               # the CPU baseline is a 1-GPU-run item (rank 0 at N = 1 only)
             try:
