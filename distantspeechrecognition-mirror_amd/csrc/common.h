@@ -6,6 +6,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
+#include <memory>
+#include <mutex>
 #include <string>
 #include <vector>
 #include <stdexcept>
@@ -38,14 +41,15 @@ template <class F> static inline dsr_status guard(F&& f) {
 
 void require_device();   // throws DSR_E_INITIALIZATION when no HIP device is usable
 
-// Owning device buffer (grows, never shrinks).
+// Owning device buffer (grows, never shrinks).  Growing frees the old block: a kernel enqueued on ANY stream may still be reading it, so the
+// device is drained first (growth happens on the first call of a shape, never in a steady state).
 template <class T> struct DevBuf {
   T* p = nullptr; size_t n = 0;
   DevBuf() = default; DevBuf(const DevBuf&) = delete; DevBuf& operator=(const DevBuf&) = delete;
   ~DevBuf() { if (p) (void) hipFree(p); }
   void reserve(size_t m) {
     if (m <= n) return;
-    if (p) { DSR_HIP(hipFree(p)); p = nullptr; n = 0; }
+    if (p) { DSR_HIP(hipDeviceSynchronize()); DSR_HIP(hipFree(p)); p = nullptr; n = 0; }
     hipError_t e = hipMalloc((void**) &p, m * sizeof(T));
     if (e != hipSuccess) { p = nullptr; throw Error(DSR_E_ALLOCATION, "hipMalloc of %zu bytes failed: %s", m * sizeof(T), hipGetErrorString(e)); }
     n = m;
@@ -55,7 +59,14 @@ template <class T> struct DevBuf {
     if (m) DSR_HIP(hipMemcpyAsync(p, h, m * sizeof(T), hipMemcpyHostToDevice, s));
     if (m) DSR_HIP(hipStreamSynchronize(s));
   }
-  void upload(const std::vector<T>& v) { upload(v.data(), v.size()); }
+  void upload(const std::vector<T>& v, hipStream_t s = nullptr) { upload(v.data(), v.size(), s); }
+};
+
+// Scratch that a kernel hands to a later kernel of the same stream (work lists, flags, staged weights): one instance per stream, so launches
+// enqueued on different streams -- two pipes in flight -- never share it, and within a stream the launches are ordered.  Never `static`.
+template <class T> struct PerStream {
+  std::mutex mu; std::map<hipStream_t, std::unique_ptr<T>> m;
+  T& at(hipStream_t s) { std::lock_guard<std::mutex> g(mu); std::unique_ptr<T>& p = m[s]; if (!p) p.reset(new T()); return *p; }
 };
 
 // pinned host memory (the target of asynchronous device-to-host copies)

@@ -40,6 +40,7 @@ struct BfState {
   // carried adaptation state (dsr_bf_rls_carry): [entry][U x F] precision matrices + active weights as the last call left them; the next call of
   // the same batch shape continues from it -- block streaming, and the reference's "keeps adapting across reset()" (beamformer.cc:1552-1612)
   bool rlsCarry = false, rlsHaveState = false; int rlsStateU = 0; DevBuf<double2> d_carry;
+  PerStream<DevBuf<float2>> d_wB;   // blockingMatrixOutput's weights, one image per stream
 };
 
 // beamformer.cc:253-305: the reference's pseudo-inverse runs LINPACK's csvdc in complex<float>; svd_linpack.cpp restates that routine
@@ -620,7 +621,7 @@ dsr_status dsr_bf_blocking_matrix_output(dsr_bf* s, const float* X, int U, int T
     if (U <= 0 || Tmax <= 0) return;
     std::vector<float2> w((size_t) F * C);
     for (int f = 0; f < F; f++) for (int c = 0; c < C; c++) { const zc b = s->B[((size_t) f * C + c) * bs + outChanX]; w[(size_t) f * C + c] = make_float2((float) b.real(), (float) b.imag()); }
-    static thread_local DevBuf<float2> dW; dW.upload(w);
+    DevBuf<float2>& dW = s->d_wB.at((hipStream_t) stream); dW.upload(w, (hipStream_t) stream);
     const long perUtt = (long) Tmax * F; const size_t lds = sizeof(float2) * (size_t) F * C;
     DSR_HIP(hipFuncSetAttribute((const void*) k_bf_apply, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
     int gx = cdiv(perUtt, 256 * 4); if (gx < 1) gx = 1; if (gx > 4096) gx = 4096;

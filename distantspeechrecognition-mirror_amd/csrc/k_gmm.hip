@@ -16,27 +16,12 @@
 //           the output bits equal mode 0.
 // This translation unit is compiled with -ffp-contract=off.
 #include "common.h"
+#include "gmm_model.h"
 #include <cmath>
 #include <string>
 
 namespace dsr {
 
-struct GmmModel {
-  int K = 0, D = 0, G = 0, maxRef = 0;
-  std::vector<int> refN, off;
-  std::vector<float> mean, ivar, det, val, scale, pi, count;
-  std::vector<std::string> cbNames, dsNames;
-  DevBuf<int> d_off;                 // [K+1]
-  DevBuf<float> d_mean, d_ivar;      // [G][Dp]  (rows padded to Dp = multiple of 4)
-  DevBuf<float> d_cst;               // [G] pi+det
-  DevBuf<float> d_val, d_scale;      // [G], [K]
-  int Dp = 0;
-  // MFMA operand image (built lazily)
-  bool mfmaReady = false; int KP = 0, GT = 0;
-  DevBuf<float> d_A;                 // [GT][KP/2][64]
-  DevBuf<float> d_bn;                // [G] norm of the expanded Gaussian row
-  DevBuf<int> d_tileCb;              // codebook ids per 32-Gaussian tile (uniform refN=16 path)
-};
 
 // ------------------------------------------------------------------------------------------------
 // mode 0: exact nearest-Gaussian.  Block = 256 threads = 256 frames; loop over codebooks, Gaussian

@@ -9,25 +9,21 @@
 // streams the Gaussian table in 32-row chunks through LDS; the 32x128 tile of distances goes to LDS and one thread
 // per frame walks its rows, keeping the running per-codebook minimum (strict '<': first Gaussian wins, as the
 // reference); scores are staged in LDS and written in contiguous runs.
-// Numerics: fp32 fmaf chain in k order (exact-f32 MFMA); the expanded form differs from the reference's
-// (mu-x)^2*iv accumulation by ~1e-6 relative -- this mode carries the stated GMM tolerance (rel 1e-5), argmin equal to
-// mode 0 except when the two best distances are closer than that.  Mode 0 stays the bit-exact path.
+// Numerics: fp32 fmaf chain in k order (exact-f32 MFMA).  The expanded form is off the reference's (mu-x)^2*iv accumulation by at most
+// (n + 2) 2^-24 S per distance, n = 2 dimN + 1 terms, S = sum of the terms' magnitudes <= 2 ivMax |x|^2 + termMax (gmm_model.h: model-wide
+// maxima, |x|^2 per frame) -- the bound grows with the CANCELLED terms, not with the distance (means far from zero: S >> distance).  Every
+// (frame, codebook) whose two best candidates lie within 1e-5 S (>= twice that bound) of each other, or whose bound is no longer small against
+// the distance itself (1e-5 S > 1e-3 |d|), is re-scored in the reference's own arithmetic over ALL Gaussians of the codebook (k_gmm_ties):
+// argmin = mode 0's on every frame; re-scored entries carry mode 0's score bits, the others agree with mode 0 to rel 2e-6 on
+// well-conditioned models (asserted in tests/test_gpu_parity.py) and to 1e-3 by construction.  Mode 0 stays the bit-exact path.
 #include "common.h"
+#include "gmm_model.h"
 #include <algorithm>
 #include <cmath>
 #include <string>
 
 namespace dsr {
 
-struct GmmModel {      // must mirror k_gmm.hip
-  int K, D, G, maxRef;
-  std::vector<int> refN, off;
-  std::vector<float> mean, ivar, det, val, scale, pi, count;
-  std::vector<std::string> cbNames, dsNames;
-  DevBuf<int> d_off; DevBuf<float> d_mean, d_ivar; DevBuf<float> d_cst; DevBuf<float> d_val, d_scale; int Dp;
-  bool mfmaReady; int KP, GT;
-  DevBuf<float> d_A; DevBuf<float> d_bn; DevBuf<int> d_tileCb;
-};
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -43,30 +39,30 @@ __device__ __noinline__ float exact_dist(const float* __restrict__ xr, const flo
   return d;
 }
 
-// closes a codebook for one frame: near ties between the two best candidates are settled in the reference's own arithmetic
+// closes a codebook for one frame; when the expanded form cannot be trusted (see the header) the whole codebook is re-scored in the reference's arithmetic
 __device__ __noinline__ void gmm_finish(const float* __restrict__ x, long nme, long N, int D, int Dp, const float* __restrict__ mean,
                                         const float* __restrict__ ivar, const float* __restrict__ cst, const float* __restrict__ val,
-                                        float sl, float m1, int a1, float m2, int a2, int cbStart, float* sdst, unsigned char* adst)
+                                        float sl, float m1, int a1, float m2, float thrS, int cbStart, int cbN, float* sdst, unsigned char* adst)
 {
   float best = m1; int ba = a1;
-  if (m2 - m1 <= 1e-4f * (fabsf(m1) + 1.0f) && nme < N) {
-    const float* xr = x + nme * D;
-    const float e1 = exact_dist(xr, mean + (size_t) (cbStart + a1) * Dp, ivar + (size_t) (cbStart + a1) * Dp, cst[cbStart + a1], D);
-    const float e2 = exact_dist(xr, mean + (size_t) (cbStart + a2) * Dp, ivar + (size_t) (cbStart + a2) * Dp, cst[cbStart + a2], D);
-    if (e2 < e1 || (e2 == e1 && a2 < a1)) { best = e2; ba = a2; } else { best = e1; ba = a1; }
+  if ((m2 - m1 <= fmaxf(1e-4f * (fabsf(m1) + 1.0f), thrS) || thrS > 1e-3f * fabsf(m1)) && nme < N) {
+    const float* xr = x + nme * D; best = 0.0f; ba = 0;
+    for (int r = 0; r < cbN; r++) {
+      const float e = exact_dist(xr, mean + (size_t) (cbStart + r) * Dp, ivar + (size_t) (cbStart + r) * Dp, cst[cbStart + r], D);
+      if (r == 0 || e < best) { best = e; ba = r; }
+    }
   }
   float sc = 0.5f * (best + 2.0f * val[cbStart + ba]);
   if (sl != 1.0f) sc *= sl;
   *sdst = sc; *adst = (unsigned char) ba;
 }
 
-// LDS: [Abuf: 2 x S2 x 64 float][tileT: FT x TS float][sbuf: FT x SC float][abuf: FT x SC u8]
 template <int S2>   // S2 = KP/2 MFMA steps
 __global__ __launch_bounds__(256) void k_gmm_mfma(const float* __restrict__ x, long N, int D, int Dp, int K, int G, int nChunks,
                                                   const int* __restrict__ off, const float* __restrict__ Apack,
                                                   const float* __restrict__ mean, const float* __restrict__ ivar, const float* __restrict__ cst,
                                                   const float* __restrict__ val, const float* __restrict__ scale,
-                                                  float* __restrict__ score, unsigned char* __restrict__ argmin)
+                                                  float* __restrict__ score, unsigned char* __restrict__ argmin, float ivMax2, float termMax)
 {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   float* Abuf = reinterpret_cast<float*>(smem);                 // [2][S2][64] double buffered
@@ -94,6 +90,9 @@ __global__ __launch_bounds__(256) void k_gmm_mfma(const float* __restrict__ x, l
       b[t][s] = v;
     }
   }
+  // |x|^2 of the scanning thread's own frame -> 1e-5 S, the trust radius of the expanded form (header)
+  float thrS;
+  { float xx = 0.0f; const long nq = n0 + tid; if (nq < N) for (int d = 0; d < D; d++) { const float q = x[nq * D + d]; xx += q * q; } thrS = 1e-5f * (ivMax2 * xx + termMax); }
   // scan state: thread tid walks the Gaussians of frame n0+tid in order (all threads in lockstep)
   int curK = 0, cbStart = 0, curEnd = __builtin_amdgcn_readfirstlane(off[1]); float m1 = 1E20f, m2 = 1E20f; int a1 = 0, a2 = 0; int kFlush0 = 0;
   const long nme = n0 + tid;
@@ -146,7 +145,7 @@ __global__ __launch_bounds__(256) void k_gmm_mfma(const float* __restrict__ x, l
           m2 = lt1 ? m1 : (lt2 ? v : m2); a2 = lt1 ? a1 : (lt2 ? idx : a2);
           m1 = lt1 ? v : m1; a1 = lt1 ? idx : a1;
           if (g0 + r + 1 == curEnd) {                            // codebook complete (uniform)
-            gmm_finish(x, nme, N, D, Dp, mean, ivar, cst, val, scale[curK], m1, a1, m2, a2, cbStart,
+            gmm_finish(x, nme, N, D, Dp, mean, ivar, cst, val, scale[curK], m1, a1, m2, thrS, cbStart, curEnd - cbStart,
                        sbuf + tid * SC + (curK - kFlush0), abuf + tid * SC + (curK - kFlush0));
             curK++; m1 = 1E20f; m2 = 1E20f; a1 = 0; a2 = 0; cbStart = curEnd;
             curEnd = (curK < K) ? __builtin_amdgcn_readfirstlane(off[curK + 1]) : 0x7FFFFFFF;
@@ -209,30 +208,35 @@ __global__ __launch_bounds__(256) void k_gmm_ties(const unsigned long long* __re
   for (unsigned i0 = 0; i0 < cnt; i0 += ngrp) {                  // (uniform trip count: the exchanges below need every lane of the wave)
     const unsigned i = i0 + grp; const bool live = i < cnt;
     const unsigned long long e = live ? list[(size_t) blockIdx.x * cap + i] : 0ull;
-    const long n = (long) (e >> 32); const int k = (int) ((e >> 16) & 0xFFFFu), a1 = (int) ((e >> 8) & 0xFFu), a2 = (int) (e & 0xFFu);
+    const long n = (long) (e >> 32); const int k = (int) (e & 0xFFFFFFFFull);
     const int cb = k * R; const float* xr = x + n * D;
-    const float* m1 = mean + (size_t) (cb + a1) * Dp; const float* v1 = ivar + (size_t) (cb + a1) * Dp;
-    const float* m2 = mean + (size_t) (cb + a2) * Dp; const float* v2 = ivar + (size_t) (cb + a2) * Dp;
-    float t1[NJ], t2[NJ];
+    float xv[NJ];
 #pragma unroll
-    for (int j = 0; j < NJ; j++) {
-      const int d = l16 + 16 * j; t1[j] = 0.0f; t2[j] = 0.0f;
-      if (live && d < D) {
-        const float xv = xr[d];
-        const float d1 = __fsub_rn(m1[d], xv), d2 = __fsub_rn(m2[d], xv);
-        t1[j] = __fmul_rn(__fmul_rn(d1, d1), v1[d]); t2[j] = __fmul_rn(__fmul_rn(d2, d2), v2[d]);
+    for (int j = 0; j < NJ; j++) { const int d = l16 + 16 * j; xv[j] = (live && d < D) ? xr[d] : 0.0f; }
+    float best = 0.0f; int ba = 0;
+    for (int r0 = 0; r0 < R; r0 += 2) {                          // two Gaussians at a time (R is even): their loads and sums side by side
+      const float* m1 = mean + (size_t) (cb + r0) * Dp; const float* v1 = ivar + (size_t) (cb + r0) * Dp;
+      const float* m2 = m1 + Dp; const float* v2 = v1 + Dp;
+      float t1[NJ], t2[NJ];
+#pragma unroll
+      for (int j = 0; j < NJ; j++) {
+        const int d = l16 + 16 * j; t1[j] = 0.0f; t2[j] = 0.0f;
+        if (live && d < D) {
+          const float d1 = __fsub_rn(m1[d], xv[j]), d2 = __fsub_rn(m2[d], xv[j]);
+          t1[j] = __fmul_rn(__fmul_rn(d1, d1), v1[d]); t2[j] = __fmul_rn(__fmul_rn(d2, d2), v2[d]);
+        }
       }
+      float e1 = live ? cst[cb + r0] : 0.0f, e2 = live ? cst[cb + r0 + 1] : 0.0f;
+#pragma unroll
+      for (int j = 0; j < NJ; j++)
+        for (int q = 0; q < 16; q++) {
+          if (16 * j + q >= D) break;                            // (uniform)
+          e1 = __fadd_rn(e1, __shfl(t1[j], gbase + q, 64)); e2 = __fadd_rn(e2, __shfl(t2[j], gbase + q, 64));
+        }
+      if (r0 == 0 || e1 < best) { best = e1; ba = r0; }          // strict '<' in file order: the first of equals wins (codebookBasic.cc:524-531)
+      if (e2 < best) { best = e2; ba = r0 + 1; }
     }
-    float e1 = live ? cst[cb + a1] : 0.0f, e2 = live ? cst[cb + a2] : 0.0f;
-#pragma unroll
-    for (int j = 0; j < NJ; j++)
-      for (int q = 0; q < 16; q++) {
-        if (16 * j + q >= D) break;                              // (uniform)
-        e1 = __fadd_rn(e1, __shfl(t1[j], gbase + q, 64)); e2 = __fadd_rn(e2, __shfl(t2[j], gbase + q, 64));
-      }
     if (live && l16 == 0) {
-      float best; int ba;
-      if (e2 < e1 || (e2 == e1 && a2 < a1)) { best = e2; ba = a2; } else { best = e1; ba = a1; }
       float sc = 0.5f * (best + 2.0f * val[cb + ba]);
       const float sl = scale[k]; if (sl != 1.0f) sc *= sl;
       score[n * K + k] = sc; if (argmin) argmin[n * K + k] = (unsigned char) ba;
@@ -248,7 +252,8 @@ __global__ __launch_bounds__(256) void k_gmm_mfma_reg(const float* __restrict__ 
                                                       const float* __restrict__ Apack, const float* __restrict__ mean, const float* __restrict__ ivar,
                                                       const float* __restrict__ cst, const float* __restrict__ val, const float* __restrict__ scale, int unitScale,
                                                       float* __restrict__ score, unsigned char* __restrict__ argmin,
-                                                      unsigned long long* __restrict__ tieList, unsigned* __restrict__ tieCount, unsigned tieCap, int valInLds, int dbg)
+                                                      unsigned long long* __restrict__ tieList, unsigned* __restrict__ tieCount, unsigned tieCap, int valInLds, int dbg,
+                                                      float ivMax2, float termMax)
 {
   constexpr int S2 = 4 * S4;
   constexpr int CPC = 32 / R;                                    // codebooks per 32-row chunk
@@ -283,19 +288,30 @@ __global__ __launch_bounds__(256) void k_gmm_mfma_reg(const float* __restrict__ 
       b[t][s] = v;
     }
   }
+  // 1e-5 S per frame of the two tiles (header): |x|^2 is the sum of the operand's squared half, the lane's steps + its partner's
+  float thrS[2];
+#pragma unroll
+  for (int t = 0; t < 2; t++) {
+    float xx = 0.0f;
+#pragma unroll
+    for (int s = 0; s < S2; s++) if (2 * s + kh < D) xx += b[t][s];
+    xx += __shfl_xor(xx, 32, 64);
+    thrS[t] = 1e-5f * (ivMax2 * xx + termMax);
+  }
   const float4* Ap4 = reinterpret_cast<const float4*>(Apack) + lane;
   int kFlush0 = 0;                                               // first codebook of the strip
   // closes one codebook for one frame: score from the best candidate; a near tie goes to the list
-  auto finish = [&](const long nme, const int fr, const int kcb, const float m1, const int a1, const float m2, const int a2) __attribute__((always_inline)) {
+  auto finish = [&](const long nme, const int fr, const int kcb, const float m1, const int a1, const float m2, const float thr) __attribute__((always_inline)) {
     float best = m1; int ba = a1;
-    if (!(dbg & 2) && m2 - m1 <= 1e-4f * (fabsf(m1) + 1.0f) && nme < N) {
+    if (!(dbg & 2) && (m2 - m1 <= fmaxf(1e-4f * (fabsf(m1) + 1.0f), thr) || thr > 1e-3f * fabsf(m1)) && nme < N) {
       const unsigned slot = atomicAdd(&s_tie, 1u);
-      if (slot < tieCap) myList[slot] = ((unsigned long long) nme << 32) | ((unsigned long long) kcb << 16) | ((unsigned long long) a1 << 8) | (unsigned long long) a2;
+      if (slot < tieCap) myList[slot] = ((unsigned long long) nme << 32) | (unsigned long long) (unsigned) kcb;
       else {                                                     // list full: settle it here (cold)
         const int cb = kcb * R; const float* xr = x + nme * D;
-        const float e1 = exact_dist_inl(xr, mean + (size_t) (cb + a1) * Dp, ivar + (size_t) (cb + a1) * Dp, cst[cb + a1], D);
-        const float e2 = exact_dist_inl(xr, mean + (size_t) (cb + a2) * Dp, ivar + (size_t) (cb + a2) * Dp, cst[cb + a2], D);
-        if (e2 < e1 || (e2 == e1 && a2 < a1)) { best = e2; ba = a2; } else { best = e1; ba = a1; }
+        for (int r = 0; r < R; r++) {
+          const float e = exact_dist_inl(xr, mean + (size_t) (cb + r) * Dp, ivar + (size_t) (cb + r) * Dp, cst[cb + r], D);
+          if (r == 0 || e < best) { best = e; ba = r; }
+        }
       }
     }
     float vv;                                                    // (two branches: "valInLds ? valL[i] : val[i]" through one pointer is a FLAT load, which pays
@@ -319,7 +335,7 @@ __global__ __launch_bounds__(256) void k_gmm_mfma_reg(const float* __restrict__ 
         m1 = lt1 ? v : m1; a1 = lt1 ? j : a1;
       }
       if (dbg & 8) { if (m1 + m2 == 123.456f) sbuf[fr] = (float) (a1 + a2); }
-      else if (kcb < K) finish(nme, fr, kcb, m1, a1, m2, a2);
+      else if (kcb < K) finish(nme, fr, kcb, m1, a1, m2, thrS[t]);
     } else {
       constexpr int RH = R / 2;                                  // registers of a codebook in this lane
       const int c = q;                                           // q counts the chunk's codebooks here
@@ -336,10 +352,10 @@ __global__ __launch_bounds__(256) void k_gmm_mfma_reg(const float* __restrict__ 
       const float p1 = __shfl_xor(m1, 32, 64), p2 = __shfl_xor(m2, 32, 64); const int pa = __shfl_xor(a1 | (a2 << 8), 32, 64);
       const int q1 = pa & 255, q2 = pa >> 8;
       auto before = [](float va, int ia, float vb, int ib) { return va < vb || (va == vb && ia < ib); };
-      float r1, r2; int s1, s2;
-      if (before(m1, a1, p1, q1)) { r1 = m1; s1 = a1; if (before(m2, a2, p1, q1)) { r2 = m2; s2 = a2; } else { r2 = p1; s2 = q1; } }
-      else { r1 = p1; s1 = q1; if (before(p2, q2, m1, a1)) { r2 = p2; s2 = q2; } else { r2 = m1; s2 = a1; } }
-      if (kh == (c & 1) && kcb < K) finish(nme, fr, kcb, r1, s1, r2, s2);          // one of the pair closes the codebook
+      float r1, r2; int s1;                                      // (the runner-up's value is all the trust test needs: its index no longer travels)
+      if (before(m1, a1, p1, q1)) { r1 = m1; s1 = a1; r2 = before(m2, a2, p1, q1) ? m2 : p1; }
+      else { r1 = p1; s1 = q1; r2 = before(p2, q2, m1, a1) ? p2 : m1; }
+      if (kh == (c & 1) && kcb < K) finish(nme, fr, kcb, r1, s1, r2, thrS[t]);          // one of the pair closes the codebook
     }
   };
   constexpr int NSRCH = 2 * (R == 4 ? 4 : CPC);                  // search groups per chunk (two tiles)
@@ -402,6 +418,7 @@ void gmm_prepare_mfma(GmmModel& m)
   const int S2 = m.KP / 2;
   m.GT = (m.G + 31) / 32;
   std::vector<float> A((size_t) m.GT * S2 * 64, 0.0f);
+  double ivMax = 0.0, termMax = 0.0;                              // model-wide maxima behind the rounding bound of the expanded form (header)
   for (int g = 0; g < m.G; g++) {
     // codebook of g
     int k = (int) (std::upper_bound(m.off.begin(), m.off.end(), g) - m.off.begin()) - 1;
@@ -410,7 +427,10 @@ void gmm_prepare_mfma(GmmModel& m)
     for (int d = 0; d < m.D; d++) {
       const double iv = m.ivar[(size_t) g * m.D + d], mu = m.mean[(size_t) g * m.D + d];
       row[d] = (float) iv; row[m.D + d] = (float) (-2.0 * mu * iv); c += mu * mu * iv;
+      if (std::fabs(iv) > ivMax) ivMax = std::fabs(iv);
     }
+    { const double c0 = (double) (float) (m.pi[k] + m.det[g]); double q = 0.0; for (int d = 0; d < m.D; d++) { const double iv = m.ivar[(size_t) g * m.D + d], mu = m.mean[(size_t) g * m.D + d]; q += std::fabs(mu * mu * iv); }
+      const double tm = 2.0 * q + std::fabs(c0); if (tm > termMax) termMax = tm; }
     row[2 * m.D] = (float) c;
     const int ch = g / 32, i = g % 32;
     for (int kk = 0; kk < m.KP; kk++) { const int s = kk / 2, kh = kk & 1; A[((size_t) ch * S2 + s) * 64 + kh * 32 + i] = row[kk]; }
@@ -418,6 +438,7 @@ void gmm_prepare_mfma(GmmModel& m)
   // padding rows of the last chunk must never win
   for (int g = m.G; g < m.GT * 32; g++) { const int ch = g / 32, i = g % 32; const int kk = 2 * m.D; A[((size_t) ch * S2 + kk / 2) * 64 + (kk & 1) * 32 + i] = 1E30f; }
   m.d_A.upload(A);
+  m.ivMax = (float) (ivMax * 1.0000002); m.termMax = (float) (termMax * 1.0000002);      // (rounded up)
   {
     // the same operand with four consecutive steps of a lane side by side: A4[(chunk S4 + s4) 64 + lane][j] = A[(chunk S2 + 4 s4 + j) 64 + lane]
     const int S4 = S2 / 4; std::vector<float> A4(A.size());
@@ -442,7 +463,8 @@ void gmm_score_mfma(GmmModel& m, const float* x, long N, float* score, unsigned 
     int unitScale = 1; for (int k = 0; k < m.K; k++) if (m.scale[k] != 1.0f) unitScale = 0;
     // near ties: one list entry each (frame, codebook, two candidates); sized for 1 in 32 (measured: 1 in a few hundred), and a full list
     // is settled in place
-    static thread_local DevBuf<unsigned long long> tieList; static thread_local DevBuf<unsigned> tieCount;
+    GmmTieScratch& ts = m.tie.at(st);                           // this stream's own (two pipes may score with one model on two streams)
+    DevBuf<unsigned long long>& tieList = ts.list; DevBuf<unsigned>& tieCount = ts.count;
     const unsigned nBlk = (unsigned) cdiv(N, FT);
     // per workgroup (256 frames x K codebooks): room for 1 near tie in 32 (measured: 1 in a thousand); a full segment is settled in place
     const unsigned cap = (unsigned) std::min<size_t>(std::max<size_t>((size_t) FT * (size_t) m.K / 32, 256), ((size_t) 1 << 30) / nBlk);
@@ -451,7 +473,7 @@ void gmm_score_mfma(GmmModel& m, const float* x, long N, float* score, unsigned 
     const int dbg = getenv("DSR_GMM_DBG") ? atoi(getenv("DSR_GMM_DBG")) : 0;
 #define LR(SS, RR) { DSR_HIP(hipFuncSetAttribute((const void*) k_gmm_mfma_reg<SS, RR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) ldsR)); \
   hipLaunchKernelGGL((k_gmm_mfma_reg<SS, RR>), gridR, dim3(256), ldsR, st, x, N, m.D, m.Dp, m.K, m.G, m.GT, m.d_bn.p, m.d_mean.p, m.d_ivar.p, m.d_cst.p, m.d_val.p, m.d_scale.p, unitScale, \
-                     score, argmin, tieList.p, tieCount.p, cap, valInLds, dbg); }
+                     score, argmin, tieList.p, tieCount.p, cap, valInLds, dbg, 2.0f * m.ivMax, m.termMax); }
 #define LRS(RR) switch (S4) { case 4: LR(4, RR) break; case 5: LR(5, RR) break; case 9: LR(9, RR) break; case 10: LR(10, RR) break; case 12: LR(12, RR) break; default: LR(17, RR) break; }
     if (R == 4) LRS(4) else if (R == 8) LRS(8) else if (R == 16) LRS(16) else LRS(32)
 #undef LRS
@@ -469,7 +491,7 @@ void gmm_score_mfma(GmmModel& m, const float* x, long N, float* score, unsigned 
   const size_t lds = sizeof(float) * ((size_t) 2 * S2 * 64 + (size_t) FT * TS + (size_t) FT * SC) + (size_t) FT * SC;
   dim3 grid(cdiv(N, FT));
 #define LAUNCH(SS) { DSR_HIP(hipFuncSetAttribute((const void*) k_gmm_mfma<SS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds)); \
-  hipLaunchKernelGGL(k_gmm_mfma<SS>, grid, dim3(256), lds, st, x, N, m.D, m.Dp, m.K, m.G, m.GT, m.d_off.p, m.d_A.p, m.d_mean.p, m.d_ivar.p, m.d_cst.p, m.d_val.p, m.d_scale.p, score, argmin); }
+  hipLaunchKernelGGL(k_gmm_mfma<SS>, grid, dim3(256), lds, st, x, N, m.D, m.Dp, m.K, m.G, m.GT, m.d_off.p, m.d_A.p, m.d_mean.p, m.d_ivar.p, m.d_cst.p, m.d_val.p, m.d_scale.p, score, argmin, 2.0f * m.ivMax, m.termMax); }
   switch (S2) {
     case 16: LAUNCH(16) break; case 20: LAUNCH(20) break; case 36: LAUNCH(36) break;
     case 40: LAUNCH(40) break; case 48: LAUNCH(48) break; default: LAUNCH(68) break;

@@ -314,7 +314,7 @@ dsr_status dsr_wpe_multi(const float* Y_dev, const int32_t* nframes_dev, int U, 
     const size_t lds = (size_t) (PT * PT + 2 * PT) * 16 + (size_t) Nmax * 8 + (size_t) chanN * Nmax * 8;
     if (lds > 150 * 1024) throw Error(DSR_E_DIMENSION, "WPE: %d channels x %d frames x %d taps do not fit the LDS working set", chanN, Nmax, P);
     hipStream_t st = (hipStream_t) stream;
-    static thread_local DevBuf<int> fail; fail.reserve(U); DSR_HIP(hipMemsetAsync(fail.p, 0, sizeof(int) * U, st));
+    static PerStream<DevBuf<int>> failBy; DevBuf<int>& fail = failBy.at(st); fail.reserve(U); DSR_HIP(hipMemsetAsync(fail.p, 0, sizeof(int) * U, st));
     DSR_HIP(hipFuncSetAttribute((const void*) k_wpe_multi, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
     hipLaunchKernelGGL(k_wpe_multi, dim3(F, chanN, U), dim3(256), lds, st, (const float2*) Y_dev, nframes_dev, (double2*) gn_dev, fail.p,
                        U, chanN, Nmax, F, fftLen, lowerN, P, iterationsN, pow(10.0, loadDb / 10.0), lowerBW);

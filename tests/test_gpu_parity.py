@@ -626,8 +626,8 @@ def test_pipelined_steps_equal_serial_steps(dsr, cuda, protos):
 
 @pytest.mark.parametrize("K,R,D", [(256, 16, 39), (1024, 4, 39), (5, 7, 13), (3, 256, 39), (40, 33, 20)])
 def test_gmm_mfma_mode(dsr, oracle, cuda, K, R, D):
-    """mode 2 (fp32 MFMA, expanded quadratic): stated tolerance rel 1e-5 on the cost; the nearest Gaussian is the
-    reference's unless the two best distances differ by less than that (near ties are re-scored in reference order)."""
+    """mode 2 (fp32 MFMA, expanded quadratic): the nearest Gaussian is the reference's on EVERY frame (every codebook whose two best lie inside the
+    rounding bound of the expanded form is re-scored in reference order, all its Gaussians); the cost carries the stated tolerance rel 1e-5."""
     import torch
     m = synth.gmm_model(K, R, D, seed=12)
     rng = np.random.default_rng(11)
@@ -637,9 +637,64 @@ def test_gmm_mfma_mode(dsr, oracle, cuda, K, R, D):
     cb = oracle.Codebooks(m["refN"], m["mean"], m["ivar"], m["det"])
     ref, arg = oracle.gmm_score_opt(cb, m["val"], x)
     sc = sc.cpu().numpy(); am = am.cpu().numpy().astype(np.int32)
-    same = am == arg
-    assert same.mean() > 0.99999
-    assert (np.abs(sc - ref)[same] / np.maximum(np.abs(ref[same]), 1.0)).max() < 1e-5
+    assert np.array_equal(am, arg)
+    assert (np.abs(sc - ref) / np.maximum(np.abs(ref), 1.0)).max() < 1e-5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("K,R,D,mu0,sigma", [(64, 4, 39, 50.0, 0.1), (32, 16, 39, 50.0, 0.1), (24, 8, 13, -300.0, 0.05), (7, 5, 20, 50.0, 0.1), (64, 4, 39, 5.0, 0.5)])
+def test_gmm_mfma_mode_offset_means(dsr, oracle, cuda, K, R, D, mu0, sigma):
+    """Means far from zero with small variances (|mu| / sigma ~ 1e3): the terms the expanded form cancels are ~1e6 times the distance, so its
+    rounding error exceeds the distances themselves.  The trust test scales with the cancelled terms (2 ivMax |x|^2 + termMax), not with the
+    distance: every such (frame, codebook) is re-scored in the reference's arithmetic -- argmin AND score equal mode 0's bits on every frame."""
+    import torch
+    rng = np.random.default_rng(5)
+    m = synth.gmm_model(K, R, D, seed=3)
+    G = m["mean"].shape[0]
+    m["mean"] = (mu0 + sigma * rng.standard_normal((G, D)) * 2.0).astype(np.float32)
+    m["ivar"] = (1.0 / (sigma * rng.uniform(0.7, 1.4, (G, D))) ** 2).astype(np.float32)
+    x = (mu0 + sigma * 2.0 * rng.standard_normal((2500, D))).astype(np.float32)
+    gm = dsr.Gmm(**m)
+    xd = torch.from_numpy(x).to(cuda)
+    sc0, am0 = gm.score(xd, mode=0)
+    sc2, am2 = gm.score(xd, mode=2)
+    cb = oracle.Codebooks(m["refN"], m["mean"], m["ivar"], m["det"])
+    ref, arg = oracle.gmm_score_opt(cb, m["val"], x)
+    assert np.array_equal(am0.cpu().numpy().astype(np.int32), arg) and np.array_equal(sc0.cpu().numpy().view(np.uint32), ref.view(np.uint32))
+    assert torch.equal(am2, am0)
+    if abs(mu0) / sigma >= 100:
+        assert torch.equal(sc2, sc0)                     # all of them went through the exact re-score
+    else:
+        assert float(((sc2 - sc0).abs() / sc0.abs().clamp(min=1.0)).max()) < 1e-5
+
+
+@pytest.mark.gpu
+def test_gmm_mfma_two_streams_do_not_share_scratch(dsr, cuda):
+    """Mode 2 hands its near-tie worklist from the contraction kernel to the re-score kernel of the same stream.  Two inputs scored with ONE model on
+    two streams, stream A held back by a long kernel between the submission and the use of its results while stream B runs through: each input
+    gets the bits of its own serial run (the worklist is owned by the model, one per stream -- csrc/gmm_model.h)."""
+    import torch
+    K, R, D, N = 1024, 4, 39, 60000
+    m = synth.gmm_model(K, R, D, seed=12)
+    gm = dsr.Gmm(**m)
+    g = torch.Generator(device=cuda); g.manual_seed(9)
+    xa = torch.randn((N, D), generator=g, device=cuda); xb = torch.randn((N, D), generator=g, device=cuda) * 1.3
+    ra = gm.score(xa, mode=2); rb = gm.score(xb, mode=2)                      # serial runs, default stream
+    ra = (ra[0].clone(), ra[1].clone()); rb = (rb[0].clone(), rb[1].clone())
+    big = torch.randn((4096, 4096), device=cuda)
+    sA, sB = torch.cuda.Stream(), torch.cuda.Stream()
+    torch.cuda.synchronize()
+    for rep in range(3):
+        with torch.cuda.stream(sA):
+            for _ in range(6):
+                big = torch.tanh(big @ big * 1e-3)                           # a few ms of work ahead of A's scoring
+            oa = gm.score(xa, mode=2)
+        with torch.cuda.stream(sB):
+            ob = gm.score(xb, mode=2)
+            ob2 = gm.score(xb, mode=2)
+        sA.synchronize(); sB.synchronize()
+        assert torch.equal(oa[0], ra[0]) and torch.equal(oa[1], ra[1]), rep
+        assert torch.equal(ob[0], rb[0]) and torch.equal(ob[1], rb[1]) and torch.equal(ob2[0], rb[0]), rep
 
 
 # ------------------------------------------------------------------------------------------- LPC / MVDR envelopes
@@ -1238,7 +1293,7 @@ def test_gmm_full_size(dsr, oracle, cuda):
     ref, arg = oracle.gmm_score_opt(cb, m["val"], x[torch.from_numpy(pick).to(cuda)].cpu().numpy())
     assert np.array_equal(sc.cpu().numpy()[pick].view(np.uint32), ref.view(np.uint32))
     assert np.array_equal(am.cpu().numpy()[pick].astype(np.int32), arg)
-    sc3, am3 = gm.score(x[:50000].contiguous(), mode=2)                  # the MFMA path returns the same bits
+    sc3, am3 = gm.score(x[:50000].contiguous(), mode=2)                  # the MFMA path: mode 0's nearest Gaussian on every frame, the cost to rel 2e-6
     assert torch.equal(am3, am[:50000]) and float((sc3 - sc[:50000]).abs().max() / sc[:50000].abs().max()) < 2e-6
 
 
