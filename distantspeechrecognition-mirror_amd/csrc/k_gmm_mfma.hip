@@ -248,7 +248,7 @@ __global__ __launch_bounds__(256) void k_gmm_ties(const unsigned long long* __re
 // (it is 1.3 MB and lives in L2; one fully coalesced 16-byte load per lane feeds four MFMA pairs; the next chunk's loads are in flight during
 // this chunk's MFMAs), a wave-private LDS strip for the scores.  No workgroup barrier inside the contraction.
 template <int S4, int R>   // S4 = KP/8: contraction steps in groups of four
-__global__ __launch_bounds__(256) void k_gmm_mfma_reg(const float* __restrict__ x, long N, int D, int Dp, int K, int G, int nChunks,
+__global__ __launch_bounds__(256, 2) void k_gmm_mfma_reg(const float* __restrict__ x, long N, int D, int Dp, int K, int G, int nChunks,
                                                       const float* __restrict__ Apack, const float* __restrict__ mean, const float* __restrict__ ivar,
                                                       const float* __restrict__ cst, const float* __restrict__ val, const float* __restrict__ scale, int unitScale,
                                                       float* __restrict__ score, unsigned char* __restrict__ argmin,

@@ -48,7 +48,7 @@ struct Bp { uint32_t prev; uint32_t rec; };
 
 static constexpr uint32_t kNone = 0xFFFFFFFFu;
 static constexpr uint32_t kEndBit = 0x80000000u;
-static constexpr int kThreads = 1024;             // 16 waves per CU at 128 VGPRs (512 x 256 VGPRs: 22 % slower, 768 x 168: 4 % slower)             // 8 waves: 256 VGPRs per thread for the register path
+static constexpr int kThreads = 1024;             // 16 waves per CU at 128 VGPRs (measured in round 2: 512 x 256 VGPRs 22 % slower, 768 x 168 VGPRs 4 % slower; two 512-thread workgroups per CU 1.2x slower)
 static constexpr int kWaves = kThreads / 64;
 static constexpr int kFastK = 8;
 static constexpr int kB = 2;                        // placements whose loads are in flight together (batch of the register-path phases)                  // placements a thread keeps in registers on the register path
@@ -56,7 +56,7 @@ static constexpr int kFastC = 24576;               // most placements per frame 
 static constexpr int kFastE = 8190;                // most expanding tokens per frame on the register path
 static constexpr int kP1 = 16;                     // token rounds per wave in the register path's beam pass
 static constexpr int kW = 4;                        // register placements whose P6 loads are in flight together (8: 3 % slower; parked ones: kB)
-static constexpr int kSideLds = 528;               // later arrivals kept in LDS (the region also holds the slot offsets, dead by then)               // most placements / expanding tokens per frame on the register path
+static constexpr int kSideLds = 496;               // later arrivals kept in LDS (the rest go to memory)
 
 struct GraphDev {
   int nNodes, initial;
@@ -81,6 +81,14 @@ struct DecDev {
   // topN > 0 (decoder.h:571-581): a frame expands the topN best tokens of the list in order of their scores and applies no beam; third token buffer
   int topN; TokA* tokA3; TokB* tokB3;
 };
+
+// every argument of the kernel, one struct in the kernarg segment (read through KP, see k_viterbi)
+struct VitArgs {
+  GraphDev G; DecDev D;
+  const float* scores; const int* nframesArr; int U, Tmax, nDist;
+  dsr_decode_result* res; int* arcsOut; unsigned* wordsOut; int maxPath, useLdsRow, hashN, regionB, cntCap;
+};
+typedef const __attribute__((address_space(4))) VitArgs* KP;
 
 __device__ __forceinline__ unsigned ld_u32(const unsigned* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ int ld_i32(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
@@ -184,6 +192,10 @@ __device__ __forceinline__ float side_score(const Side* sideL, const Side* side,
   else { const Side* p = side + idx; r = __fadd_rn(p->ac, p->lm); }
   return r;
 }
+// "uniform base + 32-bit byte offset": the address form the hardware adds for free (global_load v, v_off, s[base]); a 64-bit element index costs a
+// sign extension, a 64-bit shift and a 64-bit add per access.  Callers guarantee index * sizeof < 2^32 (checked on the host: DecoderState::fastOK).
+template <class T> __device__ __forceinline__ const T* at32(const void* base, uint32_t byteOff) { return reinterpret_cast<const T*>(reinterpret_cast<const char*>(base) + byteOff); }
+template <class T> __device__ __forceinline__ T* at32w(void* base, uint32_t byteOff) { return reinterpret_cast<T*>(reinterpret_cast<char*>(base) + byteOff); }
 // wave-uniform values computed from LDS land in vector registers; these move them to scalar ones
 __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
 __device__ __forceinline__ double uni(double v) { return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)), __builtin_amdgcn_readfirstlane(__double2loint(v))); }
@@ -197,20 +209,28 @@ __device__ __forceinline__ unsigned f2ord(float f) { const unsigned u = __float_
 //     tokens are compacted first (slot offsets in LDS), recombination goes through the LDS state table, and only the
 //     later arrivals at an occupied state (a few percent) are spilled to memory for the first arrival to fold;
 //   * the memory path (any size, and the end expansion): placements are staged in global arrays, one thread per placement.
-__global__ __launch_bounds__(kThreads) void k_viterbi(GraphDev G, DecDev Dd, const float* __restrict__ scores,
-                                                      const int* __restrict__ nframesArr, int U, int Tmax, int nDist,
-                                                      dsr_decode_result* __restrict__ res, int* __restrict__ arcsOut,
-                                                      unsigned* __restrict__ wordsOut, int maxPath, int useLdsRow, int hashN, int regionB, int cntCap)
+template <int MODES>
+__global__ __launch_bounds__(kThreads) void k_viterbi(const VitArgs argsInKernarg)
 {
+  // The arguments are read from the kernarg segment where they are used, through a pointer that is made opaque again at every phase boundary
+  // (RELOAD): a field is a scalar load from the constant cache in the phase that needs it and dead after it.  Taken by value the two structs are
+  // ~130 scalar registers that live from the first instruction to the last; with the per-slot pointers and loop state derived from them the kernel
+  // needed 444 more scalars than the 102 a wave has, and every use in the hot phases was a v_readlane reload from a spill lane.
+  (void) argsInKernarg;
+  constexpr bool PROF = (MODES & 1) != 0, EXTRA = (MODES & 2) != 0;      // EXTRA: lattice bookkeeping, topN, token dump compiled in
+  const KP KA = (KP) __builtin_amdgcn_kernarg_segment_ptr();
+  KP ka = KA;
+#define RELOAD() do { ka = KA; asm volatile("" : "+s"(ka)); } while (0)
+  RELOAD();
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   float* srow = reinterpret_cast<float*>(smem);                       // [nDist] when useLdsRow
   // per-frame open-addressing table in LDS: destination state -> first-arrival slot (hashN buckets, 0 = unused).
   // Global atomics execute at the memory side on gfx950 (no L2 residency); the LDS table keeps the recombination
   // traffic on chip.  Frames with more placements than the table can take fall back to the tagged global table.
+  const int useLdsRow = ka->useLdsRow, nDist = ka->nDist, hashN = ka->hashN, regionB = ka->regionB, cntCap = ka->cntCap;   // (the LDS layout: live for the whole kernel)
   unsigned* hkey = reinterpret_cast<unsigned*>(srow + (useLdsRow ? ((nDist + 3) & ~3) : 4));
   unsigned* hfirst = hkey + hashN;
-  unsigned short* eoff = reinterpret_cast<unsigned short*>(hfirst + hashN);     // [kFastC + 2] slot offset of every expanding token (register path)
-  Side* sideL = reinterpret_cast<Side*>(hfirst + hashN);                        // [regionB / 32] same region, used after the expansion
+  Side* sideL = reinterpret_cast<Side*>(hfirst + hashN);                        // [regionB / 32] later arrivals at an occupied state
   // [cntCap] expansion counts of the list P6 wrote, by list position: the next frame's P1 scans them without waiting for the tokens to come back from memory
   unsigned short* cntL = reinterpret_cast<unsigned short*>(reinterpret_cast<unsigned char*>(hfirst + hashN) + regionB);
   __shared__ int s_waveTot[kWaves];
@@ -221,59 +241,70 @@ __global__ __launch_bounds__(kThreads) void k_viterbi(GraphDev G, DecDev Dd, con
   __shared__ int s_sideN;
   __shared__ int s_tb[2];            // traceback: hops, words
   __shared__ unsigned s_bm[kFastC / 32];             // register path: slots where an expanding token's run starts
-  __shared__ unsigned short s_gbase[kFastC / 64 + 4]; // register path: expanding tokens that start before each group of 64 slots
+  // register path, per group of 64 slots: expanding tokens that start before the group (13 bits) | how far into its token's run the group's first slot is (19 bits)
+  __shared__ unsigned s_gbase[kFastC / 64 + 4];
   __shared__ int s_cnt[(kFastK + 32) * kWaves];
   __shared__ int s_err;             // register path: first arrivals per (k, wave) group, then their exclusive prefix
   __shared__ long long s_prof[32]; __shared__ long long s_tlast;
-  if (threadIdx.x < 32) s_prof[threadIdx.x] = 0;
-#define TICK(ix) do { if (Dd.prof && tid == 0) { const long long tn = (long long) wall_clock64(); s_prof[ix] += tn - s_tlast; s_tlast = tn; } } while (0)
-  const int nthr = blockDim.x, nw = nthr >> 6;      // 256 or 512 threads
+  // per-utterance statistics and the cold loop state (thread 0 updates them once per frame; they used to ride in scalar registers through every phase)
+  __shared__ long long s_stat[3];    // activeHypos, placements, registerFrames
+  __shared__ int s_maxActive; __shared__ unsigned s_tag; __shared__ long long s_latOff;
+  if (PROF && threadIdx.x < 32) s_prof[threadIdx.x] = 0;
+#define TICK(ix) do { if (PROF && tid == 0) { const long long tn = (long long) wall_clock64(); s_prof[ix] += tn - s_tlast; s_tlast = tn; } } while (0)
+  constexpr int nthr = kThreads, nw = kWaves;
   __shared__ int s_u;
 
   const int tid = threadIdx.x;
   const int slot = blockIdx.x;
-  TokA* tokA0 = Dd.tokA + (size_t) slot * 2 * Dd.maxTok; TokA* tokA1 = tokA0 + Dd.maxTok;
-  TokB* tokB0 = Dd.tokB + (size_t) slot * 2 * Dd.maxTok; TokB* tokB1 = tokB0 + Dd.maxTok;
-  TokA* ctok = Dd.ctok + (size_t) slot * 8192;
-  Side* side = Dd.side + (size_t) slot * kFastC;
-  // (the staging arrays of the memory path are addressed where that path starts: their base pointers would otherwise sit in
-  // scalar registers through every frame of the register path, which is short of them)
-  CandA* cA = Dd.cA + (size_t) slot * Dd.maxCand; CandB* cB = Dd.cB + (size_t) slot * Dd.maxCand;
+  // token lists: buffers 0 and 1 of the slot (current / next, swapped every frame), buffer 2 the spare of topN mode; pointers are formed where they are used
+#define TOKA(ix) ((EXTRA && (ix) == 2) ? ka->D.tokA3 + (size_t) slot * ka->D.maxTok : ka->D.tokA + ((size_t) slot * 2 + (size_t) (ix)) * ka->D.maxTok)
+#define TOKB(ix) ((EXTRA && (ix) == 2) ? ka->D.tokB3 + (size_t) slot * ka->D.maxTok : ka->D.tokB + ((size_t) slot * 2 + (size_t) (ix)) * ka->D.maxTok)
+#define curA TOKA(bufCur)
+#define nxtA TOKA(bufNxt)
+#define curB TOKB(bufCur)
+#define nxtB TOKB(bufNxt)
+#define sprA TOKA(bufSpr)
+#define sprB TOKB(bufSpr)
+#define ctok (ka->D.ctok + (size_t) slot * 8192)
+#define side (ka->D.side + (size_t) slot * kFastC)
+  // (the staging arrays of the memory path)
+#define cA (ka->D.cA + (size_t) slot * ka->D.maxCand)
+#define cB (ka->D.cB + (size_t) slot * ka->D.maxCand)
   // first[] holds (tag << 24 | slot); tags count DOWN so every entry of an older frame compares larger and never
   // needs resetting; the table is wiped when the 8-bit tag runs out (and on the very first use of a slot)
-  unsigned tag = Dd.tags[slot];
-  Bp* arena = Dd.arena + (size_t) slot * Dd.arenaCap;                 // (lattice mode: one per utterance, set below)
-  const int fastCapC = ((kFastK + 32) * nthr < kFastC) ? (kFastK + 32) * nthr : kFastC;
-  const int fastCapN = kP1 * 64 * nw;                                   // kP1 rounds of 64 tokens per wave
-  const bool fastOK = Dd.fastOK && hashN >= 8192;
+  if (tid == 0) s_tag = ka->D.tags[slot];
+  // back pointers: one arena per slot (lattice mode: one per utterance -- they outlive the slot: the host builds the lattice from them)
+#define arena (ka->D.arena + (size_t) ((EXTRA && ka->D.latOn) ? u : slot) * ka->D.arenaCap)
+#define sc (ka->scores + (size_t) u * ka->Tmax * nDist)
+  constexpr int fastCapC = ((kFastK + 32) * nthr < kFastC) ? (kFastK + 32) * nthr : kFastC;
+  constexpr int fastCapN = kP1 * 64 * nw;                                   // kP1 rounds of 64 tokens per wave
+  const bool fastOK = ka->D.fastOK && hashN >= 8192;
   // capacities that follow from the LDS budget of this launch: table (load <= 0.75 per pass), slot offsets, LDS side records
-  const int tableC = (hashN >> 1) + (hashN >> 2), eCap = (regionB >> 1) - 2 < kFastE ? (regionB >> 1) - 2 : kFastE, sideLds = regionB >> 5;
+  const int tableC = (hashN >> 1) + (hashN >> 2), eCap = kFastE, sideLds = regionB >> 5;
 
   for (;;) {
     __syncthreads();
-    if (tid == 0) s_u = atomicAdd(Dd.queue, 1);
+    if (tid == 0) s_u = atomicAdd(ka->D.queue, 1);
     __syncthreads();
+    RELOAD();
     const int u = s_u;
-    if (u >= U) break;
-    if (Dd.latOn) arena = Dd.arena + (size_t) u * Dd.arenaCap;       // the back pointers outlive the slot: the host builds the lattice from them
-    long latOff = 0;
-    if (Dd.latOn && tid == 0) Dd.latFrameOff[(size_t) u * (Tmax + 3)] = 0;
-    if (Dd.prof && tid == 0) { const long long tn = (long long) wall_clock64(); if (s_prof[15]) s_prof[10] += tn - s_prof[15]; s_tlast = tn; }
-    const int T = nframesArr[u] < Tmax ? nframesArr[u] : Tmax;
-    const float* sc = scores + (size_t) u * Tmax * nDist;
-    const bool dump = Dd.dumpOn && slot == 0;
+    if (u >= ka->U) break;
+    if (EXTRA && ka->D.latOn && tid == 0) ka->D.latFrameOff[(size_t) u * (ka->Tmax + 3)] = 0;
+    if (PROF && tid == 0) { const long long tn = (long long) wall_clock64(); if (s_prof[15]) s_prof[10] += tn - s_prof[15]; s_tlast = tn; }
+    const int T = ka->nframesArr[u] < ka->Tmax ? ka->nframesArr[u] : ka->Tmax;
+#define dump (EXTRA && ka->D.dumpOn && slot == 0)
+    if (tid == 0) { s_stat[0] = 0; s_stat[1] = 0; s_stat[2] = 0; s_maxActive = 0; s_latOff = 0; }
 
     int status = DSR_OK;
     if (T <= 0) status = DSR_E_ITERATOR;         // no frame at all: the exception escapes decode() (decoder.h:691)
 
-    TokA* curA = tokA0; TokA* nxtA = tokA1; TokB* curB = tokB0; TokB* nxtB = tokB1;
-    TokA* sprA = Dd.topN > 0 ? Dd.tokA3 + (size_t) slot * Dd.maxTok : nullptr; TokB* sprB = Dd.topN > 0 ? Dd.tokB3 + (size_t) slot * Dd.maxTok : nullptr;
-    int n = 1; long arenaOff = 0; long activeHypos = 0; long placements = 0; int maxActive = 0; long regFrames = 0;
+    int bufCur = 0, bufNxt = 1, bufSpr = 2;
+    int n = 1; long arenaOff = 0;
     double thresh = HUGE_VAL, topScore = HUGE_VAL;
     for (int i = tid; i < 2 * hashN; i += nthr) hkey[i] = (i < hashN) ? 0u : 0xFFFFFFFFu;
     if (tid == 0) {
-      TokA t0; t0.ac = 0.0f; t0.lm = 0.0f; t0.bp = kNone; t0.xs = (uint32_t) G.xoff[G.initial]; curA[0] = t0;
-      TokB b0; b0.node = G.initial; b0.cnt = G.xoff[G.initial + 1] - G.xoff[G.initial]; curB[0] = b0;
+      TokA t0; t0.ac = 0.0f; t0.lm = 0.0f; t0.bp = kNone; t0.xs = (uint32_t) ka->G.xoff[ka->G.initial]; curA[0] = t0;
+      TokB b0; b0.node = ka->G.initial; b0.cnt = ka->G.xoff[ka->G.initial + 1] - ka->G.xoff[ka->G.initial]; curB[0] = b0;
     }
     __syncthreads();
 
@@ -284,12 +315,11 @@ __global__ __launch_bounds__(kThreads) void k_viterbi(GraphDev G, DecDev Dd, con
     TICK(11);
     // frames 0..T-1 (mode 0), then the end expansion (mode 1)
     for (int fr = 0; fr <= T && status == DSR_OK; fr++) {
-#ifndef DSR_V_NOOPAQUE
+      RELOAD();
       // the thread index behind an opaque copy, once per frame: nothing derived from it (lane masks, per-thread addresses of any
       // phase or of the memory path) can be hoisted out of the frame loop, where it would sit in scratch memory and be re-read
       int tidO = (int) threadIdx.x; asm volatile("" : "+v"(tidO));
       const int tid = tidO, lane = tid & 63, wave = tid >> 6;
-#endif
       const int mode = (fr == T) ? 1 : 0;
       if (mode == 0 && useLdsRow) {
         if (preRow) {
@@ -306,8 +336,9 @@ __global__ __launch_bounds__(kThreads) void k_viterbi(GraphDev G, DecDev Dd, con
       const float* rowG = sc + (size_t) fr * nDist;                            // the frame's score row in memory
       int numNew = 0, numStat = -1;                                           // tokens written to the new list / tokens the reference's list would hold
       if (fr > 0) TICK(23);                                                   // end of the frame before -> here
-      if (Dd.prof && tid == 0) s_tlast = (long long) wall_clock64();
-      bool fast = fastOK && mode == 0 && n <= fastCapN && !Dd.latOn && Dd.topN <= 0;          // lattice bookkeeping needs every placement in memory: the memory path has them
+      if (PROF && tid == 0) s_tlast = (long long) wall_clock64();
+      bool fast = fastOK && mode == 0 && n <= fastCapN && !(EXTRA && (ka->D.latOn || ka->D.topN > 0));   // lattice bookkeeping needs every placement in memory: the memory path has them
+      int Cfr = 0;                                                             // placements of this frame (statistics)
 
       if (fast) {
         // ======================= register path =======================
@@ -377,19 +408,20 @@ __global__ __launch_bounds__(kThreads) void k_viterbi(GraphDev G, DecDev Dd, con
           // into a population count
           // (when every token expands -- the rule once the lists are pruned at write time -- compact index == list index and the
           // list itself serves as the compact list: no copy)
+          RELOAD();
           const bool ident = (E == n);
           const TokA* __restrict__ ctk = ident ? curA : ctok;
 #pragma unroll
           for (int it = 0; it < kP1; it++) if (pk[it] & 0x80000000u) {
             const int e = ebase + (int) ((pk[it] >> 15) & 0xFFFFu); const int off = cbase + (int) (pk[it] & 0x7FFFu);
-            eoff[e] = (unsigned short) off;
             if (!ident) ctok[e] = curA[wave * chunkT + it * 64 + lane];
             atomicOr(&s_bm[off >> 5], 1u << (off & 31));
-            for (int g = (off >> 6) + 1; g <= ((off + pcn[it]) >> 6); g++) s_gbase[g] = (unsigned short) (e + 1);   // this token covers slot 64g-1
+            for (int g = (off >> 6) + 1; g <= ((off + pcn[it]) >> 6); g++) s_gbase[g] = (unsigned) (e + 1) | ((unsigned) (64 * g - off) << 13);   // this token covers slot 64g-1
           }
           __syncthreads();
           TICK(1);
-          placements += C; regFrames++;
+          Cfr = C;
+          RELOAD();
           // (tq/lq/wq = tid/lane/wave behind an opaque copy: keeps the per-slot address arithmetic of the unrolled phases inside
           // the frame loop -- hoisted out of it, those hundred-odd invariants would live in scratch memory)
           int tq = tid; asm volatile("" : "+v"(tq)); const int lq = tq & 63, wq = tq >> 6;
@@ -399,12 +431,13 @@ __global__ __launch_bounds__(kThreads) void k_viterbi(GraphDev G, DecDev Dd, con
           // registers for the whole frame; slots beyond (one more batch of eight) are parked in memory between the phases.
           const int K = (C + nthr - 1) / nthr;
           float qac[kFastK], qlm[kFastK]; int qrec[kFastK]; unsigned ek[kFastK];
-          double* ttlS = reinterpret_cast<double*>(cA);                        // unrounded totals, read back by later arrivals only
-          uint4* ovf = reinterpret_cast<uint4*>(cB);                           // parked placements [slot - kFastK * nthr]
+          double* const ttlS = reinterpret_cast<double*>(cA);                  // unrounded totals, read back by later arrivals only
+          uint4* const ovf = reinterpret_cast<uint4*>(cB);                     // parked placements [slot - kFastK * nthr]
+          const XRecD* const xrecD = ka->G.xrecD; const float* const pathCost = ka->G.pathCost; const uint32_t silenceX = ka->D.silenceX;
           double locMin = HUGE_VAL; float locMag = 0.0f;                       // locMag: largest |ac| + |lm| of the frame's placements (bounds the rounding of a score, see P4)
           const bool prevNull0 = (fr == 0);                                    // only the start token has no edge (decoder.h:960)
-          const double lmS = Dd.lmScale, lsPen = __dmul_rn(Dd.lmScale, Dd.lmPenalty), lsSil = __dmul_rn(Dd.lmScale, Dd.silPenalty);
-          const bool sil0 = (0u == Dd.silenceX);
+          const double lmS = ka->D.lmScale, lsPen = __dmul_rn(ka->D.lmScale, ka->D.lmPenalty), lsSil = __dmul_rn(ka->D.lmScale, ka->D.silPenalty);
+          const bool sil0 = (0u == silenceX);
 #pragma unroll
           for (int k = 0; k < kFastK; k++) { qac[k] = 0.0f; qlm[k] = 0.0f; qrec[k] = 0; ek[k] = 0u; }
 
@@ -415,7 +448,7 @@ __global__ __launch_bounds__(kThreads) void k_viterbi(GraphDev G, DecDev Dd, con
             for (;;) {
               const unsigned kk = atomicCAS(&hkey[h], 0u, key);
               if (kk == 0u || kk == key) break;
-              h = (h + 1u) & (unsigned) (hashN - 1);
+              h = (h + 1u) & (unsigned) (hashN - 1);                           // (triangular steps instead of linear ones: 16.5 vs 16.6 ms, nothing)
               if (++probes > hashN) { s_err = 1; break; }                      // table full: cannot happen below its capacity; fail loudly, never spin
             }
             atomicMin(&hfirst[h], (unsigned) c);
@@ -428,13 +461,16 @@ __global__ __launch_bounds__(kThreads) void k_viterbi(GraphDev G, DecDev Dd, con
             unsigned e = 0u; int j = 0;
             if (c < C) {
               const unsigned long long W = ((unsigned long long) s_bm[2 * grp + 1] << 32) | s_bm[2 * grp];
-              e = (unsigned) s_gbase[grp] + (unsigned) __popcll(W & ((2ull << lq) - 1ull)) - 1u;
-              j = c - (int) eoff[e];
+              const unsigned gb = s_gbase[grp]; const unsigned long long mine = W & ((2ull << lq) - 1ull);
+              e = (gb & 0x1FFFu) + (unsigned) __popcll(mine) - 1u;
+              // position in the token's run: slots since the run's start -- inside this group (highest start bit at or below the lane), or carried in from
+              // the group before (no second, dependent LDS read of the token's slot offset)
+              j = mine ? lq - (63 - __clzll((long long) mine)) : lq + (int) (gb >> 13);
             }
             ekk = e; rec = j;
           };
           auto tokload = [&](float& ac, float& lm, int& rec, unsigned& ekk) __attribute__((always_inline)) {
-            const TokA t = ctk[ekk];
+            const TokA t = *at32<TokA>(ctk, ekk * 16u);
             ac = t.ac; lm = t.lm; rec += (int) (t.xs & 0x7FFFFFFFu); ekk |= (t.xs >> 31) << 29;
           };
           auto expandR = [&](const int g8, float* ac8, float* lm8, int* rec8, unsigned* ek8) __attribute__((always_inline)) {
@@ -443,8 +479,9 @@ __global__ __launch_bounds__(kThreads) void k_viterbi(GraphDev G, DecDev Dd, con
             for (int i = 0; i < kB; i++) { tsil[i] = (ek8[i] >> 29) & 1u; ek8[i] &= 0x1FFFu; }
 #pragma unroll
             for (int i = 0; i < kB; i++) {                                      // eight record loads in flight
-              xr[i] = *reinterpret_cast<const int4*>(&G.xrecD[rec8[i]]); xd[i] = *reinterpret_cast<const int2*>(&G.xrecD[rec8[i]].dst);
+              xr[i] = *at32<int4>(xrecD, (uint32_t) rec8[i] * 32u); xd[i] = *at32<int2>(xrecD, (uint32_t) rec8[i] * 32u + 16u);
             }
+            if (PROF) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); TICK(28); }
 #pragma unroll
             for (int i = 0; i < kB; i++) {
               const int c = (g8 + i) * nthr + tq;
@@ -467,45 +504,51 @@ __global__ __launch_bounds__(kThreads) void k_viterbi(GraphDev G, DecDev Dd, con
                 const bool pinSil = has ? sil0 : tsil[i];                      // after an epsilon hop the edge input is 0
                 if (plen > 1) {
                   if (!(xmeta & 0x80000000u)) {
+                    float hc0 = 0.0f, hc1 = 0.0f, hc2 = 0.0f;                  // three and four hops (and the head of longer paths): their costs in flight together
+                    if (plen > 2) { const float* pc = pathCost + xd[i].y; hc0 = pc[0]; hc1 = pc[1]; hc2 = pc[(plen > 3) ? 2 : 1]; }
                     for (int h = 1; h < plen; h++) {                           // hop costs: inline (two hops) or one independent load per hop
-                      const float ch = (plen == 2) ? __int_as_float(xd[i].y) : G.pathCost[xd[i].y + h - 1];
+                      const float ch = (plen == 2) ? __int_as_float(xd[i].y) : (h == 1 ? hc0 : h == 2 ? hc1 : h == 3 ? hc2 : pathCost[xd[i].y + h - 1]);
                       double l = __dadd_rn(lmNode, __dmul_rn(lmS, (double) ch));
                       if ((xmeta >> (17 + h)) & 1u) l = __dadd_rn(l, lsPen);
                       lmNode = (double) (float) l;                              // (the edge before is an epsilon edge: no silence penalty possible here)
                     }
                   } else {
-                    const int* pp = G.path + G.xpathOff[rec8[i]];
+                    const int* pp = ka->G.path + ka->G.xpathOff[rec8[i]];
                     for (int h = 1; h < plen; h++) {
                       const int a = pp[h];
-                      double l = __dadd_rn(lmNode, __dmul_rn(lmS, (double) G.arcCost[a]));
-                      if (G.arcOut[a] != 0) l = __dadd_rn(l, lsPen);
+                      double l = __dadd_rn(lmNode, __dmul_rn(lmS, (double) ka->G.arcCost[a]));
+                      if (ka->G.arcOut[a] != 0) l = __dadd_rn(l, lsPen);
                       lmNode = (double) (float) l;
                     }
                   }
                 }
                 double lm = __dadd_rn(lmNode, __dmul_rn(lmS, (double) xcost));
                 { const double lm1 = __dadd_rn(lm, lsPen); lm = (xmeta & 0x10000u) ? lm1 : lm; }
-                const bool silArc = ((uint32_t) (xdist + 1) == Dd.silenceX);
+                const bool silArc = ((uint32_t) (xdist + 1) == silenceX);
                 { const double lm2 = __dadd_rn(lm, lsSil); lm = (silArc && (pnull || !pinSil)) ? lm2 : lm; }
                 float rowv;                                                    // (two branches, not "useLdsRow ? srow[..] : rowG[..]": that is one FLAT load)
                 if (useLdsRow) { rowv = ((const lds_float_t*) srow)[xdist]; DSR_NO_MERGE(); } else rowv = rowG[xdist];
                 const double ac = __dadd_rn((double) ac8[i], (double) rowv);
                 const double ttl = __dadd_rn(ac, lm);
-                ttlS[c] = ttl; ac8[i] = (float) ac; lm8[i] = (float) lm; rec8[i] |= (silArc ? 0x40000000 : 0);
+                *at32w<double>(ttlS, (uint32_t) c * 8u) = ttl; ac8[i] = (float) ac; lm8[i] = (float) lm; rec8[i] |= (silArc ? 0x40000000 : 0);
                 if (ttl < locMin) locMin = ttl;                                // _topScore
                 locMag = fmaxf(locMag, __fadd_rn(fabsf(ac8[i]), fabsf(lm8[i])));
                 // state table: claim the bucket, keep the smallest slot (with two passes, the other half of the states waits)
+                if (PROF) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); TICK(29); }
                 const unsigned prod = (unsigned) xd[i].x * 2654435761u;
                 if (nPass > 1 && (prod >> 31)) ek8[i] |= 1u << 27;
                 else ek8[i] |= (table_insert((unsigned) xd[i].x, prod, c) << 13) | (1u << 28);      // bit28: in the table, not folded yet
+                if (PROF) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); TICK(30); }
               }
             }
           };
           auto expand8 = [&](const int g8, float* ac8, float* lm8, int* rec8, unsigned* ek8) __attribute__((always_inline)) {
 #pragma unroll
             for (int i = 0; i < kB; i++) locate(g8 + i, rec8[i], ek8[i]);
+            if (PROF) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); TICK(26); }
 #pragma unroll
             for (int i = 0; i < kB; i++) tokload(ac8[i], lm8[i], rec8[i], ek8[i]);
+            if (PROF) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); TICK(27); }
             expandR(g8, ac8, lm8, rec8, ek8);
           };
 #pragma unroll
@@ -540,7 +583,8 @@ __global__ __launch_bounds__(kThreads) void k_viterbi(GraphDev G, DecDev Dd, con
           // (decoder.h:586-588) and is never looked at again: it is counted (activeHypos, maxActive) but neither written to the list
           // nor to the back-pointer arena.  The order of the tokens that stay is unchanged, so the next frame's arrival slots are too.
           // Not on the last frame (the end expansion takes every token) and not when the lists are dumped.
-          const double threshNext = __dadd_rn(topScore, Dd.beam);
+          RELOAD();
+          const double threshNext = __dadd_rn(topScore, ka->D.beam);
           const bool prune = !dump && (fr + 1 < T);
           // A LATER arrival that far above the threshold cannot touch a token that stays: a token that stays has score <= threshNext, and its
           // unrounded total (what the recombination compares, decoder.h:519-528) is within 2^-23 (|ac| + |lm|) of its score, so it beats
@@ -621,7 +665,7 @@ __global__ __launch_bounds__(kThreads) void k_viterbi(GraphDev G, DecDev Dd, con
           auto insert8 = [&](const int g8, const int* rec8, unsigned* ek8) __attribute__((always_inline)) {
             int xd[kB];
 #pragma unroll
-            for (int i = 0; i < kB; i++) xd[i] = G.xrecD[rec8[i] & 0x3FFFFFFF].dst;
+            for (int i = 0; i < kB; i++) xd[i] = ka->G.xrecD[rec8[i] & 0x3FFFFFFF].dst;
 #pragma unroll
             for (int i = 0; i < kB; i++) {
               const int c = (g8 + i) * nthr + tq;
@@ -738,6 +782,10 @@ __global__ __launch_bounds__(kThreads) void k_viterbi(GraphDev G, DecDev Dd, con
           TICK(13);
           __syncthreads();
           TICK(14);
+          {                                                                    // every chain has been folded: the state table is dead.  Wiped here, under wave 0's prefix sum
+            uint4* h4 = reinterpret_cast<uint4*>(hkey); const int q4 = hashN >> 2;
+            for (int i = tq; i < 2 * q4; i += nthr) { unsigned wv = (i < q4) ? 0u : 0xFFFFFFFFu; asm volatile("" : "+v"(wv)); h4[i] = make_uint4(wv, wv, wv, wv); }
+          }
           if (wq == 0) {                                                       // exclusive prefix over (k, wave) = slot order of the groups
             const int nG = K * nw;                                             // <= 6 * 64
             int a[6], tot = 0;
@@ -752,7 +800,9 @@ __global__ __launch_bounds__(kThreads) void k_viterbi(GraphDev G, DecDev Dd, con
           TICK(6);
           numNew = uni(s_waveTot[0]);
           { const int a = (lq < nw) ? s_waveTotE[lq] : 0; numStat = __builtin_amdgcn_readlane(wave_incl_scan(a, lq), 63); }
-          if (numNew > Dd.maxTok || arenaOff + numNew > Dd.arenaCap) { status = DSR_E_ALLOCATION; break; }
+          RELOAD();
+          if (numNew > ka->D.maxTok || arenaOff + numNew > ka->D.arenaCap) { status = DSR_E_ALLOCATION; break; }
+          const XRecD* const xrecW = ka->G.xrecD; TokA* const outA = nxtA; TokB* const outB = nxtB; Bp* const outBp = arena + arenaOff;
           // ---- P6: the new list in reverse first-arrival order + back pointers; the state table is wiped for the next frame
           auto write4 = [&](auto NB, const int g4, const float* ac4, const float* lm4, const int* rec4, const unsigned* ek4) __attribute__((always_inline)) {
             constexpr int nb = decltype(NB)::value;
@@ -760,7 +810,7 @@ __global__ __launch_bounds__(kThreads) void k_viterbi(GraphDev G, DecDev Dd, con
 #pragma unroll
             for (int i = 0; i < nb; i++) {                                      // unconditional loads (every index is in bounds), in flight together;
               const bool kp = (keepMask >> (g4 + i)) & 1ull;                   // placements that are not written all read record 0 / token 0 (one line)
-              dx[i] = *reinterpret_cast<const int4*>(&G.xrecD[kp ? (rec4[i] & 0x3FFFFFFF) : 0].dst);       // same state for every arrival
+              dx[i] = *reinterpret_cast<const int4*>(&xrecW[kp ? (rec4[i] & 0x3FFFFFFF) : 0].dst);       // same state for every arrival
               const bool sw = kp && (ek4[i] & 0x80000000u) != 0u; const unsigned si = ek4[i] & 0x7FFFFFFFu;
               const uint32_t* pb = (sw && si >= (unsigned) sideLds) ? &side[si].prevBp : &ctk[(sw || !kp) ? 0u : (ek4[i] & 0x1FFFu)].bp;
               pv[i] = *pb;
@@ -777,12 +827,66 @@ __global__ __launch_bounds__(kThreads) void k_viterbi(GraphDev G, DecDev Dd, con
                   TokA na; na.ac = ac4[i]; na.lm = lm4[i]; na.bp = (uint32_t) (arenaOff + pos); na.xs = (uint32_t) dx[i].z | ((rec4[i] & 0x40000000) ? 0x80000000u : 0u);
                   TokB nb; nb.node = dx[i].x; nb.cnt = dx[i].w;
                   Bp bp; bp.prev = pv[i]; bp.rec = (uint32_t) (rec4[i] & 0x3FFFFFFF);
-                  nxtA[pos] = na; nxtB[pos] = nb; arena[arenaOff + pos] = bp;
+                  outA[pos] = na; outB[pos] = nb; outBp[pos] = bp;
                   if (pos < cntCap) cntL[pos] = (unsigned short) dx[i].w;
                 }
               }
             }
           };
+          // Three placements in four are not written (pruned, or later arrivals): the ones that are go through the (wiped) state table as a dense
+          // list -- {ac, lm, record, where the parent's back pointer is} at its rank -- and the loads and stores of the write run over that list,
+          // every lane at work, instead of over all slots with a quarter of the lanes.  A thread restores the table words it has read.
+          const bool dense = numNew <= (hashN >> 1);
+          if (dense) {
+            uint4* const stage = reinterpret_cast<uint4*>(hkey);
+            auto stage1 = [&](const int k, const float ac, const float lm, const int rec, const unsigned ekk) __attribute__((always_inline)) {
+              const bool isFirst = (keepMask >> k) & 1ull;
+              const unsigned long long bal = __ballot(isFirst);
+              if (isFirst) stage[s_cnt[k * nw + wq] + __popcll(bal & ((1ull << lq) - 1ull))] = make_uint4(__float_as_uint(ac), __float_as_uint(lm), (unsigned) rec, ekk);
+            };
+#pragma unroll
+            for (int k = 0; k < kFastK; k++) if (k < K) stage1(k, qac[k], qlm[k], qrec[k], ek[k]);
+            for (int kb = kFastK; kb < K; kb += kB) {
+              float oac[kB], olm[kB]; int orec[kB]; unsigned oek[kB]; park_load(kb, oac, olm, orec, oek);
+#pragma unroll
+              for (int i = 0; i < kB; i++) if (kb + i < K) stage1(kb + i, oac[i], olm[i], orec[i], oek[i]);
+            }
+            __syncthreads();
+            TICK(21);
+            const int q4 = hashN >> 2;
+            for (int f0 = 0; f0 < numNew; f0 += 2 * nthr) {
+              uint4 en[2]; int4 dx[2]; uint32_t pv[2];
+#pragma unroll
+              for (int i = 0; i < 2; i++) {
+                const int f = f0 + i * nthr + tq; const bool on = f < numNew;
+                en[i] = stage[on ? f : 0];
+                if (on) { unsigned wv = (f < q4) ? 0u : 0xFFFFFFFFu; asm volatile("" : "+v"(wv)); stage[f] = make_uint4(wv, wv, wv, wv); }
+              }
+#pragma unroll
+              for (int i = 0; i < 2; i++) {
+                const bool on = f0 + i * nthr + tq < numNew;
+                dx[i] = *at32<int4>(xrecW, (on ? (en[i].z & 0x3FFFFFFFu) : 0u) * 32u + 16u);
+                const bool sw = on && (en[i].w & 0x80000000u) != 0u; const unsigned si = en[i].w & 0x7FFFFFFFu;
+                const uint32_t* pb = (sw && si >= (unsigned) sideLds) ? &side[si].prevBp : &ctk[(sw || !on) ? 0u : (en[i].w & 0x1FFFu)].bp;
+                pv[i] = *pb;
+                if (sw && si < (unsigned) sideLds) pv[i] = sideL[si].prevBp;
+              }
+#pragma unroll
+              for (int i = 0; i < 2; i++) {
+                const int f = f0 + i * nthr + tq;
+                if (f < numNew) {
+                  const int pos = numNew - 1 - f;
+                  TokA na; na.ac = __uint_as_float(en[i].x); na.lm = __uint_as_float(en[i].y); na.bp = (uint32_t) (arenaOff + pos); na.xs = (uint32_t) dx[i].z | ((en[i].z & 0x40000000u) ? 0x80000000u : 0u);
+                  TokB nb; nb.node = dx[i].x; nb.cnt = dx[i].w;
+                  Bp bp; bp.prev = pv[i]; bp.rec = (uint32_t) (en[i].z & 0x3FFFFFFFu);
+                  outA[pos] = na; outB[pos] = nb; outBp[pos] = bp;
+                  if (pos < cntCap) cntL[pos] = (unsigned short) dx[i].w;
+                }
+              }
+            }
+            TICK(22);
+          } else
+          {
 #pragma unroll
           for (int g4 = 0; g4 < kFastK; g4 += kW) if (g4 < K) write4(std::integral_constant<int, kW>{}, g4, &qac[g4], &qlm[g4], &qrec[g4], &ek[g4]);
           for (int kb = kFastK; kb < K; kb += kB) {
@@ -790,26 +894,27 @@ __global__ __launch_bounds__(kThreads) void k_viterbi(GraphDev G, DecDev Dd, con
             write4(std::integral_constant<int, kB>{}, kb, oac, olm, orec, oek);
           }
           TICK(21);
-          {
-            uint4* h4 = reinterpret_cast<uint4*>(hkey); const int q4 = hashN >> 2;
-            for (int i = tid; i < 2 * q4; i += nthr) { unsigned wv = (i < q4) ? 0u : 0xFFFFFFFFu; asm volatile("" : "+v"(wv)); h4[i] = make_uint4(wv, wv, wv, wv); }   /* (opaque: a hoisted constant vector lived through the whole frame loop, partly in scratch) */
-          }
           TICK(22);
+          }
           cntOK = prune && numNew <= cntCap;
         }
       }
       if (!fast) {
       cntOK = false;
       // ======================= memory path =======================
-      int* tokOff = Dd.tokOff + (size_t) slot * (Dd.maxTok + 1);
-      int* tokCnt = Dd.tokCnt + (size_t) slot * (Dd.maxTok + 1);
-      int* chead = Dd.chead + (size_t) slot * Dd.maxCand;
-      int* owner = Dd.owner + (size_t) slot * Dd.maxCand;
-      int* rank = Dd.rank + (size_t) slot * Dd.maxCand;
-      unsigned* first = Dd.first + (size_t) slot * G.nNodes;
-      if (tag <= 1u) { for (int i = tid; i < G.nNodes; i += nthr) first[i] = 0xFFFFFFFFu; tag = 255u; __syncthreads(); } else tag--;
+      RELOAD();
+      int* tokOff = ka->D.tokOff + (size_t) slot * (ka->D.maxTok + 1);
+      int* tokCnt = ka->D.tokCnt + (size_t) slot * (ka->D.maxTok + 1);
+      int* chead = ka->D.chead + (size_t) slot * ka->D.maxCand;
+      int* owner = ka->D.owner + (size_t) slot * ka->D.maxCand;
+      int* rank = ka->D.rank + (size_t) slot * ka->D.maxCand;
+      unsigned* first = ka->D.first + (size_t) slot * ka->G.nNodes;
+      unsigned tag = s_tag;
+      __syncthreads();                                                         // (every thread has read the tag before thread 0 replaces it)
+      if (tag <= 1u) { for (int i = tid; i < ka->G.nNodes; i += nthr) first[i] = 0xFFFFFFFFu; tag = 255u; __syncthreads(); } else tag--;
+      if (tid == 0) s_tag = tag;
       const unsigned tagw = tag << 24;
-      const bool sorted = Dd.topN > 0 && mode == 0 && fr > 0;
+      const bool sorted = EXTRA && ka->D.topN > 0 && mode == 0 && fr > 0;
       if (sorted) {
         // SortedIterator (decoder.h:298-320): the list sorted by the tokens' float scores (ties: list order -- std::sort leaves them unspecified),
         // of which _processFrame expands the first topN (:571-581).  Rank by counting: the lists of this mode are short (topN tokens' expansions).
@@ -819,13 +924,13 @@ __global__ __launch_bounds__(kThreads) void k_viterbi(GraphDev G, DecDev Dd, con
         for (int i = tid; i < n; i += nthr) {
           const unsigned long long ki = keys[i]; int rk = 0;
           for (int j = 0; j < n; j++) rk += (keys[j] < ki) ? 1 : 0;
-          if (rk < Dd.topN) { sprA[rk] = curA[i]; sprB[rk] = curB[i]; }
+          if (rk < ka->D.topN) { sprA[rk] = curA[i]; sprB[rk] = curB[i]; }
         }
         __syncthreads();
-        { TokA* ta = curA; curA = sprA; sprA = ta; TokB* tb = curB; curB = sprB; sprB = tb; }
-        n = n < Dd.topN ? n : Dd.topN;
+        { const int t = bufCur; bufCur = bufSpr; bufSpr = t; }
+        n = n < ka->D.topN ? n : ka->D.topN;
       }
-      const double threshM = (Dd.topN > 0) ? HUGE_VAL : thresh;                // topN mode: no beam
+      const double threshM = (EXTRA && ka->D.topN > 0) ? HUGE_VAL : thresh;       // topN mode: no beam
       // ---------------- phase A: per-token placement counts, wave-local exclusive scan
       const int chunkT = ((n + nw * 64 - 1) / (nw * 64)) * 64;
       {
@@ -838,7 +943,7 @@ __global__ __launch_bounds__(kThreads) void k_viterbi(GraphDev G, DecDev Dd, con
             if (mode == 0) {
               const float s = __fadd_rn(ta.ac, ta.lm);
               if (!((double) s > threshM)) cnt = tb.cnt;                       // beam (decoder.h:586-588)
-            } else cnt = (G.nodeFinal[tb.node] ? 1 : 0) + (G.eoff[tb.node + 1] - G.eoff[tb.node]);
+            } else cnt = (ka->G.nodeFinal[tb.node] ? 1 : 0) + (ka->G.eoff[tb.node + 1] - ka->G.eoff[tb.node]);
           }
           const int incl = wave_incl_scan(cnt, lane);
           if (i < b1) { tokOff[i] = running + incl - cnt; tokCnt[i] = cnt; }
@@ -849,9 +954,9 @@ __global__ __launch_bounds__(kThreads) void k_viterbi(GraphDev G, DecDev Dd, con
       __syncthreads();
       int C = 0;
       for (int w = 0; w < nw; w++) C += s_waveTot[w];
-      if (C > Dd.maxCand) { status = DSR_E_ALLOCATION; break; }
-      if (Dd.latOn && latOff + C > Dd.latCap) { status = DSR_E_ALLOCATION; break; }
-      placements += C;
+      if (C > ka->D.maxCand) { status = DSR_E_ALLOCATION; break; }
+      if (EXTRA && ka->D.latOn && s_latOff + C > ka->D.latCap) { status = DSR_E_ALLOCATION; break; }
+      Cfr = C;
       const bool useHash = hashN > 0 && C <= (hashN >> 1) + (hashN >> 2);        // load factor <= 0.75 even if every placement is a new state
       // ---------------- phase A2: absolute offsets + owner fill
       for (int i = tid; i < n; i += nthr) {
@@ -872,42 +977,42 @@ __global__ __launch_bounds__(kThreads) void k_viterbi(GraphDev G, DecDev Dd, con
         const int j = c - tokOff[i];
         double ac = (double) t.ac, lm; int dst, recId; bool silArc = false;
         if (mode == 0) {
-          recId = (int) (ta.xs & 0x7FFFFFFFu) + j; const XRec x = G.xrec[recId];
+          recId = (int) (ta.xs & 0x7FFFFFFFu) + j; const XRec x = ka->G.xrec[recId];
           const int plen = (int) (x.meta & 0xFFFFu);
-          double lmNode = (double) t.lm; uint32_t prevIn = tokSil ? Dd.silenceX : (Dd.silenceX + 1u);   // only equality with silenceX matters
+          double lmNode = (double) t.lm; uint32_t prevIn = tokSil ? ka->D.silenceX : (ka->D.silenceX + 1u);   // only equality with silenceX matters
           bool prevNull = (t.bp == kNone) && (fr == 0);
           if (plen) {
-            const int* pp = G.path + G.xpathOff[recId];
+            const int* pp = ka->G.path + ka->G.xpathOff[recId];
             for (int h = 0; h < plen; h++) {                                   // intermediate epsilon tokens (decoder.h:979-983)
               const int a = pp[h];
-              double l = __dadd_rn(lmNode, __dmul_rn(Dd.lmScale, (double) G.arcCost[a]));
-              if (G.arcOut[a] != 0) l = __dadd_rn(l, __dmul_rn(Dd.lmScale, Dd.lmPenalty));
-              if (0u == Dd.silenceX && (prevNull || prevIn != Dd.silenceX)) l = __dadd_rn(l, __dmul_rn(Dd.lmScale, Dd.silPenalty));
+              double l = __dadd_rn(lmNode, __dmul_rn(ka->D.lmScale, (double) ka->G.arcCost[a]));
+              if (ka->G.arcOut[a] != 0) l = __dadd_rn(l, __dmul_rn(ka->D.lmScale, ka->D.lmPenalty));
+              if (0u == ka->D.silenceX && (prevNull || prevIn != ka->D.silenceX)) l = __dadd_rn(l, __dmul_rn(ka->D.lmScale, ka->D.silPenalty));
               lmNode = (double) (float) l; prevIn = 0u; prevNull = false;
             }
           }
-          lm = __dadd_rn(lmNode, __dmul_rn(Dd.lmScale, (double) x.cost));
-          if (x.meta & 0x10000u) lm = __dadd_rn(lm, __dmul_rn(Dd.lmScale, Dd.lmPenalty));
-          if ((uint32_t) (x.dist + 1) == Dd.silenceX && (prevNull || prevIn != Dd.silenceX)) lm = __dadd_rn(lm, __dmul_rn(Dd.lmScale, Dd.silPenalty));
+          lm = __dadd_rn(lmNode, __dmul_rn(ka->D.lmScale, (double) x.cost));
+          if (x.meta & 0x10000u) lm = __dadd_rn(lm, __dmul_rn(ka->D.lmScale, ka->D.lmPenalty));
+          if ((uint32_t) (x.dist + 1) == ka->D.silenceX && (prevNull || prevIn != ka->D.silenceX)) lm = __dadd_rn(lm, __dmul_rn(ka->D.lmScale, ka->D.silPenalty));
           ac = __dadd_rn(ac, (double) (useLdsRow ? srow[x.dist] : rowG[x.dist]));
-          dst = x.dst; silArc = ((uint32_t) (x.dist + 1) == Dd.silenceX);
+          dst = x.dst; silArc = ((uint32_t) (x.dist + 1) == ka->D.silenceX);
         } else {
-          const int hasSelf = G.nodeFinal[nd] ? 1 : 0;
+          const int hasSelf = ka->G.nodeFinal[nd] ? 1 : 0;
           if (hasSelf && j == 0) {                                             // _expandToEnd self placement (decoder.h:506-509)
-            const float lmf = (float) __dadd_rn((double) t.lm, __dmul_rn(Dd.lmScale, (double) G.nodeCost[nd]));
+            const float lmf = (float) __dadd_rn((double) t.lm, __dmul_rn(ka->D.lmScale, (double) ka->G.nodeCost[nd]));
             lm = (double) lmf; dst = nd; recId = (int) 0x7FFFFFFE;
           } else {
-            recId = G.eoff[nd] + (j - hasSelf); const ERec e = G.erec[recId];
-            const int* pp = G.path + e.pathOff; double lmNode = (double) t.lm; double l = lmNode;
-            uint32_t prevIn = tokSil ? Dd.silenceX : (Dd.silenceX + 1u);
+            recId = ka->G.eoff[nd] + (j - hasSelf); const ERec e = ka->G.erec[recId];
+            const int* pp = ka->G.path + e.pathOff; double lmNode = (double) t.lm; double l = lmNode;
+            uint32_t prevIn = tokSil ? ka->D.silenceX : (ka->D.silenceX + 1u);
             for (int h = 0; h < e.pathLen; h++) {                              // _expandNodeToEnd (decoder.h:992-1015)
               const int a = pp[h];
-              l = __dadd_rn(lmNode, __dmul_rn(Dd.lmScale, (double) G.arcCost[a]));
-              if (G.arcOut[a] != 0) l = __dadd_rn(l, __dmul_rn(Dd.lmScale, Dd.lmPenalty));
-              if (0u == Dd.silenceX && prevIn != Dd.silenceX) l = __dadd_rn(l, __dmul_rn(Dd.lmScale, Dd.silPenalty));
+              l = __dadd_rn(lmNode, __dmul_rn(ka->D.lmScale, (double) ka->G.arcCost[a]));
+              if (ka->G.arcOut[a] != 0) l = __dadd_rn(l, __dmul_rn(ka->D.lmScale, ka->D.lmPenalty));
+              if (0u == ka->D.silenceX && prevIn != ka->D.silenceX) l = __dadd_rn(l, __dmul_rn(ka->D.lmScale, ka->D.silPenalty));
               lmNode = (double) (float) l; prevIn = 0u;
             }
-            lm = __dadd_rn(l, __dmul_rn(Dd.lmScale, (double) G.nodeCost[e.lastSrc]));
+            lm = __dadd_rn(l, __dmul_rn(ka->D.lmScale, (double) ka->G.nodeCost[e.lastSrc]));
             dst = e.dst; recId = (int) ((uint32_t) recId | kEndBit);
           }
         }
@@ -945,8 +1050,8 @@ __global__ __launch_bounds__(kThreads) void k_viterbi(GraphDev G, DecDev Dd, con
       // ---------------- phase C1: fold per destination state (by its first-arrival thread), count new tokens
       const int chunkC = ((C + nw * 64 - 1) / (nw * 64)) * 64;
       // (as on the register path: tokens above this frame's best emitting total + beam are counted but not written)
-      const double threshNextM = __dadd_rn(topScore, Dd.beam);
-      const bool pruneM = !dump && mode == 0 && (fr + 1 < T) && Dd.topN <= 0;
+      const double threshNextM = __dadd_rn(topScore, ka->D.beam);
+      const bool pruneM = !dump && mode == 0 && (fr + 1 < T) && !(EXTRA && ka->D.topN > 0);
       {
         int running = 0, runAll = 0;
         const int b0 = wave * chunkC, b1 = (b0 + chunkC < C) ? b0 + chunkC : C;
@@ -979,7 +1084,7 @@ __global__ __launch_bounds__(kThreads) void k_viterbi(GraphDev G, DecDev Dd, con
       __syncthreads();
       numStat = 0;
       for (int w = 0; w < nw; w++) { numNew += s_waveTot[w]; numStat += s_waveTotE[w]; }
-      if (numNew > Dd.maxTok || arenaOff + numNew > Dd.arenaCap) { status = DSR_E_ALLOCATION; break; }
+      if (numNew > ka->D.maxTok || arenaOff + numNew > ka->D.arenaCap) { status = DSR_E_ALLOCATION; break; }
       // ---------------- phase C2: write the new token list (reverse first-arrival order) + back pointers
       {
         int wbase = 0; for (int q = 0; q < wave; q++) wbase += s_waveTot[q];
@@ -992,9 +1097,9 @@ __global__ __launch_bounds__(kThreads) void k_viterbi(GraphDev G, DecDev Dd, con
               const CandB bc = cB[c];
               const int pos = numNew - 1 - (wbase + rank[c]);
               const CandA aw = cA[w]; const CandB bw = (w == c) ? bc : cB[w]; const int recW = (bw.rec & 0x3FFFFFFF) | (bw.rec & (int) 0x80000000);
-              const int xo = G.xoff[bc.dst];
+              const int xo = ka->G.xoff[bc.dst];
               TokA na; na.ac = aw.ac; na.lm = aw.lm; na.bp = (uint32_t) (arenaOff + pos); na.xs = (uint32_t) xo;
-              TokB nb; nb.node = bc.dst; nb.cnt = G.xoff[bc.dst + 1] - xo;
+              TokB nb; nb.node = bc.dst; nb.cnt = ka->G.xoff[bc.dst + 1] - xo;
               Bp bp;
               if (mode == 0) {
                 if (bw.rec & 0x40000000) na.xs |= 0x80000000u;
@@ -1004,41 +1109,43 @@ __global__ __launch_bounds__(kThreads) void k_viterbi(GraphDev G, DecDev Dd, con
                 else { bp.prev = bw.prevBp; bp.rec = (uint32_t) bw.rec; }
               }
               nxtA[pos] = na; nxtB[pos] = nb; arena[arenaOff + pos] = bp;
-              if (Dd.latOn) Dd.arenaLat[(size_t) u * Dd.arenaCap + arenaOff + pos] = (int) (latOff + w);
+              if (EXTRA && ka->D.latOn) ka->D.arenaLat[(size_t) u * ka->D.arenaCap + arenaOff + pos] = (int) (s_latOff + w);
             }
           }
         }
       }
-      if (Dd.latOn) {                                                          // this frame's placements, arrival order
-        uint4* lat = Dd.lat + (size_t) u * Dd.latCap; double* ltt = Dd.latTtl + (size_t) u * Dd.latCap;
+      if (EXTRA && ka->D.latOn) {                                                 // this frame's placements, arrival order
+        uint4* lat = ka->D.lat + (size_t) u * ka->D.latCap; double* ltt = ka->D.latTtl + (size_t) u * ka->D.latCap;
+        const long latOff = (long) s_latOff;
         for (int c = tid; c < C; c += nthr) {
           const CandA a = cA[c]; const CandB b = cB[c];
           lat[latOff + c] = make_uint4(__float_as_uint(a.ac), __float_as_uint(a.lm), (unsigned) b.rec, b.prevBp); ltt[latOff + c] = a.ttl;
         }
-        latOff += C;
-        if (tid == 0) Dd.latFrameOff[(size_t) u * (Tmax + 3) + fr + 1] = latOff;
+        __syncthreads();                                                       // (every thread has read the offset before thread 0 advances it)
+        if (tid == 0) { s_latOff = latOff + C; ka->D.latFrameOff[(size_t) u * (ka->Tmax + 3) + fr + 1] = latOff + C; }
       }
       }   // memory path
       __syncthreads();
       TICK(fast ? 7 : 8);
+      RELOAD();
       if (mode == 0) {
         if (dump) {
-          long* cnt = Dd.dumpCount; const long o = cnt[0];
-          if (o + numNew <= Dd.dumpCap) {
+          long* cnt = ka->D.dumpCount; const long o = cnt[0];
+          if (o + numNew <= ka->D.dumpCap) {
             for (int i = tid; i < numNew; i += nthr) {
-              const TokA t = ld_tok(&nxtA[i]); Dd.dumpNode[o + i] = nxtB[i].node; Dd.dumpAc[o + i] = t.ac; Dd.dumpLm[o + i] = t.lm;
-              Dd.dumpArc[o + i] = G.xarc[arena[t.bp].rec];
+              const TokA t = ld_tok(&nxtA[i]); ka->D.dumpNode[o + i] = nxtB[i].node; ka->D.dumpAc[o + i] = t.ac; ka->D.dumpLm[o + i] = t.lm;
+              ka->D.dumpArc[o + i] = ka->G.xarc[arena[t.bp].rec];
             }
           }
           __syncthreads();
-          if (tid == 0) { Dd.dumpFrameOff[fr] = o; Dd.dumpFrameOff[fr + 1] = o + numNew; cnt[0] = o + numNew; cnt[1] = fr + 1; }
+          if (tid == 0) { ka->D.dumpFrameOff[fr] = o; ka->D.dumpFrameOff[fr + 1] = o + numNew; cnt[0] = o + numNew; cnt[1] = fr + 1; }
         }
         if (numStat < 0) numStat = numNew;                                     // memory path: every new token is written
         if (numStat == 0 || numNew == 0) { status = DSR_E_CONSISTENCY; break; } // no token can be expanded in the next frame: the reference never terminates from here
-        { TokA* tmp = curA; curA = nxtA; nxtA = tmp; TokB* tmb = curB; curB = nxtB; nxtB = tmb; }
+        { const int t = bufCur; bufCur = bufNxt; bufNxt = t; }
         n = numNew; arenaOff += numNew;
-        activeHypos += numStat; if (numStat > maxActive) maxActive = numStat;
-        thresh = __dadd_rn(topScore, Dd.beam);
+        if (tid == nthr - 1) { s_stat[0] += numStat; s_stat[1] += Cfr; if (fast) s_stat[2] += 1; if (numStat > s_maxActive) s_maxActive = numStat; }   // (off wave 0's path: it carries the prefix sums)
+        thresh = __dadd_rn(topScore, ka->D.beam);
       } else {
         // ---------------- best token (decoder.h:639-685): list order, strict '<' on the float score
         const TokA* lst = numNew > 0 ? nxtA : curA; const int cntL = numNew > 0 ? numNew : n;
@@ -1049,22 +1156,23 @@ __global__ __launch_bounds__(kThreads) void k_viterbi(GraphDev G, DecDev Dd, con
         }
         key = wave_min_u64(key);
         if (lane == 0) s_waveKey[wave] = key;
-        if (Dd.latOn) {                                                        // _next after _expandToEnd (or _current when no token is final), list order
-          const TokB* lstB = numNew > 0 ? nxtB : curB; int4* lf = Dd.latFinal + (size_t) u * Dd.maxTok;
+        if (EXTRA && ka->D.latOn) {                                               // _next after _expandToEnd (or _current when no token is final), list order
+          const TokB* lstB = numNew > 0 ? nxtB : curB; int4* lf = ka->D.latFinal + (size_t) u * ka->D.maxTok;
           for (int i = tid; i < cntL; i += nthr) { const TokA t = ld_tok(&lst[i]); lf[i] = make_int4(lstB[i].node, (int) t.bp, __float_as_int(t.ac), __float_as_int(t.lm)); }
-          if (tid == 0) { int* li = Dd.latInfo + 4 * (size_t) u; li[0] = cntL; li[1] = numNew > 0 ? 1 : 0; li[2] = (int) (arenaOff + (numNew > 0 ? numNew : 0)); li[3] = T; }
+          if (tid == 0) { int* li = ka->D.latInfo + 4 * (size_t) u; li[0] = cntL; li[1] = numNew > 0 ? 1 : 0; li[2] = (int) (arenaOff + (numNew > 0 ? numNew : 0)); li[3] = T; }
         }
         __syncthreads();
         // traceback (bestHypo, decoder.h:748-773).  One thread follows the back pointers (one dependent 8-byte load per frame) and
         // leaves the hop records in scratch memory; everything else -- arcs per hop, their places in the list, the word sequence --
         // is done by the whole workgroup with two prefix sums.
-        int* hopRec = reinterpret_cast<int*>(cB); const int hopCap = 2 * Dd.maxCand; int* hopOff = hopRec + hopCap;
+        int* hopRec = reinterpret_cast<int*>(cB); const int hopCap = 2 * ka->D.maxCand; int* hopOff = hopRec + hopCap;
         // (the result record is written by thread 0 alone and lives in memory between its two steps: as a register struct of every thread it was
         // a block of zeros carried -- and spilled -- through the whole kernel)
         if (tid == 0) {
+          dsr_decode_result* const res = ka->res;
           clear_result(&res[u]); dsr_decode_result& r = res[u];
           unsigned long long k = ~0ull; for (int w = 0; w < nw; w++) if (s_waveKey[w] < k) k = s_waveKey[w];
-          r.frames = T - 1; r.reachedFinal = numNew > 0 ? 1 : 0; r.finalStatesN = numNew; /* every token of _next after _expandToEnd sits in a final state */ r.activeHypos = activeHypos; r.placements = placements; r.registerFrames = regFrames; r.maxActiveSeen = maxActive; r.status = DSR_OK;
+          r.frames = T - 1; r.reachedFinal = numNew > 0 ? 1 : 0; r.finalStatesN = numNew; /* every token of _next after _expandToEnd sits in a final state */ r.activeHypos = (long) s_stat[0]; r.placements = (long) s_stat[1] + Cfr; r.registerFrames = (long) s_stat[2]; r.maxActiveSeen = s_maxActive; r.status = DSR_OK;
           int nH = 0;
           if (k != ~0ull) {
             const TokA bt = ld_tok(&lst[(unsigned) (k & 0xFFFFFFFFu)]);
@@ -1087,22 +1195,23 @@ __global__ __launch_bounds__(kThreads) void k_viterbi(GraphDev G, DecDev Dd, con
         int nA = 0;
         for (int b0 = 0; b0 < nH; b0 += nthr) {                                  // arcs per hop; hopOff = arcs of the hops walked before (= later in time)
           const int i = b0 + tid; int len = 0;
-          if (i < nH) { const uint32_t rc = (uint32_t) hopRec[i]; len = (rc & kEndBit) ? G.erec[rc & ~kEndBit].pathLen : (int) (G.xrec[rc].meta & 0xFFFFu) + 1; }
+          if (i < nH) { const uint32_t rc = (uint32_t) hopRec[i]; len = (rc & kEndBit) ? ka->G.erec[rc & ~kEndBit].pathLen : (int) (ka->G.xrec[rc].meta & 0xFFFFu) + 1; }
           int total; const int ex = block_excl(len, total);
           if (i < nH) hopOff[i] = nA + ex;
           nA += total;
         }
+        int* const arcsOut = ka->arcsOut; unsigned* const wordsOut = ka->wordsOut; const int maxPath = ka->maxPath; dsr_decode_result* const res = ka->res;
         int* ao = arcsOut ? arcsOut + (size_t) u * maxPath : nullptr;
         int nWloc = 0;
         for (int i = tid; i < nH; i += nthr) {                                   // every hop writes its arcs, first..last
           const uint32_t rc = (uint32_t) hopRec[i]; int pos = nA - hopOff[i];
           if (rc & kEndBit) {
-            const ERec e = G.erec[rc & ~kEndBit];
-            for (int h = e.pathLen - 1; h >= 0; h--) { const int a = G.path[e.pathOff + h]; pos--; if (ao && pos < maxPath) ao[pos] = a; if (G.arcOut[a] != 0) nWloc++; }
+            const ERec e = ka->G.erec[rc & ~kEndBit];
+            for (int h = e.pathLen - 1; h >= 0; h--) { const int a = ka->G.path[e.pathOff + h]; pos--; if (ao && pos < maxPath) ao[pos] = a; if (ka->G.arcOut[a] != 0) nWloc++; }
           } else {
-            const int a = G.xarc[rc]; pos--; if (ao && pos < maxPath) ao[pos] = a; if (G.arcOut[a] != 0) nWloc++;
-            const int pl = (int) (G.xrec[rc].meta & 0xFFFFu); const int po = G.xpathOff[rc];
-            for (int h = pl - 1; h >= 0; h--) { const int a2 = G.path[po + h]; pos--; if (ao && pos < maxPath) ao[pos] = a2; if (G.arcOut[a2] != 0) nWloc++; }
+            const int a = ka->G.xarc[rc]; pos--; if (ao && pos < maxPath) ao[pos] = a; if (ka->G.arcOut[a] != 0) nWloc++;
+            const int pl = (int) (ka->G.xrec[rc].meta & 0xFFFFu); const int po = ka->G.xpathOff[rc];
+            for (int h = pl - 1; h >= 0; h--) { const int a2 = ka->G.path[po + h]; pos--; if (ao && pos < maxPath) ao[pos] = a2; if (ka->G.arcOut[a2] != 0) nWloc++; }
           }
         }
         if (nWloc) atomicAdd(&s_tb[1], nWloc);
@@ -1112,7 +1221,7 @@ __global__ __launch_bounds__(kThreads) void k_viterbi(GraphDev G, DecDev Dd, con
           const int lim = nA < maxPath ? nA : maxPath;
           for (int b0 = 0; b0 < lim; b0 += nthr) {
             const int i = b0 + tid; unsigned o = 0u;
-            if (i < lim) o = G.arcOut[ao[i]];
+            if (i < lim) o = ka->G.arcOut[ao[i]];
             int total; const int ex = block_excl(o != 0u ? 1 : 0, total);
             if (o != 0u && q + ex < maxPath) wo[q + ex] = o;
             q += total;
@@ -1129,15 +1238,33 @@ __global__ __launch_bounds__(kThreads) void k_viterbi(GraphDev G, DecDev Dd, con
       }
     }   // frames
 
-    if (Dd.prof && tid == 0) s_prof[15] = (long long) wall_clock64();
+    RELOAD();
+    if (PROF && tid == 0) s_prof[15] = (long long) wall_clock64();
     if (status != DSR_OK) {
       // abort: the tagged state table needs no cleaning
-      if (tid == 0) { clear_result(&res[u]); res[u].status = status; res[u].frames = T - 1; }
+      if (tid == 0) { dsr_decode_result* const res = ka->res; clear_result(&res[u]); res[u].status = status; res[u].frames = T - 1; }
     }
   }
-  if (tid == 0) Dd.tags[slot] = tag;
-  if (Dd.prof && tid < 32) Dd.prof[slot * 32 + tid] = s_prof[tid];
+  RELOAD();
+  if (tid == 0) ka->D.tags[slot] = s_tag;
+  if (PROF && tid < 32) ka->D.prof[slot * 32 + tid] = s_prof[tid];
 #undef TICK
+#undef RELOAD
+#undef TOKA
+#undef TOKB
+#undef curA
+#undef nxtA
+#undef curB
+#undef nxtB
+#undef sprA
+#undef sprB
+#undef ctok
+#undef side
+#undef cA
+#undef cB
+#undef arena
+#undef sc
+#undef dump
 }
 
 struct DecoderState {
@@ -1147,7 +1274,7 @@ struct DecoderState {
   DevBuf<XRec> d_xrec; DevBuf<ERec> d_erec; DevBuf<float> d_arcCost, d_nodeCost; DevBuf<uint32_t> d_arcOut, d_arcIn;
   DevBuf<TokA> d_tokA, d_ctok; DevBuf<TokB> d_tokB; DevBuf<Side> d_side; DevBuf<XRecD> d_xrecD; int fastOK = 0; int maxCnt = 0; DevBuf<int> d_tokOff, d_tokCnt, d_owner, d_rank, d_chead; DevBuf<unsigned> d_tags; DevBuf<CandA> d_cA; DevBuf<CandB> d_cB; DevBuf<unsigned> d_first; DevBuf<Bp> d_arena;
   DevBuf<long long> d_prof; DevBuf<dsr_decode_result> d_res; DevBuf<int> d_arcs; DevBuf<unsigned> d_words;
-  long arenaCap = 0; int initial = 0; int threads = kThreads; bool twoPerCu = false;
+  long arenaCap = 0; int initial = 0;
   // lattice bookkeeping of the last decode (cfg.latticeTokens > 0), per utterance
   DevBuf<uint4> d_lat; DevBuf<double> d_latTtl; DevBuf<long> d_latFrameOff; DevBuf<int> d_arenaLat; DevBuf<int4> d_latFinal; DevBuf<int> d_latInfo;
   int latU = 0, latTmax = 0; long latArenaCap = 0; WfstGraph graphCopy; DevBuf<TokA> d_tokA3; DevBuf<TokB> d_tokB3;
@@ -1223,12 +1350,9 @@ dsr_status dsr_decoder_create(const dsr_decoder_cfg* cfg, dsr_decoder** out)
     if (d->cfg.maxActive <= 0) d->cfg.maxActive = 65536;
     if (d->cfg.maxCandidates <= 0) d->cfg.maxCandidates = 8 * d->cfg.maxActive;
     if (d->cfg.maxCandidates >= (1 << 24)) throw Error(DSR_E_PARAMETER, "maxCandidates must be < 2^24");
-    if (const char* e = getenv("DSR_VITERBI_THREADS")) { const int t = atoi(e); if (t == 256 || t == 512 || t == 768 || t == 1024) d->threads = t; }
     if (d->cfg.streams <= 0) {
       hipDeviceProp_t prop; int dev = 0; DSR_HIP(hipGetDevice(&dev)); DSR_HIP(hipGetDeviceProperties(&prop, dev));
-      if (const char* e = getenv("DSR_VITERBI_TWO")) d->twoPerCu = atoi(e) != 0;
-      if (d->twoPerCu && !getenv("DSR_VITERBI_THREADS")) d->threads = 256;
-      d->cfg.streams = prop.multiProcessorCount * (d->twoPerCu ? 2 : 1);
+      d->cfg.streams = prop.multiProcessorCount;
       if (const char* e = getenv("DSR_VITERBI_SLOTS")) { const int t = atoi(e); if (t > 0) d->cfg.streams = t; }
     }
     *out = d;
@@ -1266,7 +1390,7 @@ dsr_status dsr_decoder_set(dsr_decoder* d, const dsr_wfst* g)
         if (o.dstCnt > maxCnt) maxCnt = o.dstCnt;
       }
       d->d_xrecD.upload(xd); d->d_pathCost.upload(pc);
-      d->fastOK = (maxCnt < (1 << 19) && nx < ((size_t) 1 << 30)) ? 1 : 0; d->maxCnt = maxCnt;
+      d->fastOK = (maxCnt < (1 << 19) && nx < ((size_t) 1 << 27)) ? 1 : 0; d->maxCnt = maxCnt;       // (2^27 records x 32 bytes: the register path addresses them with 32-bit byte offsets)
       if (getenv("DSR_VITERBI_NOFAST")) d->fastOK = 0;
     }
     { std::vector<ERec> e = d->tab.erec; if (e.empty()) e.push_back(ERec{0, 0, 0, 0}); d->d_erec.upload(e); }
@@ -1434,27 +1558,30 @@ dsr_status dsr_decoder_decode_launch(dsr_decoder* d, const float* score, const i
       d->latU = U; d->latTmax = Tmax; d->latArenaCap = d->arenaCap;
     } else d->latU = 0;
     // LDS: [score row][state table: 2 x hashN words][slot offsets of the expanding tokens]; the row stays in global memory
-    // when it would push the state table below the size the register path needs
-    // Two shapes: one workgroup per CU (16384 buckets, 512 threads) or two per CU (8192 buckets, 256 threads each: two
-    // utterances advance side by side and fill each other's stalls).  The region after the table holds the slot offsets
-    // (u16 per expanding token) and later the LDS side records.
-    const bool two = d->twoPerCu;
-    size_t eoffB = two ? 8960 : (size_t) kSideLds * sizeof(Side); const size_t ldsCap = two ? 74752 : 159 * 1024;     // two per CU: 2 x (74752 + 7 KB of static LDS) <= 160 KB
-    if (two) { if (const char* e = getenv("DSR_VITERBI_EOFFB")) eoffB = (size_t) atoi(e); }
-    static_assert((size_t) kSideLds * sizeof(Side) >= (size_t) (kFastE + 2) * sizeof(unsigned short), "side region must cover the slot offsets");
-    const int hashMax = two ? 8192 : 16384;
+    // when it would push the state table below the size the register path needs.  One 1024-thread workgroup per CU (16384 buckets).  The region
+    // after the table holds the slot offsets (u16 per expanding token) and later the LDS side records.
+    // instantiations: bit 0 per-phase ticks (DSR_VITERBI_PROF), bit 1 lattice bookkeeping / topN / token dump compiled in
+    const int modes = (D.prof ? 1 : 0) | ((latOn || D.topN > 0 || d->dumpOn) ? 2 : 0);
+    const void* kfn = modes == 0 ? (const void*) k_viterbi<0> : modes == 1 ? (const void*) k_viterbi<1> : modes == 2 ? (const void*) k_viterbi<2> : (const void*) k_viterbi<3>;
+    hipFuncAttributes fattr; DSR_HIP(hipFuncGetAttributes(&fattr, kfn));
+    const size_t eoffB = (size_t) kSideLds * sizeof(Side); const size_t ldsCap = (size_t) 160 * 1024 - fattr.sharedSizeBytes;      // what the kernel's static LDS leaves of a CU's 160 KB
+    const int hashMax = 16384;
     int useLds = (size_t) nDist * sizeof(float) <= 64 * 1024;
     if (useLds && (size_t) ((nDist + 3) & ~3) * sizeof(float) + (size_t) hashMax * 8 + eoffB > ldsCap) useLds = 0;
     const size_t rowB = useLds ? (size_t) ((nDist + 3) & ~3) * sizeof(float) : 16;
     int hashN = hashMax; while (hashN > 0 && rowB + (size_t) hashN * 8 + eoffB > ldsCap) hashN >>= 1;
     if (getenv("DSR_VITERBI_NOHASH")) hashN = 0;
     // + the expansion counts of up to 2048 tokens (u16) when the budget and the graph's largest fan-out allow
-    int cntCap = (!two && hashN > 0 && d->maxCnt < 65536 && rowB + (size_t) hashN * 8 + eoffB + 4096 <= ldsCap) ? 2048 : 0;
+    int cntCap = (hashN > 0 && d->maxCnt < 65536 && rowB + (size_t) hashN * 8 + eoffB + 4096 <= ldsCap) ? 2048 : 0;
     if (getenv("DSR_VITERBI_NOCNT")) cntCap = 0;
     const size_t lds = rowB + (size_t) hashN * 8 + eoffB + 2 * (size_t) cntCap;
-    DSR_HIP(hipFuncSetAttribute((const void*) k_viterbi, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
-    hipLaunchKernelGGL(k_viterbi, dim3(slots), dim3(d->threads), lds, st, G, D, score, nframes, U, Tmax, nDist, d->d_res.p,
-                       (arcs_out || words_out) ? d->d_arcs.p : nullptr, (arcs_out || words_out) ? d->d_words.p : nullptr, maxPath, useLds, hashN, (int) eoffB, cntCap);
+    VitArgs A; A.G = G; A.D = D; A.scores = score; A.nframesArr = nframes; A.U = U; A.Tmax = Tmax; A.nDist = nDist; A.res = d->d_res.p;
+    A.arcsOut = (arcs_out || words_out) ? d->d_arcs.p : nullptr; A.wordsOut = (arcs_out || words_out) ? d->d_words.p : nullptr; A.maxPath = maxPath;
+    A.useLdsRow = useLds; A.hashN = hashN; A.regionB = (int) eoffB; A.cntCap = cntCap;
+#define DSR_LAUNCH_V(MM) { DSR_HIP(hipFuncSetAttribute((const void*) k_viterbi<MM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds)); \
+      hipLaunchKernelGGL(k_viterbi<MM>, dim3(slots), dim3(kThreads), lds, st, A); }
+    switch (modes) { case 0: DSR_LAUNCH_V(0) break; case 1: DSR_LAUNCH_V(1) break; case 2: DSR_LAUNCH_V(2) break; default: DSR_LAUNCH_V(3) break; }
+#undef DSR_LAUNCH_V
     DSR_HIP(hipGetLastError());
     const size_t nPath = want_paths ? (size_t) U * maxPath : 0;
     d->h_res.reserve(U); d->h_arcs.reserve(nPath ? nPath : 1); d->h_words.reserve(nPath ? nPath : 1);
@@ -1482,8 +1609,11 @@ dsr_status dsr_decoder_decode_collect(dsr_decoder* d, dsr_decode_result* res, in
       std::vector<long long> hp((size_t) slots * 32); DSR_HIP(hipMemcpy(hp.data(), prof, hp.size() * sizeof(long long), hipMemcpyDeviceToHost));
       double acc[32] = {0}; for (int s2 = 0; s2 < slots; s2++) for (int i = 0; i < 32; i++) acc[i] += (double) hp[(size_t) s2 * 32 + i];
       fprintf(stderr, "[dsr viterbi prof] mean us per slot:");
-      for (int i = 0; i < 28; i++) if (i != 15) fprintf(stderr, " p%d=%.0f", i, acc[i] / slots / 100.0);
+      for (int i = 0; i < 32; i++) if (i != 15) fprintf(stderr, " p%d=%.0f", i, acc[i] / slots / 100.0);
       fprintf(stderr, "\n");
+      double tmin = 1e30, tmax = 0.0, tsum = 0.0;                   // busy time per slot: how even the slots' shares of the batch were
+      for (int s2 = 0; s2 < slots; s2++) { double t = 0.0; for (int i = 0; i < 32; i++) if (i != 15) t += (double) hp[(size_t) s2 * 32 + i]; t /= 100.0; tsum += t; if (t < tmin) tmin = t; if (t > tmax) tmax = t; }
+      fprintf(stderr, "[dsr viterbi prof] busy us per slot: mean %.0f min %.0f max %.0f\n", tsum / slots, tmin, tmax);
     }
     if (d->dumpOn) {
       long cnt[2]; DSR_HIP(hipMemcpy(cnt, d->d_dumpCount.p, sizeof(cnt), hipMemcpyDeviceToHost));

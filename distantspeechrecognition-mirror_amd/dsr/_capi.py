@@ -102,9 +102,12 @@ def load():
     if _lib is not None:
         return _lib
     import torch  # noqa: F401  (binds libamdhip64.so.7 before our library asks for it)
-    if not os.path.exists(_LIBPATH):
-        raise ImportError("libdsr_hip.so is not built: run `python -c 'import __graft_entry__ as g; g.build()'` (%s)" % _LIBPATH)
-    L = C.CDLL(_LIBPATH)
+    path = _LIBPATH
+    if os.environ.get("DSR_LIB_VARIANT"):      # A/B tooling (tools/ab_*.sh): a variant build under lib/var/<name>/, never copied over the shipped library
+        path = os.path.join(os.path.dirname(_LIBPATH), "var", os.environ["DSR_LIB_VARIANT"], "libdsr_hip.so")
+    if not os.path.exists(path):
+        raise ImportError("libdsr_hip.so is not built: run `python -c 'import __graft_entry__ as g; g.build()'` (%s)" % path)
+    L = C.CDLL(path)
     declare_from_header(L)
     _lib = L
     return L
