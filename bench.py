@@ -188,6 +188,7 @@ def main():
     ap.add_argument("--beam", type=float, default=0.0, help="0 = tune to ~5k active tokens")
     ap.add_argument("--gmm-mode", type=int, default=2, help="2: MFMA contraction + candidate search in the accumulator layout + exact re-score inside the rounding bound (argmin = mode 0 on every frame, cost rel <= 2e-6; config.gmm_mode2_vs_mode0 reports the agreement on the full batch); 0: exact VALU kernel")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--pipes", type=int, default=2, help="pipe objects / HIP streams the steps rotate over (default 2; --serial: 1)")
     ap.add_argument("--overlap", action="store_true", help="(default) two pipe objects on two HIP streams: a step is enqueued whole while the step before is still decoding, "
                     "so the front end of step k+1 runs on the CUs the persistent decode workgroups of step k free as its utterances finish (+8 %% throughput; every step "
                     "still does all of its work, and everything is collected before the clock stops)")
@@ -249,7 +250,7 @@ def main():
     # (utterances finish at different times) overlaps the front end of the next step; every step still does all of its work
     # and everything is collected before the clock stops.
     maxPath = 2 * Tm + 64
-    npipes = 1 if args.serial else 2
+    npipes = 1 if args.serial else max(2, args.pipes)
     pipes, streams = [], []
     for i in range(npipes):
         dec = dsr.Decoder(beam=beam, lmScale=12.0, maxActive=65536); dec.set(mdl["gd"])

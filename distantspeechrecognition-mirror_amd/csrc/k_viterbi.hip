@@ -309,6 +309,7 @@ __global__ __launch_bounds__(kThreads) void k_viterbi(const VitArgs argsInKernar
     __syncthreads();
 
     bool cntOK = false;                                                        // cntL holds the counts of the current list, and every token of it passes the beam
+    int preC = -1;                                                             // >= 0: the frame before has already laid out this frame's slots (bitmap, group table): preC placements
     const bool preRow = useLdsRow && nDist <= 2 * nthr;
     float rowNext[2] = {0.0f, 0.0f};
     if (preRow && T > 0) { if (tid < nDist) rowNext[0] = sc[tid]; if (tid + nthr < nDist) rowNext[1] = sc[tid + nthr]; }
@@ -342,9 +343,12 @@ __global__ __launch_bounds__(kThreads) void k_viterbi(const VitArgs argsInKernar
 
       if (fast) {
         // ======================= register path =======================
+        const bool pre = preC >= 0;                                            // the slots of this frame were laid out when the list was written (P6): no P1, no P2
         // ---- P1: beam test, per-wave exclusive scans of the placement counts and of the expanding tokens.
         // Token loads are issued eight at a time (straight-line, clamped indices) so their latencies overlap.
         const int chunkT = ((n + nw * 64 - 1) / (nw * 64)) * 64;
+        int C = preC, E = n;
+        if (!pre) {
         float psc[kP1]; int pcn[kP1]; unsigned pk[kP1];                        // score; expansion count; slot offset | token index << 15 | bit31: expands
         int runC = 0, runE = 0;
         {
@@ -392,7 +396,7 @@ __global__ __launch_bounds__(kThreads) void k_viterbi(const VitArgs argsInKernar
         }
         __syncthreads();
         TICK(0);
-        int C, E, cbase, ebase;
+        int cbase, ebase;
         {                                                                      // lane w reads wave w's totals: two scans instead of a serial walk over 32 LDS words
           const int a = (lane < nw) ? s_waveTot[lane] : 0, b = (lane < nw) ? s_waveTotE[lane] : 0;
           const int sa = wave_incl_scan(a, lane), sb = wave_incl_scan(b, lane);
@@ -401,8 +405,7 @@ __global__ __launch_bounds__(kThreads) void k_viterbi(const VitArgs argsInKernar
           cbase = __builtin_amdgcn_readlane(sa - a, wu); ebase = __builtin_amdgcn_readlane(sb - b, wu);
         }
         TICK(19);
-        if (C > fastCapC || E > eCap || C > 2 * tableC) { fast = false; __syncthreads(); }     // uniform: the memory path redoes the frame
-        else {
+        if (!(C > fastCapC || E > eCap || C > 2 * tableC)) {
           // ---- P2: compact list of the expanding tokens (their slot offsets in LDS, the tokens themselves in memory); a bitmap
           // of the slots where a token's run starts and the token count before every group of 64 slots turn "slot -> token"
           // into a population count
@@ -410,7 +413,6 @@ __global__ __launch_bounds__(kThreads) void k_viterbi(const VitArgs argsInKernar
           // list itself serves as the compact list: no copy)
           RELOAD();
           const bool ident = (E == n);
-          const TokA* __restrict__ ctk = ident ? curA : ctok;
 #pragma unroll
           for (int it = 0; it < kP1; it++) if (pk[it] & 0x80000000u) {
             const int e = ebase + (int) ((pk[it] >> 15) & 0xFFFFu); const int off = cbase + (int) (pk[it] & 0x7FFFu);
@@ -419,6 +421,13 @@ __global__ __launch_bounds__(kThreads) void k_viterbi(const VitArgs argsInKernar
             for (int g = (off >> 6) + 1; g <= ((off + pcn[it]) >> 6); g++) s_gbase[g] = (unsigned) (e + 1) | ((unsigned) (64 * g - off) << 13);   // this token covers slot 64g-1
           }
           __syncthreads();
+        }
+        } else __syncthreads();                                                // (laid out by the frame before; this barrier: the score row is in LDS)
+        if (C > fastCapC || E > eCap || C > 2 * tableC) { fast = false; __syncthreads(); }     // uniform: the memory path redoes the frame
+        else {
+          RELOAD();
+          const bool ident = (E == n);
+          const TokA* __restrict__ ctk = ident ? curA : ctok;
           TICK(1);
           Cfr = C;
           RELOAD();
@@ -575,6 +584,7 @@ __global__ __launch_bounds__(kThreads) void k_viterbi(const VitArgs argsInKernar
           TICK(3);
           __syncthreads();
           TICK(4);
+          for (int i = tq; i < kFastC / 32; i += nthr) s_bm[i] = 0u;          // every slot has found its token: the bitmap is free for the layout of the next frame (P6)
           topScore = HUGE_VAL;
           float frameMag;
           { const double v = (lq < nw) ? s_waveMin[lq] : HUGE_VAL; const float g = (lq < nw) ? s_waveMag[lq] : 0.0f;
@@ -854,6 +864,8 @@ __global__ __launch_bounds__(kThreads) void k_viterbi(const VitArgs argsInKernar
             __syncthreads();
             TICK(21);
             const int q4 = hashN >> 2;
+            const bool layNext = prune && numNew <= 2 * nthr;                  // (one round of the loop below)
+            preC = -1;
             for (int f0 = 0; f0 < numNew; f0 += 2 * nthr) {
               uint4 en[2]; int4 dx[2]; uint32_t pv[2];
 #pragma unroll
@@ -870,6 +882,35 @@ __global__ __launch_bounds__(kThreads) void k_viterbi(const VitArgs argsInKernar
                 const uint32_t* pb = (sw && si >= (unsigned) sideLds) ? &side[si].prevBp : &ctk[(sw || !on) ? 0u : (en[i].w & 0x1FFFu)].bp;
                 pv[i] = *pb;
                 if (sw && si < (unsigned) sideLds) pv[i] = sideL[si].prevBp;
+              }
+              // The list this loop writes is the list the next frame expands, every token of it (pruning on: all pass the beam).  A token's first slot
+              // there is the sum of the expansion counts of the tokens before it in the list = after it in rank: one block-wide sum over the counts the
+              // loop has in hand anyway gives every token its slot offset, and the bitmap of run starts and the per-group table -- what P1 and P2 of the
+              // next frame would rebuild from the list -- are written here.  That frame then starts at P3 (one barrier for its score row).
+              if (layNext) {
+                const int cA0 = (tq < numNew) ? dx[0].w : 0, cB0 = (nthr + tq < numNew) ? dx[1].w : 0;
+                const int inA = wave_incl_scan(cA0, lq), inB = wave_incl_scan(cB0, lq);
+                const bool bad = (tq < numNew && cA0 == 0) || (nthr + tq < numNew && cB0 == 0);     // a token without arcs: the list is not its own compact list
+                const int badW = __any(bad) ? 1 : 0;
+                if (lq == 63) { s_waveTot[wq] = inA; s_waveTotE[wq] = inB | (badW << 30); }
+                __syncthreads();
+                const int ta = (lq < nw) ? s_waveTot[lq] : 0, tbv = (lq < nw) ? s_waveTotE[lq] : 0, tb = tbv & 0x3FFFFFFF;
+                const int sa = wave_incl_scan(ta, lq), sb = wave_incl_scan(tb, lq);
+                const int totA = __builtin_amdgcn_readlane(sa, 63), totB = __builtin_amdgcn_readlane(sb, 63), wu = uni(wq);
+                const int total = totA + totB;
+                const int offA = total - (__builtin_amdgcn_readlane(sa - ta, wu) + inA), offB = total - (totA + __builtin_amdgcn_readlane(sb - tb, wu) + inB);
+                const bool anyBad = __any((tbv >> 30) & 1);
+#pragma unroll
+                for (int i = 0; i < 2; i++) {
+                  const int f = i * nthr + tq; const int off = i ? offB : offA, cn = i ? cB0 : cA0;
+                  if (f < numNew && cn > 0) {
+                    const int e = numNew - 1 - f;
+                    atomicOr(&s_bm[off >> 5], 1u << (off & 31));
+                    for (int g = (off >> 6) + 1; g <= ((off + cn) >> 6); g++) s_gbase[g] = (unsigned) (e + 1) | ((unsigned) (64 * g - off) << 13);
+                  }
+                }
+                if (tq == 0) { s_sideN = 0; s_gbase[0] = 0; s_err = 0; }
+                preC = anyBad ? -1 : total;
               }
 #pragma unroll
               for (int i = 0; i < 2; i++) {
@@ -895,12 +936,13 @@ __global__ __launch_bounds__(kThreads) void k_viterbi(const VitArgs argsInKernar
           }
           TICK(21);
           TICK(22);
+          preC = -1;
           }
           cntOK = prune && numNew <= cntCap;
         }
       }
       if (!fast) {
-      cntOK = false;
+      cntOK = false; preC = -1;
       // ======================= memory path =======================
       RELOAD();
       int* tokOff = ka->D.tokOff + (size_t) slot * (ka->D.maxTok + 1);
