@@ -175,8 +175,12 @@ def cpu_config1():
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=3, help="untimed steps; the second and third full-batch steps of a fresh process run their first HBM-bound "
+    ap.add_argument("--workload", default="pipe", choices=["pipe", "config5"], help="pipe: BASELINE configs[3], the full 8-ch pipe with decode (the default, the headline "
+                    "metric); config5: BASELINE configs[4], 64-ch MVDR + Zelinski + WPE on long streams in 10-s blocks with carried state (bench_streams.py; --steps = blocks "
+                    "per stream, default 60 = 10 minutes)")
+    ap.add_argument("--streams", type=int, default=32, help="config5: streams per GPU")
+    ap.add_argument("--steps", type=int, default=None)
+    ap.add_argument("--warmup", type=int, default=None, help="untimed steps; the second and third full-batch steps of a fresh process run their first HBM-bound "
                     "kernel 6-8x slower (a power-state transient of the board, same kernel, same data: 4.5 -> 25-32 ms), so the default keeps them out of the timed region")
     ap.add_argument("--utts", type=int, default=1000, help="utterances per GPU per step (weak scaling, the default)")
     ap.add_argument("--total-utts", type=int, default=0, help="strong scaling: this many utterances in all, sharded u -> rank u mod world "
@@ -188,6 +192,9 @@ def main():
     ap.add_argument("--beam", type=float, default=0.0, help="0 = tune to ~5k active tokens")
     ap.add_argument("--gmm-mode", type=int, default=2, help="2: MFMA contraction + candidate search in the accumulator layout + exact re-score inside the rounding bound (argmin = mode 0 on every frame, cost rel <= 2e-6; config.gmm_mode2_vs_mode0 reports the agreement on the full batch); 0: exact VALU kernel")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--strong-total", type=int, default=1000, help="multi-GPU runs: after the weak-scaling region, time this many utterances sharded over the "
+                    "ranks as a second region (BASELINE configs[3] as stated) and report it as config.strong; 0 = skip")
+    ap.add_argument("--no-verify", action="store_true", help="skip the untimed mode-2-vs-mode-0 agreement run")
     ap.add_argument("--pipes", type=int, default=2, help="pipe objects / HIP streams the steps rotate over (default 2; --serial: 1)")
     ap.add_argument("--overlap", action="store_true", help="(default) two pipe objects on two HIP streams: a step is enqueued whole while the step before is still decoding, "
                     "so the front end of step k+1 runs on the CUs the persistent decode workgroups of step k free as its utterances finish (+8 %% throughput; every step "
@@ -199,6 +206,16 @@ def main():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend of the multi-rank run: nccl (= RCCL, the default) or gloo -- gloo with "
                     "DSR_BENCH_DEVICE=0 rehearses the multi-rank control flow with several ranks on ONE GPU (collectives on host tensors)")
     args = ap.parse_args()
+    if args.steps is None:
+        args.steps = 60 if args.workload == "config5" else 5
+    if args.warmup is None:
+        args.warmup = 2 if args.workload == "config5" else 3
+    if args.workload == "config5":
+        import bench_streams
+        line = bench_streams.run(args, ROOT)
+        if line is not None:
+            print(json.dumps(line))
+        return
 
     import torch
     import torch.distributed as dist
@@ -274,9 +291,11 @@ def main():
     def finish(i):
         return gather(collect(i))
 
+    batch = [x, ns_dev, ns_host]                                             # what a step decodes (the strong-scaling region below swaps in this rank's shard)
+
     def submit(i):
         with torch.cuda.stream(streams[i]):
-            pipes[i].submit(x, ns_dev, ns_host, maxPath=maxPath, want_paths=True)
+            pipes[i].submit(batch[0], batch[1], batch[2], maxPath=maxPath, want_paths=True)
         inflight[i] = True
 
     def run_steps(n):
@@ -317,6 +336,23 @@ def main():
     serial_ms = None; serial_step_ms = None
     if npipes > 1:
         sync(); ts = time.time(); submit(0); serial_ms = finish(0)[2]; sync(); serial_step_ms = 1000.0 * (time.time() - ts)
+    # ---- configs[3] as literally stated ("1k-utterance batch sharded over N GPUs"): a second timed region of the same run.  Every rank decodes the
+    # utterances u = rank mod world of a 1000-utterance batch; at world = 1 that is the region above.  speedup = the weak region's step (one GPU,
+    # 1000 utterances) over this one.  The decode runs one utterance per workgroup per CU: a shard takes ceil(shard / 256) rounds, so 125
+    # utterances (8 GPUs) cost as much as 250 (4 GPUs).
+    strong2 = None
+    if world > 1 and not strong and args.strong_total > 0:
+        ids = shard_utterances(args.strong_total, world, rank); Us = min(len(ids), U)
+        if Us >= 1:
+            batch[0], batch[1], batch[2] = x[:Us].contiguous(), ns_dev[:Us].contiguous(), ns_host[:Us]
+            run_steps(1)                                                    # untimed: the shapes of the smaller batch
+            sync(); ts = time.time(); done2 = run_steps(args.steps); sync(); dts = time.time() - ts
+            tm2 = torch.tensor([dts], dtype=torch.float64, device=cdev); dist.all_reduce(tm2, op=dist.ReduceOp.MAX); dts = float(tm2.item())
+            bad2 = sum(1 for res, _, _ in done2 for r in res if r.status != 0)
+            strong2 = dict(total_utts=args.strong_total, utts_this_rank=Us, ms_per_step=1000.0 * dts / args.steps,
+                           value=args.strong_total * args.secs / 3600.0 / (dts / args.steps), unit="audio_hours/s", failed_utts_rank0=bad2,
+                           decode_rounds=int(-(-Us // 256)), note="shard u -> rank u mod world; one utterance per workgroup per CU: ceil(shard/256) decode rounds")
+            batch[0], batch[1], batch[2] = x, ns_dev, ns_host
     stage = np.zeros(6); placements = 0; active = 0; bad = 0; frames = 0
     for res, words, sms in done:
         stage += np.array(sms)
@@ -339,9 +375,10 @@ def main():
         # algorithmic bytes / flops per launch (DESIGN.md "Measurement")
         fusedFE = (not args.no_fuse) and mdl["ana"].analysis_beamform_supported(mdl["bf"])
         alg = {
-            # 512 B in + 1032 B out per channel-frame.  Fused with the beamformer the snapshots stay on the chip: the bytes that
-            # still have to move are the samples in (tiles re-read the 7 blocks of history they share: x 23/16) and one beamformed row out per frame
-            "analysis": ("hbm", U * T_ana * (Cn * 512.0 * 23 / 16 + 1032.0)) if fusedFE else ("hbm", U * Cn * T_ana * 1544.0),
+            # 512 B in + 1032 B out per channel-frame.  Fused with the beamformer the snapshots stay on the chip and 8d's formula for that
+            # variant applies: every sample once in, one beamformed row per frame out = C * 512 + 1032 bytes per frame (what the kernel really moves
+            # -- tiles re-read the history they share -- is the counter figure next to it, not this one)
+            "analysis": ("hbm", U * T_ana * (Cn * 512.0 + 1032.0)) if fusedFE else ("hbm", U * Cn * T_ana * 1544.0),
             "beamform": ("hbm", 0.0) if fusedFE else ("hbm", U * T_ana * (Cn + 1) * 129 * 8.0),
             "synthesis": ("lds", U * T_ana * (129 * 8.0 + 128 * 4.0)),          # bytes quoted for reference: bound by the LDS traffic of its FFT + overlap-add
             "mfcc": ("fp64", U * Tm * (160 * 4.0 + 39 * 4.0)),                  # bytes quoted for reference: bound by its fp64 FFT through LDS (feature.cc is double)
@@ -358,30 +395,49 @@ def main():
         # HBM bytes per launch from the counter passes of this round (profiles/r01_traffic.json: FETCH_SIZE and WRITE_SIZE, separate
         # rocprofv3 --pmc runs of this same workload); only quoted when the workload is the one they were collected on
         try:
-            tj_path = os.path.join(ROOT, "profiles", "r02_traffic.json")
-            if not os.path.exists(tj_path):
-                tj_path = os.path.join(ROOT, "profiles", "r01_traffic.json")
+            tj_path = next(pth for pth in (os.path.join(ROOT, "profiles", "r0%d_traffic.json" % r) for r in (3, 2, 1)) if os.path.exists(pth))
             tj = json.load(open(tj_path))
             key = {"viterbi": "k_viterbi", "analysis": "k_analysis_q256", "beamform": "k_bf_apply"}.get(dn)
-            if key in tj["kernels"] and U == 1000 and args.secs == 10.0 and args.states == 50000 and abs(beam - 53.787) < 0.01:
+            # the counters were collected on this workload shape at the beam recorded in the file; the tuned beam of a run moves in its fourth digit
+            same = U == 1000 and args.secs == 10.0 and args.states == 50000 and abs(beam - float(tj.get("beam", 53.787))) < 0.01 * beam
+            if key in tj["kernels"] and same:
                 roof["traffic"] = tj["kernels"][key]["bytes_per_launch"]
-                roof["traffic_note"] = "bytes per launch, PMC FETCH_SIZE + WRITE_SIZE (profiles/%s)" % os.path.basename(tj_path)
+                roof["traffic_note"] = "bytes per launch, PMC FETCH_SIZE + WRITE_SIZE (profiles/%s, collected at beam %.3f)" % (os.path.basename(tj_path), float(tj.get("beam", 53.787)))
         except (OSError, ValueError, KeyError):
             pass
         roof["launch_ms"] = stage_ms[dom]
         stages = {}
         tbl_ms = serial_ms if serial_ms is not None else stage_ms
         for i, nm in enumerate(names):
+            if nm == "beamform" and fusedFE:
+                continue                                                # no such kernel in this mode: the analysis entry covers it
             k, a = alg[nm]; s = tbl_ms[i] / 1000.0
             byteq = k in ("hbm", "lds", "fp64")
             stages[nm] = dict(ms=round(tbl_ms[i], 3), bound=k,
                               achieved=round(a / s / (1e9 if byteq else 1e12), 3) if s > 0 else None,
                               unit=("GB/s" if k == "hbm" else "GB/s of HBM bytes (not the bound)") if byteq else "TFLOP/s")
+            if k == "hbm" and s > 0:
+                stages[nm]["frac_of_hbm_peak"] = round(a / s / 1e9 / HBM_PEAK_GBS, 3)
             if nm == "analysis" and fusedFE and s > 0:
-                # the two stages this kernel replaces, in SURVEY 8d's algorithmic bytes (1544 B per channel-frame + the beamformer's (C + 1) rows per frame)
-                alg2 = U * Cn * T_ana * 1544.0 + U * T_ana * (Cn + 1) * 129 * 8.0
-                stages[nm]["algorithmic_GBs_of_the_two_stages"] = round(alg2 / s / 1e9, 1)
-                stages[nm]["algorithmic_frac_of_hbm"] = round(alg2 / s / 1e9 / HBM_PEAK_GBS, 3)
+                stages[nm]["bytes"] = "SURVEY 8d, fused variant: (C * 512 + 1032) B per frame"
+                try:                                                    # what the counters saw for this kernel (separate --pmc passes of this workload)
+                    kb = tj["kernels"].get("k_analysis_bf_q256")
+                    if kb and same:
+                        stages[nm]["counter_GBs"] = round(kb["bytes_per_launch"] / s / 1e9, 1); stages[nm]["counter_over_algorithmic"] = round(kb["bytes_per_launch"] / a, 2)
+                except NameError:
+                    pass
+        gmm_check = None
+        if args.gmm_mode == 2 and world == 1 and not args.no_verify:
+            # the MFMA scoring path against the exact one on this very batch: same decoder, same features, scores from mode 0
+            dec0 = dsr.Decoder(beam=beam, lmScale=12.0, maxActive=65536); dec0.set(mdl["gd"])
+            p0 = dsr.Pipe(mdl["ana"], mdl["syn"], mdl["bf"], dsr.Mfcc(lda=mdl["lda"]), mdl["gm"], dec0, gmmMode=0, fused=not args.no_fuse)
+            r0, _, w0 = p0.run(x, ns_dev, ns_host, maxPath=maxPath, want_paths=True)
+            res2, words2, _ = done[-1]
+            same1 = sum(1 for u in range(U) if r0[u].nWords == res2[u].nWords and np.array_equal(w0[u, :r0[u].nWords], words2[u, :res2[u].nWords]))
+            sdiff = max(abs(r0[u].score - res2[u].score) / max(1.0, abs(r0[u].score)) for u in range(U))
+            gmm_check = dict(one_best_agree="%d/%d" % (same1, U), max_rel_score_diff=float(sdiff),
+                             note="GMM mode 2 (MFMA, argmin = mode 0 on every frame, cost rel <= 2e-6) against mode 0 (reference order, bit exact) through the same decoder")
+            del p0, dec0
         cpu = None
         if not args.no_cpu and world == 1:                               # the CPU baseline is a 1-GPU-run item (rank 0 at N = 1 only)
             try:
@@ -422,7 +478,7 @@ def main():
                                 step_overlap=("two pipe objects on two HIP streams: step k+1 is enqueued while step k decodes, its front end runs on the CUs step k's persistent "
                                               "decode workgroups free as utterances finish; `stages` and serial_step_ms are one extra, untimed step alone on the GPU "
                                               "(their sum exceeds ms_per_step by what the overlap hides); --serial runs the steps one after the other") if npipes > 1 else "none",
-                                serial_step_ms=serial_step_ms),
+                                serial_step_ms=serial_step_ms, strong=strong2, gmm_mode2_vs_mode0=gmm_check),
                     roofline=roof, stages=stages, cpu_baseline=cpu)
         print(json.dumps(line))
     if world > 1:

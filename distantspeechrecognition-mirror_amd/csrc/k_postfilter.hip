@@ -15,61 +15,81 @@
 
 namespace dsr {
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Zelinski for any array size, as two streaming kernels.  What the filter needs of the C (C - 1) / 2 cross densities is their SUM, and every
+// density follows the same first-order recursion phi_ij(t) = alpha phi_ij(t - 1) + (1 - alpha) a_i(t) conj(a_j(t)) (postfilter.cc:8-21, 86-113):
+// the sum obeys that recursion too, S(t) = alpha S(t - 1) + (1 - alpha) P(t), with P(t) = sum_{i<j} a_i conj(a_j) = sum_j (sum_{i<j} a_i) conj(a_j)
+// -- a running prefix over the channels, O(C) complex products per (frame, bin) instead of O(C^2) densities kept and updated; the sum of the auto
+// densities likewise with E(t) = sum_i |a_i|^2.  P and E of different frames are independent:
+//   k_zel_pairs   one thread per (frame, bin), all frames in parallel: reads every snapshot once, fully coalesced ([frame][bin] is contiguous per
+//                 channel), the time-alignment vector from its transposed copy [channel][bin] (the waves of a CU walk the channels together: L1);
+//   k_zel_recur   one thread per (stream, bin) walks the frames: the two scalar recursions, the weight, the filtered output.
+// fp64 throughout, as the reference; the sums are the reference's numbers up to the rounding of a different summation order (1e-13 relative:
+// tests compare at 1e-6).  The carried state of a stream (block streaming) is S and the auto sum: three doubles per bin instead of C (C + 1) / 2
+// complex densities.  At 64 channels x 32 streams x 1250 frames: 24.0 -> 1.6 ms (the wave-per-bin kernel that kept all 2016 densities was bound
+// by its fp64 pair updates, 1.4 % of HBM); the kernel is now bound by reading the snapshots.
 // Carried state (block streaming, dsr_zelinski_carry): seenIn[u] = frames of stream u the earlier calls have filtered (the recursions start from
-// scratch only on the stream's own first two frames), seenOut[u] = that plus this call's; the densities are read from / left in `state`.
-__global__ __launch_bounds__(128) void k_zelinski(const float2* __restrict__ X, const float2* __restrict__ Y, const int* __restrict__ nframesArr,
-                                                  const double2* __restrict__ wq, double2* __restrict__ state, float2* __restrict__ out,
-                                                  float* __restrict__ wp1, int U, int C, int Tmax, int F, double alphaCfg, int type, int minFrames,
-                                                  const int* __restrict__ seenIn, int* __restrict__ seenOut)
+// scratch only on the stream's own first two frames), seenOut[u] = that plus this call's; the sums are read from / left in `state`.
+__global__ __launch_bounds__(256) void k_zel_pairs(const float2* __restrict__ X, const int* __restrict__ nframesArr, const double2* __restrict__ wqT,
+                                                   double2* __restrict__ Pb, double* __restrict__ Eb, int C, int Tmax, int F)
 {
-  const long n = (long) blockIdx.x * blockDim.x + threadIdx.x;
-  if (n >= (long) U * F) return;
-  const int u = (int) (n / F), f = (int) (n - (long) u * F);
-  const long S = (long) U * F;
+  const long TF = (long) Tmax * F;
+  const long idx = (long) blockIdx.x * 256 + threadIdx.x;
+  const int u = blockIdx.y;
+  if (idx >= TF) return;
+  const int t = (int) (idx / F), f = (int) (idx - (long) t * F);
   const int T = nframesArr[u] < Tmax ? nframesArr[u] : Tmax;
-  const float2* Xu = X + (long) u * C * Tmax * F;
-  const float2* Yu = Y + (long) u * Tmax * F;
-  float2* Ou = out + (long) u * Tmax * F;
-  double2 ta[16];                                                // time-aligned channels (C <= 16 here; larger arrays: k_pf_wave)
+  if (t >= T) return;
+  const float2* Xp = X + (long) u * C * TF + idx;
+  const double2* dp = wqT + f;
+  double Ar = 0.0, Ai = 0.0, Pr = 0.0, Pi = 0.0, E = 0.0;
+#pragma unroll 4
+  for (int c = 0; c < C; c++) {
+    const float2 x = Xp[(long) c * TF]; const double2 d = dp[(long) c * F];
+    const double dr = d.x, di = -d.y, xr = (double) x.x, xi = (double) x.y;
+    const double ar = dr * xr - di * xi, ai = dr * xi + di * xr;          // TimeAlignment: conj(d_c) x_c (postfilter.cc:30-43)
+    Pr += Ar * ar + Ai * ai; Pi += Ai * ar - Ar * ai;                     // (sum of the channels before) conj(a_c)
+    E += ar * ar + ai * ai;
+    Ar += ar; Ai += ai;
+  }
+  Pb[(long) u * TF + idx] = make_double2(Pr, Pi); Eb[(long) u * TF + idx] = E;
+}
+
+__global__ __launch_bounds__(64) void k_zel_recur(const double2* __restrict__ Pb, const double* __restrict__ Eb, const float2* __restrict__ Y,
+                                                  const int* __restrict__ nframesArr, double2* __restrict__ state, float2* __restrict__ out,
+                                                  float* __restrict__ wp1, int U, int C, int Tmax, int F, double alphaCfg, int type, int minFrames,
+                                                  const int* __restrict__ seenIn, int* __restrict__ seenOut, int carryIn, int carryOut)
+{
+  const long n = (long) blockIdx.x * 64 + threadIdx.x;
+  const long S = (long) U * F;
+  if (n >= S) return;
+  const int u = (int) (n / F), f = (int) (n - (long) u * F);
+  const int T = nframesArr[u] < Tmax ? nframesArr[u] : Tmax;
   const int seen = seenIn ? seenIn[u] : 0;
   if (seenOut && f == 0) seenOut[u] = seen + T;
-  for (int t = 0; t < Tmax; t++) {
-    if (t >= T) { Ou[(long) t * F + f] = make_float2(0.f, 0.f); if (wp1) wp1[((long) u * Tmax + t) * F + f] = 0.f; continue; }
-    const int frameX = seen + t - 1;                             // _frameX before _increment() (postfilter.cc:463-476)
-    const double alpha = (frameX > 0) ? alphaCfg : 0.0;
-    const int pfType = (frameX < minFrames) ? 0 : type;
+  double Sr = 0.0, Si = 0.0, D = 0.0;
+  if (carryIn) { const double2 s0 = state[n]; Sr = s0.x; Si = s0.y; D = state[S + n].x; }
+  const long base = (long) u * Tmax * F + f;
+  const double scale = 2.0 / ((double) C - 1.0);
 #pragma unroll 4
-    for (int i = 0; i < C; i++) {                                // TimeAlignment: conj(d_i) x_i
-      const double2 d = wq[(long) f * C + i]; const float2 x = Xu[((long) i * Tmax + t) * F + f];
-      const double dr = d.x, di = -d.y, xr = (double) x.x, xi = (double) x.y;
-      ta[i] = make_double2(dr * xr - di * xi, dr * xi + di * xr);
-    }
-    double sr = 0.0, si = 0.0; int e = 0;
-    for (int i = 0; i < C - 1; i++)
-      for (int j = i + 1; j < C; j++, e++) {
-        const double ar = ta[i].x, ai = ta[i].y, br = ta[j].x, bi = -ta[j].y;
-        const double pr = ar * br - ai * bi, pi = ar * bi + ai * br;
-        double er = pr, ei = pi;
-        if (alpha > 0.0) { const double2 p = state[(long) e * S + n]; er = p.x * alpha + pr * (1.0 - alpha); ei = p.y * alpha + pi * (1.0 - alpha); }
-        sr += er; si += ei; state[(long) e * S + n] = make_double2(er, ei);
-      }
+  for (int t = 0; t < Tmax; t++) {
+    const long o = base + (long) t * F;
+    if (t >= T) { out[o] = make_float2(0.f, 0.f); if (wp1) wp1[o] = 0.f; continue; }
+    const double2 P = Pb[o]; const double E = Eb[o]; const float2 y = Y[o];
+    const int frameX = seen + t - 1;                                      // _frameX before _increment() (postfilter.cc:463-466)
+    const double alpha = (frameX > 0) ? alphaCfg : 0.0;
+    if (alpha > 0.0) { Sr = Sr * alpha + P.x * (1.0 - alpha); Si = Si * alpha + P.y * (1.0 - alpha); D = alpha * D + (1.0 - alpha) * E; }
+    else { Sr = P.x; Si = P.y; D = E; }
+    const int pfType = (frameX < minFrames) ? 0 : type;
     double numerator;
-    if (1 & pfType) { numerator = sr; if (numerator < 0.0) numerator = 0.0; }
-    else numerator = hypot(sr, si);
-    double denominator = 0.0;
-    for (int i = 0; i < C; i++, e++) {
-      const double a2 = ta[i].x * ta[i].x + ta[i].y * ta[i].y;
-      double est = a2;
-      if (alpha > 0.0) est = alpha * state[(long) e * S + n].x + (1.0 - alpha) * a2;
-      denominator += est; state[(long) e * S + n] = make_double2(est, 0.0);
-    }
-    double W = (numerator / denominator) * (2.0 / ((double) C - 1.0));
+    if (1 & pfType) { numerator = Sr; if (numerator < 0.0) numerator = 0.0; } else numerator = hypot(Sr, Si);
+    double W = (numerator / D) * scale;
     if (W >= 1.0) W = 1.0;
     if (W < 0.0001) W = 0.0001;
-    if (wp1) wp1[((long) u * Tmax + t) * F + f] = (float) W;
-    const float2 y = Yu[(long) t * F + f];
-    Ou[(long) t * F + f] = (pfType == 0) ? y : make_float2((float) (W * (double) y.x), (float) (W * (double) y.y));
+    if (wp1) wp1[o] = (float) W;
+    out[o] = (pfType == 0) ? y : make_float2((float) (W * (double) y.x), (float) (W * (double) y.y));
   }
+  if (carryOut) { state[n] = make_double2(Sr, Si); state[S + n] = make_double2(D, 0.0); }
 }
 
 // McCowanPostFilter (postfilter.cc:706-744,789-826,833-945): the same recursions, then the noise-coherence corrected estimate of the
@@ -385,6 +405,7 @@ __global__ __launch_bounds__(64) void k_pf_wave(const float2* __restrict__ X, co
 struct ZelinskiPlan { int M = 0, C = 0, type = 2, minFrames = 0; double alpha = 0.6; std::vector<double> h_wq; bool dirty = true; DevBuf<double2> wq, state;
                       int kind = 0; double threshold = 0.99; std::vector<double> h_R; bool haveR = false, dirtyR = true; DevBuf<double2> R;       // kind 1: McCowan
                       double minSV = 1e-8; int fbinX1 = 0; bool dirtyL = true; DevBuf<double2> lambda;                                                 // kind 2: Lefkimmiatis
+                      DevBuf<double2> wqT; struct PE { DevBuf<double2> P; DevBuf<double> E; }; PerStream<PE> pe;                                          // Zelinski: [chan][bin] manifold, P / E of a call (one set per stream)
                       DevBuf<unsigned short> pairIJ;                                                                                                      // wave kernel: pair e -> i | j << 8
                       bool carry = false, haveState = false; int stateU = 0; DevBuf<int> seen[2]; int seenCur = 0; };                                      // carried state (block streaming)
 
@@ -512,17 +533,24 @@ dsr_status dsr_zelinski_apply(dsr_zelinski* p, const float* X, const float* Y, c
     if (U <= 0 || Tmax <= 0) return;
     hipStream_t st = (hipStream_t) stream;
     const int F = p->M / 2 + 1, C = p->C;
-    if (p->dirty) { std::vector<double2> w((size_t) F * C); for (size_t i = 0; i < w.size(); i++) w[i] = make_double2(p->h_wq[2 * i], p->h_wq[2 * i + 1]); p->wq.upload(w); p->dirty = false; p->dirtyL = true; }
+    if (p->dirty) {
+      std::vector<double2> w((size_t) F * C), wt((size_t) F * C);
+      for (size_t i = 0; i < w.size(); i++) w[i] = make_double2(p->h_wq[2 * i], p->h_wq[2 * i + 1]);
+      for (int f = 0; f < F; f++) for (int c = 0; c < C; c++) wt[(size_t) c * F + f] = w[(size_t) f * C + c];
+      p->wq.upload(w); p->wqT.upload(wt); p->dirty = false; p->dirtyL = true;
+    }
     const size_t S = (size_t) U * F, NE = (size_t) C * (C + 1) / 2;
+    // Zelinski: the register kernel for the small arrays it is instantiated for, the two streaming kernels for every other size (and on request)
+    const bool zsum = p->kind == 0 && (!(C == 2 || C == 3 || C == 4 || C == 6 || C == 8) || getenv("DSR_PF_SUM"));
     // carried state: densities [entry][U x F] + frames seen per stream (double buffered: a call reads one array and writes the other)
     int carryIn = 0, carryOut = 0; const int* seenIn = nullptr; int* seenOut = nullptr;
     if (p->carry) {
       if (p->haveState && p->stateU != U) throw Error(DSR_E_CONSISTENCY, "post-filter: the carried state holds %d streams, this call has %d (reset the state first)", p->stateU, U);
-      p->state.reserve(S * NE); p->seen[0].reserve(U); p->seen[1].reserve(U);
+      p->state.reserve(zsum ? 2 * S : S * NE); p->seen[0].reserve(U); p->seen[1].reserve(U);
       carryIn = p->haveState ? 1 : 0; carryOut = 1;
       seenIn = p->haveState ? p->seen[p->seenCur].p : nullptr; seenOut = p->seen[p->seenCur ^ 1].p;
     }
-    const bool wave = C > 16 || getenv("DSR_PF_WAVE");
+    const bool wave = !zsum && (C > 16 || getenv("DSR_PF_WAVE"));
     if (wave) {
       if (!p->pairIJ.p) { std::vector<unsigned short> t; for (int i = 0; i < C - 1; i++) for (int j = i + 1; j < C; j++) t.push_back((unsigned short) (i | (j << 8))); p->pairIJ.upload(t); }
       if (!p->carry) p->state.reserve(16);
@@ -538,7 +566,14 @@ dsr_status dsr_zelinski_apply(dsr_zelinski* p, const float* X, const float* Y, c
       }
     }
 #define PF_TAIL seenIn, seenOut, carryIn, carryOut
-    if (wave) {
+    if (zsum) {
+      if (!p->carry) p->state.reserve(16);
+      ZelinskiPlan::PE& pe = p->pe.at(st); const size_t TF = (size_t) Tmax * F;
+      pe.P.reserve((size_t) U * TF); pe.E.reserve((size_t) U * TF);
+      hipLaunchKernelGGL(k_zel_pairs, dim3((unsigned) ((TF + 255) / 256), (unsigned) U), dim3(256), 0, st, (const float2*) X, nframes_dev, p->wqT.p, pe.P.p, pe.E.p, C, Tmax, F);
+      hipLaunchKernelGGL(k_zel_recur, dim3((unsigned) ((S + 63) / 64)), dim3(64), 0, st, pe.P.p, pe.E.p, (const float2*) Y, nframes_dev, p->state.p, (float2*) out, wp1,
+                         U, C, Tmax, F, p->alpha, p->type, p->minFrames, PF_TAIL);
+    } else if (wave) {
       const size_t ldsPf = p->kind ? sizeof(double2) * (size_t) C * (C - 1) / 2 : 0;
 #define PFW(K) hipLaunchKernelGGL((k_pf_wave<K>), dim3((unsigned) S), dim3(64), ldsPf, st, (const float2*) X, (const float2*) Y, nframes_dev, p->wq.p, p->R.p, p->pairIJ.p, p->state.p, \
                                   (float2*) out, wp1, U, C, Tmax, F, p->alpha, p->type, p->minFrames, p->threshold, p->kind == 2 ? p->lambda.p : nullptr, p->fbinX1, PF_TAIL)
@@ -553,14 +588,11 @@ dsr_status dsr_zelinski_apply(dsr_zelinski* p, const float* X, const float* Y, c
       if (!regsM) { MC_LAUNCH(0) } else if (C == 8) { MC_LAUNCH(8) } else if (C == 6) { MC_LAUNCH(6) } else if (C == 4) { MC_LAUNCH(4) } else if (C == 3) { MC_LAUNCH(3) } else { MC_LAUNCH(2) }
 #undef MC_LAUNCH
     } else {
-      const bool regs = !getenv("DSR_PF_MEMSTATE") && (C == 2 || C == 3 || C == 4 || C == 6 || C == 8);
-      if (!p->carry) p->state.reserve(regs ? 16 : S * NE);
+      if (!p->carry) p->state.reserve(16);
 #define ZREG(CC) if (C == CC) hipLaunchKernelGGL(k_zelinski_reg<CC>, dim3((unsigned) ((S + 63) / 64)), dim3(64), 0, st, (const float2*) X, (const float2*) Y, \
       nframes_dev, p->wq.p, (float2*) out, wp1, U, Tmax, F, p->alpha, p->type, p->minFrames, seenIn, seenOut, p->state.p, carryIn, carryOut);
-      if (regs) { ZREG(2) ZREG(3) ZREG(4) ZREG(6) ZREG(8) }
+      ZREG(2) ZREG(3) ZREG(4) ZREG(6) ZREG(8)
 #undef ZREG
-      else hipLaunchKernelGGL(k_zelinski, dim3((unsigned) ((S + 127) / 128)), dim3(128), 0, st, (const float2*) X, (const float2*) Y, nframes_dev, p->wq.p, p->state.p,
-                              (float2*) out, wp1, U, C, Tmax, F, p->alpha, p->type, p->minFrames, seenIn, seenOut);
     }
 #undef PF_TAIL
     DSR_HIP(hipGetLastError());

@@ -261,3 +261,74 @@ def test_gsc_rls_ragged_and_carried(dsr, oracle, cuda, Cn, qc):
     bf.rlsResetState()                                                     # fresh streams start from P0 and zero weights again
     Yd, _ = bf.gsc_rls(torch.from_numpy(np.ascontiguousarray(X[:, :, :cut])).to(cuda))
     assert torch.equal(Yd, Ya)
+
+
+def test_ten_minute_stream_in_sixty_blocks(dsr, oracle, cuda):
+    """BASELINE configs[4] at its own length: a 10-minute 64-channel stream handed over in sixty 10-second blocks (the last one ragged).  Errors of the
+    carried state -- filter-bank history, post-filter densities, WPE filters -- that need many blocks to show would show here:
+      * analysis -> MVDR -> Zelinski -> synthesis block by block = the same operators run ONCE over the whole stream on the device;
+      * the first block against the oracle (analysis, MVDR weights through the restated csvdc, Zelinski);
+      * WPE of a late block (the 58th) against the oracle started from the filters the device carried into that block."""
+    import torch
+    from bench_streams import planar_array, planar_block
+    M, m, r = 256, 4, 1
+    D = M >> r; F = M // 2 + 1
+    h, g = load_proto("M256-m4-r1")
+    mp = planar_array(); Cn = mp.shape[0]
+    nblk, nb = 60, 1250 * D
+    N = nblk * nb + 57
+    x = planar_block(torch, cuda, 1, mp, N, seed=4242)                             # [1][64][N] on the device (2.5 GB)
+    delays = dsr.calcDelaysPolar2(np.float32(0.6), np.float32(1.1), mp)
+    bf = dsr.Beamformer(M, Cn); bf.calcArrayManifoldVectors(16000.0, delays); bf.setDiffuseNoiseModel(mp, 16000.0, 343740.0)
+    bf.divideAllNonDiagonalElements(0.01); bf.calcMVDRWeights(16000.0, 1e-8); bf.select("mvdr")
+    W = bf.get(1); wq = bf.get(0)
+    ana = dsr.FilterBank(h, M, m, r, False, 0); syn = dsr.FilterBank(g, M, m, r, True, 0)
+    sa = dsr.FilterBankState(ana, 1, Cn); ss = dsr.FilterBankState(syn, 1); sw = dsr.FilterBankState(syn, 1)
+    pf = dsr.ZelinskiPostFilter(M, Cn, wq[:F], alpha=0.6, type=2, minFrames=0); pf.carry(True)
+    lowerN, upperN = 2, 5
+    gn = torch.zeros((1, F, upperN - lowerN + 1), dtype=torch.complex128, device=cuda)
+    Ys, Zs, ys, yw = [], [], [], []
+    probe = {}
+    for b in range(nblk):
+        lo = b * nb; hi = N if b == nblk - 1 else lo + nb
+        X = sa.analysis_block(x[:, :, lo:hi].contiguous(), last=(b == nblk - 1))
+        Y = bf.apply(X); Z = pf.apply(X, Y)
+        if b == 57:
+            probe["gn"] = gn.clone(); probe["Z"] = Z.clone()
+        V, gn = dsr.wpe_single(Z, M, lowerN, upperN, 2, -20.0, 0.0, 16000.0, gn=gn)
+        if b == 57:
+            probe["V"] = V.clone()
+        if b == 0:
+            probe["X0"] = X.cpu().numpy(); probe["Y0"] = Y.cpu().numpy(); probe["Z0"] = Z.cpu().numpy()
+        Ys.append(Y); Zs.append(Z); ys.append(ss.synthesis_block(Z)); yw.append(sw.synthesis_block(V))
+        del X
+    Yb = torch.cat(Ys, 1); Zb = torch.cat(Zs, 1); yb = torch.cat(ys, 1); ywb = torch.cat(yw, 1)
+    assert bool(torch.isfinite(ywb).all()) and float(ywb.abs().max()) > 0.0        # the dereverberated stream stays finite over all sixty blocks
+    # ---- one run over the whole stream
+    X1 = ana.analysis(x); assert X1.shape[2] == Yb.shape[1]
+    Y1 = bf.apply(X1)
+    pf1 = dsr.ZelinskiPostFilter(M, Cn, wq[:F], alpha=0.6, type=2, minFrames=0)
+    Z1 = pf1.apply(X1, Y1); del X1
+    y1 = syn.synthesis_run(Z1)
+    assert float((Y1 - Yb).abs().max()) <= 1e-6 * float(Y1.abs().max())
+    assert float((Z1 - Zb).abs().max()) <= 1e-5 * float(Z1.abs().max())
+    assert y1.shape == yb.shape and float((y1 - yb).abs().max()) <= 1e-5 * float(y1.abs().max())
+    # ---- the first block against the oracle
+    x0 = x[0, :, :nb].cpu().numpy()
+    Ro = oracle.diffuse_noise_model(mp, M, 16000.0, 343740.0, mu=0.01)
+    Wo = oracle.mvdr_weights(oracle.calc_mainlobe(16000.0, delays, M), Ro, 1e-8)
+    assert np.abs(W - Wo).max() <= 1e-12 * np.abs(Wo).max()
+    # (the block's frames reach no further than its own samples: the oracle run on the block alone gives those frames; its zero-input tail frames are dropped)
+    Xo = np.stack([oracle.analysis_bank(x0[c], h, M, m, r, 0) for c in range(Cn)])[:, :probe["X0"].shape[2]]
+    rms = np.sqrt(np.mean(np.abs(Xo[:, :, :F]) ** 2))
+    assert np.abs(probe["X0"][0] - Xo[:, :, :F]).max() < 2e-5 * rms * np.sqrt(M)
+    Yo = oracle.beamform_apply(Xo, Wo)
+    rmsY = np.sqrt(np.mean(np.abs(Yo[:, :F]) ** 2))
+    assert np.abs(probe["Y0"][0] - Yo[:, :F]).max() < 2e-5 * rmsY * np.sqrt(M)
+    Zo, _ = oracle.zelinski_postfilter(Xo[:, :, :F], Yo[:, :F], wq[:F], 0.6, 2, 0)
+    assert np.abs(probe["Z0"][0] - Zo).max() < 2e-5 * rmsY * np.sqrt(M)
+    # ---- WPE of block 58, from the filters the device carried into it
+    Zp = probe["Z"][0].cpu().numpy().astype(np.complex128)
+    gn0 = np.ascontiguousarray(_full(probe["gn"][0].cpu().numpy().T, M).T)               # [F][P] -> [M][P]: the mirrored bins carry the conjugate filters
+    Vo, _ = oracle.wpe_single(_full(Zp, M), lowerN, upperN, 2, -20.0, 0.0, 16000.0, gnInit=gn0)
+    assert np.abs(probe["V"][0].cpu().numpy() - Vo[:, :F]).max() < 1e-4 * np.sqrt(np.mean(np.abs(Zp) ** 2)) * np.sqrt(M)
