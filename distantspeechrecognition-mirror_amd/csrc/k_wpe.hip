@@ -16,8 +16,8 @@
 namespace dsr {
 
 __global__ __launch_bounds__(256) void k_wpe(const float2* __restrict__ Y, const int* __restrict__ nframesArr, float2* __restrict__ out,
-                                             double2* __restrict__ gnOut, int U, int Nmax, int F, int M, int lowerN, int P, int iterationsN,
-                                             double loadFactor, int lowerBW, const double2* __restrict__ gnIn)
+                                             double2* gnOut, int U, int Nmax, int F, int M, int lowerN, int P, int iterationsN,
+                                             double loadFactor, int lowerBW, const double2* gnIn)      // (gnIn and gnOut may be ONE buffer -- dsr_wpe_single_continue: no __restrict__)
 {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   double2* y = reinterpret_cast<double2*>(smem);                 // [N]
@@ -122,21 +122,37 @@ __global__ __launch_bounds__(256) void k_wpe(const float2* __restrict__ Y, const
 }
 
 
-// MultiChannelWPEDereverberation (dereverberation.cc:281-586).  One workgroup owns one (utterance, subband, channel): the subband's series of
-// ALL channels sit in LDS (fp32 as delivered, widened when used), the stacked lag vector is [channel][lag] (_getLags :422-437), theta_n,
-// the (C P) x (C P) weighted correlation matrix, its loading, Cholesky and the prediction filter are this channel's (:439-573).
-// The filters go to memory; k_wpe_multi_out then subtracts the predictions (getOutput :365-395).
-__global__ __launch_bounds__(256) void k_wpe_multi(const float2* __restrict__ Y, const int* __restrict__ nframesArr, double2* __restrict__ gnOut,
-                                                   int* __restrict__ failOut, int U, int C, int Nmax, int F, int M, int lowerN, int P, int iterationsN,
+// MultiChannelWPEDereverberation (dereverberation.cc:281-586).  One workgroup owns one (utterance, subband, channel): theta_n, the stacked lag
+// vector [channel][lag] (_getLags :422-437), the (C P) x (C P) weighted correlation matrix, its loading, Cholesky and the prediction filter are
+// this channel's (:439-573).  The matrix is Hermitian: only its lower triangle is kept, packed (entry (i, j), j <= i, at i (i + 1) / 2 + j) -- half
+// the LDS of the square, which is what lets 8 channels x 10 taps (80 x 80) sit next to the subband's series of all channels at the benchmark's
+// 1257 frames.  YLDS: the series (fp32 as delivered, widened when used) are staged in LDS; otherwise they are read from a copy of the snapshots
+// transposed to [utterance][subband][channel][frame] (k_wpe_series: contiguous per subband, so the accumulation loops hit L1/L2 lines whole) and
+// only the matrix, the filters and 1 / theta_n live in LDS.  The filters go to memory; k_wpe_multi_out then subtracts the predictions (getOutput :365-395).
+__global__ __launch_bounds__(256) void k_wpe_series(const float2* __restrict__ Y, float2* __restrict__ Yt, int C, int Nmax, int F)
+{
+  // Yt[((u F + b) C + ch) Nmax + n] = Y[((u C + ch) Nmax + n) F + b]: a 32 x 32 (frame, bin) tile per workgroup through LDS, both sides coalesced
+  __shared__ float2 tile[32][33];
+  const int uc = blockIdx.z, u = uc / C, ch = uc - u * C;
+  const int n0 = blockIdx.y * 32, b0 = blockIdx.x * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int j = ty; j < 32; j += 8) { const int n = n0 + j, b = b0 + tx; if (n < Nmax && b < F) tile[j][tx] = Y[((long) uc * Nmax + n) * F + b]; }
+  __syncthreads();
+  for (int j = ty; j < 32; j += 8) { const int b = b0 + j, n = n0 + tx; if (n < Nmax && b < F) Yt[(((long) u * F + b) * C + ch) * Nmax + n] = tile[tx][j]; }
+}
+
+template <bool YLDS>
+__global__ __launch_bounds__(256) void k_wpe_multi(const float2* __restrict__ Y, const float2* __restrict__ Yt, const int* __restrict__ nframesArr,
+                                                   double2* __restrict__ gnOut, int U, int C, int Nmax, int F, int M, int lowerN, int P, int iterationsN,
                                                    double loadFactor, int lowerBW)
 {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const int PT = P * C;
-  double2* R = reinterpret_cast<double2*>(smem);                 // [PT][PT] lower triangle
-  double2* r = R + PT * PT;                                      // [PT]
+  const int PT = P * C, nEnt = PT * (PT + 1) / 2;
+  double2* R = reinterpret_cast<double2*>(smem);                 // packed lower triangle
+  double2* r = R + nEnt;                                         // [PT]
   double2* g = r + PT;                                           // [PT]
   double* rth = reinterpret_cast<double*>(g + PT);               // [N]  1 / theta_n
-  float2* y = reinterpret_cast<float2*>(rth + Nmax);             // [C][N]
+  float2* yl = reinterpret_cast<float2*>(rth + Nmax);            // [C][N] (YLDS)
   __shared__ int s_fail;
   const int tid = threadIdx.x, nthr = blockDim.x;
   const int b = blockIdx.x, c0 = blockIdx.y, u = blockIdx.z;
@@ -144,7 +160,9 @@ __global__ __launch_bounds__(256) void k_wpe_multi(const float2* __restrict__ Y,
   const bool selected = (b <= lowerBW) || (b >= M - lowerBW);    // dereverberation.cc:552
   double2* gOut = gnOut + (((long) u * C + c0) * F + b) * PT;
   if (!selected) { for (int l = tid; l < PT; l += nthr) gOut[l] = make_double2(0.0, 0.0); return; }
-  for (int i = tid; i < C * N; i += nthr) { const int ch = i / N, n = i - ch * N; y[ch * Nmax + n] = Y[(((long) u * C + ch) * Nmax + n) * F + b]; }
+  if (YLDS) for (int i = tid; i < C * N; i += nthr) { const int ch = i / N, n = i - ch * N; yl[ch * Nmax + n] = Y[(((long) u * C + ch) * Nmax + n) * F + b]; }
+  const float2* y = YLDS ? yl : Yt + ((long) u * F + b) * C * Nmax;      // [C][Nmax] either way (two instantiations: no pointer select at run time)
+  auto tri = [](int i, int j) { return i * (i + 1) / 2 + j; };
   for (int l = tid; l < PT; l += nthr) g[l] = make_double2(0.0, 0.0);
   if (tid == 0) s_fail = 0;
   __syncthreads();
@@ -165,7 +183,6 @@ __global__ __launch_bounds__(256) void k_wpe_multi(const float2* __restrict__ Y,
       rth[n] = 1.0 / (th * th);
     }
     __syncthreads();
-    const int nEnt = PT * (PT + 1) / 2;
     for (int e = tid; e < nEnt + PT; e += nthr) {                // _calculateRr: lower triangle of R, then r
       double sr = 0.0, si = 0.0;
       if (e < nEnt) {
@@ -177,11 +194,11 @@ __global__ __launch_bounds__(256) void k_wpe_multi(const float2* __restrict__ Y,
           const float2 a = yr[n], q = yc[n]; const double w = rth[n];
           sr += ((double) a.x * (double) q.x + (double) a.y * (double) q.y) * w; si += ((double) a.y * (double) q.x - (double) a.x * (double) q.y) * w;
         }
-        R[row * PT + col] = make_double2(sr, si);
+        R[e] = make_double2(sr, si);                             // (e IS the packed index of (row, col))
       } else {
         const int l = e - nEnt;
-        const int chL = l / P, lL = l - chL * P; const float2* yl = y + chL * Nmax - lowerN - lL;
-        for (int n = lowerN + lL; n < N; n++) { const float2 v = y[c0 * Nmax + n], a = yl[n]; const double w = rth[n];
+        const int chL = l / P, lL = l - chL * P; const float2* ylag = y + chL * Nmax - lowerN - lL;
+        for (int n = lowerN + lL; n < N; n++) { const float2 v = y[c0 * Nmax + n], a = ylag[n]; const double w = rth[n];
           sr += ((double) v.x * (double) a.x + (double) v.y * (double) a.y) * w; si += ((double) v.x * (double) a.y - (double) v.y * (double) a.x) * w; }
         r[l] = make_double2(sr, si);
       }
@@ -189,23 +206,23 @@ __global__ __launch_bounds__(256) void k_wpe_multi(const float2* __restrict__ Y,
     __syncthreads();
     if (tid == 0) {                                              // _loadR
       double maxd = 0.0;
-      for (int k = 0; k < PT; k++) { const double d = hypot(R[k * PT + k].x, R[k * PT + k].y); if (d > maxd) maxd = d; }
-      for (int k = 0; k < PT; k++) { const double d = hypot(R[k * PT + k].x, R[k * PT + k].y) + maxd * loadFactor; R[k * PT + k] = make_double2(d, 0.0); }
+      for (int k = 0; k < PT; k++) { const double2 v = R[tri(k, k)]; const double d = hypot(v.x, v.y); if (d > maxd) maxd = d; }
+      for (int k = 0; k < PT; k++) { const double2 v = R[tri(k, k)]; const double d = hypot(v.x, v.y) + maxd * loadFactor; R[tri(k, k)] = make_double2(d, 0.0); }
     }
     __syncthreads();
     for (int j = 0; j < PT; j++) {                               // Cholesky (lower): the diagonal entry by one thread, the column below it by all
       if (tid == 0) {
-        double ajj = R[j * PT + j].x;
-        for (int k = 0; k < j; k++) ajj -= R[j * PT + k].x * R[j * PT + k].x + R[j * PT + k].y * R[j * PT + k].y;
-        if (ajj <= 0.0) s_fail = 1; else R[j * PT + j] = make_double2(sqrt(ajj), 0.0);
+        double ajj = R[tri(j, j)].x;
+        for (int k = 0; k < j; k++) { const double2 v = R[tri(j, k)]; ajj -= v.x * v.x + v.y * v.y; }
+        if (ajj <= 0.0) s_fail = 1; else R[tri(j, j)] = make_double2(sqrt(ajj), 0.0);
       }
       __syncthreads();
       if (s_fail) break;
-      const double ajj = R[j * PT + j].x;
+      const double ajj = R[tri(j, j)].x;
       for (int i = j + 1 + tid; i < PT; i += nthr) {
-        double sr = R[i * PT + j].x, si = R[i * PT + j].y;
-        for (int k = 0; k < j; k++) { const double2 a = R[i * PT + k], q = R[j * PT + k]; sr -= a.x * q.x + a.y * q.y; si -= a.y * q.x - a.x * q.y; }
-        R[i * PT + j] = make_double2(sr / ajj, si / ajj);
+        double sr = R[tri(i, j)].x, si = R[tri(i, j)].y;
+        for (int k = 0; k < j; k++) { const double2 a = R[tri(i, k)], q = R[tri(j, k)]; sr -= a.x * q.x + a.y * q.y; si -= a.y * q.x - a.x * q.y; }
+        R[tri(i, j)] = make_double2(sr / ajj, si / ajj);
       }
       __syncthreads();
     }
@@ -213,20 +230,19 @@ __global__ __launch_bounds__(256) void k_wpe_multi(const float2* __restrict__ Y,
       if (!s_fail) {
         for (int i = 0; i < PT; i++) {
           double sr = r[i].x, si = r[i].y;
-          for (int k = 0; k < i; k++) { const double2 a = R[i * PT + k]; sr -= a.x * g[k].x - a.y * g[k].y; si -= a.x * g[k].y + a.y * g[k].x; }
-          const double d = R[i * PT + i].x; g[i] = make_double2(sr / d, si / d);
+          for (int k = 0; k < i; k++) { const double2 a = R[tri(i, k)]; sr -= a.x * g[k].x - a.y * g[k].y; si -= a.x * g[k].y + a.y * g[k].x; }
+          const double d = R[tri(i, i)].x; g[i] = make_double2(sr / d, si / d);
         }
         for (int i = PT - 1; i >= 0; i--) {
           double sr = g[i].x, si = g[i].y;
-          for (int k = i + 1; k < PT; k++) { const double ar = R[k * PT + i].x, ai = -R[k * PT + i].y; sr -= ar * g[k].x - ai * g[k].y; si -= ar * g[k].y + ai * g[k].x; }
-          const double d = R[i * PT + i].x; g[i] = make_double2(sr / d, si / d);
+          for (int k = i + 1; k < PT; k++) { const double ar = R[tri(k, i)].x, ai = -R[tri(k, i)].y; sr -= ar * g[k].x - ai * g[k].y; si -= ar * g[k].y + ai * g[k].x; }
+          const double d = R[tri(i, i)].x; g[i] = make_double2(sr / d, si / d);
         }
       }
     }
     __syncthreads();
     if (s_fail) break;
   }
-  if (s_fail && tid == 0) atomicExch(&failOut[u], 1);
   for (int l = tid; l < PT; l += nthr) gOut[l] = s_fail ? make_double2(NAN, NAN) : g[l];
 }
 
@@ -311,13 +327,26 @@ dsr_status dsr_wpe_multi(const float* Y_dev, const int32_t* nframes_dev, int U, 
     require_device();
     const int P = upperN - lowerN + 1, F = fftLen / 2 + 1, PT = P * chanN;
     const int lowerBW = (bandWidth == 0.0) ? fftLen / 2 : (int) (unsigned) ((bandWidth / (sampleRate / 2.0)) * (fftLen / 2));
-    const size_t lds = (size_t) (PT * PT + 2 * PT) * 16 + (size_t) Nmax * 8 + (size_t) chanN * Nmax * 8;
-    if (lds > 150 * 1024) throw Error(DSR_E_DIMENSION, "WPE: %d channels x %d frames x %d taps do not fit the LDS working set", chanN, Nmax, P);
+    // LDS: packed triangle + r + g + 1 / theta_n, and the series of all channels when they fit beside them; otherwise the series come from a
+    // transposed copy of the snapshots in memory (one per stream: the copy is handed from its kernel to the estimation kernel of the same stream)
+    const size_t ldsCore = ((size_t) PT * (PT + 1) / 2 + 2 * (size_t) PT) * 16 + (size_t) Nmax * 8, ldsSeries = (size_t) chanN * Nmax * 8, ldsCap = 150 * 1024;
+    if (ldsCore > ldsCap) throw Error(DSR_E_DIMENSION, "WPE: %d channels x %d taps (a %d x %d matrix) and %d frames do not fit the LDS working set", chanN, P, PT, PT, Nmax);
+    const bool yLds = ldsCore + ldsSeries <= ldsCap && !getenv("DSR_WPE_SERIES_MEM");
     hipStream_t st = (hipStream_t) stream;
-    static PerStream<DevBuf<int>> failBy; DevBuf<int>& fail = failBy.at(st); fail.reserve(U); DSR_HIP(hipMemsetAsync(fail.p, 0, sizeof(int) * U, st));
-    DSR_HIP(hipFuncSetAttribute((const void*) k_wpe_multi, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
-    hipLaunchKernelGGL(k_wpe_multi, dim3(F, chanN, U), dim3(256), lds, st, (const float2*) Y_dev, nframes_dev, (double2*) gn_dev, fail.p,
-                       U, chanN, Nmax, F, fftLen, lowerN, P, iterationsN, pow(10.0, loadDb / 10.0), lowerBW);
+    if (yLds) {
+      const size_t lds = ldsCore + ldsSeries;
+      DSR_HIP(hipFuncSetAttribute((const void*) k_wpe_multi<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
+      hipLaunchKernelGGL(k_wpe_multi<true>, dim3(F, chanN, U), dim3(256), lds, st, (const float2*) Y_dev, (const float2*) nullptr, nframes_dev, (double2*) gn_dev,
+                         U, chanN, Nmax, F, fftLen, lowerN, P, iterationsN, pow(10.0, loadDb / 10.0), lowerBW);
+    } else {
+      float2* Yt = nullptr;                                          // stream-ordered scratch: lives from here to the end of the estimation kernel on this stream
+      DSR_HIP(hipMallocAsync((void**) &Yt, sizeof(float2) * (size_t) U * F * chanN * Nmax, st));
+      hipLaunchKernelGGL(k_wpe_series, dim3((F + 31) / 32, (Nmax + 31) / 32, U * chanN), dim3(256), 0, st, (const float2*) Y_dev, Yt, chanN, Nmax, F);
+      DSR_HIP(hipFuncSetAttribute((const void*) k_wpe_multi<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) ldsCore));
+      hipLaunchKernelGGL(k_wpe_multi<false>, dim3(F, chanN, U), dim3(256), ldsCore, st, (const float2*) Y_dev, (const float2*) Yt, nframes_dev, (double2*) gn_dev,
+                         U, chanN, Nmax, F, fftLen, lowerN, P, iterationsN, pow(10.0, loadDb / 10.0), lowerBW);
+      DSR_HIP(hipFreeAsync(Yt, st));
+    }
     DSR_HIP(hipGetLastError());
     const long tot = (long) U * chanN * Nmax * F;
     hipLaunchKernelGGL(k_wpe_multi_out, dim3((unsigned) ((tot + 255) / 256)), dim3(256), 0, st, (const float2*) Y_dev, nframes_dev, (const double2*) gn_dev,

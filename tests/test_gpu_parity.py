@@ -1374,3 +1374,37 @@ def test_beamformer_half_band_shift(dsr, oracle, cuda, mode):
         bf.rlsConfig(0.9, 0.0); bf.initPrecisionMatrix(0.01)
         with pytest.raises(dsr.DsrError):
             bf.gsc_rls(torch.from_numpy(X[:, :, :, :M // 2 + 1].copy()).to(cuda))       # "not yet implemented"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("series_in_memory", [False, True])
+def test_wpe_multi_at_benchmark_size(dsr, oracle, cuda, monkeypatch, series_in_memory):
+    """Multi-channel WPE at the benchmark's own utterance size: 8 channels x 1257 frames x 10 taps -- an 80 x 80 normal matrix per (subband, channel),
+    kept as a packed triangle next to the subband's series of all channels (145 KB of LDS; the square layout needed 192 KB and was refused).  Second case:
+    the series read from the transposed copy in memory instead of LDS (what larger tap counts fall back to).  Few subbands: the oracle's cost is per
+    subband and the limit being tested is per (channels, frames, taps).  dereverberation.cc:397-620."""
+    import torch
+    if series_in_memory:
+        monkeypatch.setenv("DSR_WPE_SERIES_MEM", "1")
+    rng = np.random.default_rng(77)
+    U, Cn, N, M = 1, 8, 1257, 8
+    F = M // 2 + 1
+    lowerN, upperN = 2, 11
+    s = rng.standard_normal((U, 1, N, F)) + 1j * rng.standard_normal((U, 1, N, F))
+    Y = np.zeros((U, Cn, N, F), np.complex128)
+    for c in range(Cn):
+        Y[:, c] = s[:, 0] * np.exp(1j * c) + 0.1 * (rng.standard_normal((U, N, F)) + 1j * rng.standard_normal((U, N, F)))
+        for k in range(1, 14):
+            Y[:, c, k:] += (0.5 + 0.04 * c) ** k * np.roll(s[:, 0], k, axis=1)[:, k:] * np.exp(1j * k * (c + 1))
+    Y = Y.astype(np.complex64)
+    out, gn = dsr.wpe_multi(torch.from_numpy(Y).to(cuda), M, lowerN, upperN, 2, -20.0, 0.0, 16000.0, filterChan=-1)
+    out, gn = out.cpu().numpy(), gn.cpu().numpy()
+    f = np.zeros((Cn, N, M), np.complex128); f[:, :, :F] = Y[0]; f[:, :, F:] = np.conj(Y[0][:, :, 1:F - 1][:, :, ::-1])
+    wo, wg = oracle.wpe_multi(f, lowerN, upperN, 2, -20.0, 0.0, 16000.0, filterChan=-1)
+    assert np.isfinite(gn).all()
+    np.testing.assert_allclose(gn[0], wg[:, :F], rtol=2e-6, atol=1e-9)
+    assert np.abs(out[0] - wo[:, :, :F]).max() <= 2e-6 * np.abs(wo).max()
+    # dereverberation does something: the late part of the response is gone from the output's autocorrelation at the predicted lags
+    def late(a):
+        return np.mean([np.abs(np.vdot(a[0, :-k, 1], a[0, k:, 1])) for k in range(3, 10)]) / np.real(np.vdot(a[0, :, 1], a[0, :, 1]))
+    assert late(out[0]) < 0.9 * late(Y[0].astype(np.complex128))
