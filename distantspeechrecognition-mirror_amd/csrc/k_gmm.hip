@@ -32,8 +32,10 @@ __global__ __launch_bounds__(256) void k_gmm_exact(const float* __restrict__ x, 
                                                    const float* __restrict__ mean, const float* __restrict__ ivar,
                                                    const float* __restrict__ cst, const float* __restrict__ val,
                                                    const float* __restrict__ scale, float* __restrict__ score,
-                                                   unsigned char* __restrict__ argmin, int chunkG)
+                                                   unsigned char* __restrict__ argmin, int chunkG, int finish)
 {
+  // finish 0: _scoreOpt's 0.5 (min + 2 val) x codebook scale (codebookBasic.cc:533-549); 1 / 2: CodebookBasic::logLhood's own rounding,
+  // 0.5 min + val[argmin] / 0.5 min when val is NULL, no scale (:600-606)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   float* sm = reinterpret_cast<float*>(smem);            // [chunkG][DP] means
   float* sv = sm + (size_t) chunkG * DP;                  // [chunkG][DP] inverse variances
@@ -70,8 +72,14 @@ __global__ __launch_bounds__(256) void k_gmm_exact(const float* __restrict__ x, 
         if (dist < minDist) { minDist = dist; minIdx = g - a; }
       }
       if (live) {
-        float sc = (float) (0.5 * (double) __fadd_rn(minDist, __fmul_rn(2.0f, val[off[kk] + minIdx])));
-        const float s = scale[kk]; if (s != 1.0f) sc = __fmul_rn(sc, s);
+        float sc;
+        if (finish == 0) {
+          sc = (float) (0.5 * (double) __fadd_rn(minDist, __fmul_rn(2.0f, val[off[kk] + minIdx])));
+          const float s = scale[kk]; if (s != 1.0f) sc = __fmul_rn(sc, s);
+        } else {
+          sc = __fmul_rn(minDist, 0.5f);                                   // "minDistSum *= 0.5" (exact), then "+= val[minDistIdx]" in float
+          if (finish == 1) sc = __fadd_rn(sc, val[off[kk] + minIdx]);
+        }
         tile[threadIdx.x * (kTW + 1) + (kk - k)] = sc;
         if (argmin) tileI[threadIdx.x * (kTW + 4) + (kk - k)] = (unsigned char) minIdx;
       }
@@ -322,7 +330,14 @@ dsr_status dsr_gmm_find_dist(const dsr_gmm* g, const char* name, int* distX)
   });
 }
 
+static dsr_status gmm_score_impl(dsr_gmm* m, const float* x, int64_t N, int mode, int finish, float* score, uint8_t* argmin, void* stream);
 dsr_status dsr_gmm_score(dsr_gmm* m, const float* x, int64_t N, int mode, float* score, uint8_t* argmin, void* stream)
+{ return gmm_score_impl(m, x, N, mode, 0, score, argmin, stream); }
+// CodebookBasic::logLhood(frame, val) (codebookBasic.cc:557-609) for every (frame, codebook) of a batch: the nearest Gaussian as _scoreOpt finds it
+// (same accumulation order, strict '<'; the early exit cannot change it) but finished as that method does: 0.5 * min, + val[argmin] when useVal
+dsr_status dsr_gmm_log_lhood(dsr_gmm* m, const float* x, int64_t N, int useVal, float* score, uint8_t* argmin, void* stream)
+{ return gmm_score_impl(m, x, N, 0, useVal ? 1 : 2, score, argmin, stream); }
+static dsr_status gmm_score_impl(dsr_gmm* m, const float* x, int64_t N, int mode, int finish, float* score, uint8_t* argmin, void* stream)
 {
   return guard([&] {
     if (!m || !x || !score) throw Error(DSR_E_PARAMETER, "null argument");
@@ -336,7 +351,7 @@ dsr_status dsr_gmm_score(dsr_gmm* m, const float* x, int64_t N, int mode, float*
       dim3 grid(cdiv(N, 256));
 #define LAUNCH(DPV) { DSR_HIP(hipFuncSetAttribute((const void*) k_gmm_exact<DPV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds)); \
       hipLaunchKernelGGL(k_gmm_exact<DPV>, grid, dim3(256), lds, st, x, (long) N, m->D, m->K, m->d_off.p, m->d_mean.p, m->d_ivar.p, \
-                         m->d_cst.p, m->d_val.p, m->d_scale.p, score, argmin, chunkG); }
+                         m->d_cst.p, m->d_val.p, m->d_scale.p, score, argmin, chunkG, finish); }
       if (m->Dp == 16) LAUNCH(16) else if (m->Dp == 40) LAUNCH(40) else if (m->Dp == 64) LAUNCH(64) else LAUNCH(128)
 #undef LAUNCH
       DSR_HIP(hipGetLastError());

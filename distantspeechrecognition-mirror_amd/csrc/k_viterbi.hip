@@ -1316,7 +1316,7 @@ struct DecoderState {
   DevBuf<XRec> d_xrec; DevBuf<ERec> d_erec; DevBuf<float> d_arcCost, d_nodeCost; DevBuf<uint32_t> d_arcOut, d_arcIn;
   DevBuf<TokA> d_tokA, d_ctok; DevBuf<TokB> d_tokB; DevBuf<Side> d_side; DevBuf<XRecD> d_xrecD; int fastOK = 0; int maxCnt = 0; DevBuf<int> d_tokOff, d_tokCnt, d_owner, d_rank, d_chead; DevBuf<unsigned> d_tags; DevBuf<CandA> d_cA; DevBuf<CandB> d_cB; DevBuf<unsigned> d_first; DevBuf<Bp> d_arena;
   DevBuf<long long> d_prof; DevBuf<dsr_decode_result> d_res; DevBuf<int> d_arcs; DevBuf<unsigned> d_words;
-  long arenaCap = 0; int initial = 0;
+  long arenaCap = 0; int initial = 0; unsigned tokenMemoryLimit = 0;
   // lattice bookkeeping of the last decode (cfg.latticeTokens > 0), per utterance
   DevBuf<uint4> d_lat; DevBuf<double> d_latTtl; DevBuf<long> d_latFrameOff; DevBuf<int> d_arenaLat; DevBuf<int4> d_latFinal; DevBuf<int> d_latInfo;
   int latU = 0, latTmax = 0; long latArenaCap = 0; WfstGraph graphCopy; DevBuf<TokA> d_tokA3; DevBuf<TokB> d_tokB3;
@@ -1344,6 +1344,15 @@ void dsr_wfst_destroy(dsr_wfst* g) { delete g; }
 dsr_status dsr_wfst_read(dsr_wfst* g, const char* f, int binary) { return guard([&] { if (!g) throw Error(DSR_E_PARAMETER, "null argument"); g->read(f, binary != 0); }); }
 dsr_status dsr_wfst_read_dynamic(dsr_wfst* g, const char* f, int noSelfLoops) { return guard([&] { if (!g) throw Error(DSR_E_PARAMETER, "null argument"); g->readEx(f, false, noSelfLoops != 0); }); }
 dsr_status dsr_wfst_write(const dsr_wfst* g, const char* f, int binary) { return guard([&] { if (!g) throw Error(DSR_E_PARAMETER, "null argument"); g->write(f, binary != 0); }); }
+// WFSTFlyWeight::write(fileName, binary, useSymbols) (wfstFlyWeight.cc:415-463): with useSymbols every arc line carries the lexica's strings (Edge::write
+// :499-516: states too when the state lexicon is non-empty, costs below 1e-4 left out); final-state lines and -- with binary -- the end marker stay numeric
+dsr_status dsr_wfst_write_symbols(const dsr_wfst* g, const char* f, int binary, int useSymbols)
+{ return guard([&] { if (!g) throw Error(DSR_E_PARAMETER, "null argument"); g->write(f, binary != 0, useSymbols != 0); }); }
+// WFSTFlyWeight::reverse(wfst) (:141-213) and reverseRead(fileName) (:215-297)
+dsr_status dsr_wfst_reverse(dsr_wfst* g, const dsr_wfst* src)
+{ return guard([&] { if (!g || !src) throw Error(DSR_E_PARAMETER, "null argument"); g->reverse(*src); }); }
+dsr_status dsr_wfst_reverse_read(dsr_wfst* g, const char* f)
+{ return guard([&] { if (!g) throw Error(DSR_E_PARAMETER, "null argument"); g->reverseRead(f); }); }
 dsr_status dsr_wfst_add_arc(dsr_wfst* g, unsigned s1, unsigned s2, unsigned in, unsigned out, float cost)
 { return guard([&] { if (!g) throw Error(DSR_E_PARAMETER, "null argument"); g->addArc(s1, s2, in, out, cost, true); }); }
 dsr_status dsr_wfst_add_final(dsr_wfst* g, unsigned s, float cost) { return guard([&] { if (!g) throw Error(DSR_E_PARAMETER, "null argument"); g->addFinal(s, cost); }); }
@@ -1373,6 +1382,12 @@ dsr_status dsr_wfst_set_lexicons(dsr_wfst* g, dsr_lexicon* stateLex, dsr_lexicon
       if (!l) throw Error(DSR_E_KEY, "field '%s' is not a number and the transducer has no %s lexicon", t, which == 0 ? "state" : which == 1 ? "input" : "output");
       return l->index(t);
     };
+    g->nameOf = [g](int which, uint32_t i) -> std::string {
+      const dsr_lexicon* l = which == 0 ? g->lexState : which == 1 ? g->lexIn : g->lexOut;
+      if (!l) throw Error(DSR_E_KEY, "the transducer has no %s lexicon", which == 0 ? "state" : which == 1 ? "input" : "output");
+      return l->symbol(i);
+    };
+    g->stateLexSize = [g]() -> size_t { return g->lexState ? g->lexState->syms.size() : 0; };
   });
 }
 dsr_lexicon* dsr_wfst_state_lexicon(const dsr_wfst* g) { return g ? g->lexState : nullptr; }
@@ -1523,6 +1538,13 @@ dsr_status dsr_decoder_final_states_n(const dsr_decoder* d, int u, int* n)
 { return guard([&] { if (!n) throw Error(DSR_E_PARAMETER, "null argument"); need_last(d, u, false); *n = d->h_res.p[u].finalStatesN; }); }
 dsr_status dsr_decoder_trace_back_succeeded(const dsr_decoder* d, int u, int* ok)
 { return guard([&] { if (!ok) throw Error(DSR_E_PARAMETER, "null argument"); need_last(d, u, false); *ok = d->h_res.p[u].reachedFinal; }); }
+
+// _Decoder::setTokenMemoryLimit(limit) (decoder.h:396) caps the reference's Token memory pool (MemoryManager).  Tokens here live in per-slot
+// arrays sized by cfg.maxActive / maxCandidates / arenaTokens (a decode that outgrows them returns DSR_E_ALLOCATION for that utterance): there
+// is no pool to limit.  The value is accepted and kept so that drivers that set it run unchanged.
+dsr_status dsr_decoder_set_token_memory_limit(dsr_decoder* d, unsigned limit)
+{ return guard([&] { if (!d) throw Error(DSR_E_PARAMETER, "null argument"); d->tokenMemoryLimit = limit; }); }
+unsigned dsr_decoder_token_memory_limit(const dsr_decoder* d) { return d ? d->tokenMemoryLimit : 0u; }
 
 dsr_status dsr_decoder_set_beam(dsr_decoder* d, double beam) { return guard([&] { if (!d) throw Error(DSR_E_PARAMETER, "null argument"); d->cfg.beam = beam; }); }
 

@@ -58,7 +58,7 @@ namespace {
 hipStream_t S0 = nullptr;
 
 struct SampleSrc : dsr_stream {      // SampleFeature (feature.cc:222-689)
-  int blockLen, shiftLen, padZeros; std::vector<float> samples; DevBuf<float> dx;
+  int blockLen, shiftLen, padZeros; std::vector<float> samples; DevBuf<float> dx; int sampleRate = 16000, nChan = 1;
   void compute() override {
     const int n = (int) samples.size(); int T;
     if (padZeros) T = (n + shiftLen - 1) / shiftLen; else { long a = (long) n - blockLen; T = a > 0 ? (int) ((a + shiftLen - 1) / shiftLen) : 0; }
@@ -335,12 +335,85 @@ dsr_status dsr_sample_feature_create(int blockLen, int shiftLen, int padZeros, c
 }
 dsr_status dsr_sample_feature_set_samples(dsr_stream* s, const float* samples, size_t n, unsigned sampleRate)
 {
-  (void) sampleRate;
   return guard([&] {
     SampleSrc* q = dynamic_cast<SampleSrc*>(s); if (!q || (!samples && n)) throw Error(DSR_E_PARAMETER, "not a SampleFeature");
-    q->samples.assign(samples, samples + n); q->reset();                                       // setSamples() resets (feature.cc:688)
+    q->samples.assign(samples, samples + n); if (sampleRate) q->sampleRate = (int) sampleRate; q->reset();    // setSamples() resets (feature.cc:688)
   });
 }
+// SampleFeature::read(fn, format, samplerate, chX, chN, cfrom, to, outsamplerate, norm) (feature.cc:243-393).  The reference reads through libsndfile's
+// sf_readf_float; here: RIFF/WAVE PCM of 8, 16, 24 or 32 bits (format tag 1, or the extensible tag carrying PCM), parsed by hand.  norm == 0 keeps the
+// file's integer scale (SFC_SET_NORM_FLOAT off), otherwise samples are normalised to [-1, 1) and, for norm != 1, multiplied by norm.  The error branches
+// are the reference's: a file that cannot be opened or parsed and an empty sample range are jio errors, chX == 0 and chX out of range jconsistency
+// errors (in the reference's order: the range is checked before the channel).  Sample-rate conversion (outsamplerate != the file's rate; SRCONV builds
+// only) is refused.  format / samplerate / chN only steer libsndfile's RAW reader and are accepted for the signature.  *nread = frames read.
+dsr_status dsr_sample_feature_read(dsr_stream* s, const char* fn, int format, int samplerate, int chX, int chN, int cfrom, int to, int outsamplerate,
+                                   float norm, int* nread)
+{
+  (void) format; (void) samplerate; (void) chN;
+  return guard([&] {
+    SampleSrc* q = dynamic_cast<SampleSrc*>(s); if (!q || !fn) throw Error(DSR_E_PARAMETER, "not a SampleFeature");
+    FILE* fp = fopen(fn, "rb");
+    if (!fp) throw Error(DSR_E_IO, "Could not open file %s.", fn);
+    std::vector<unsigned char> raw; int nch = 0, bits = 0, rate = 0; long frames = 0; int sw = 0;
+    try {
+      auto rd = [&](void* p, size_t n) { if (fread(p, 1, n, fp) != n) throw Error(DSR_E_IO, "Could not open file %s.", fn); };
+      auto u32 = [&]() { unsigned char b[4]; rd(b, 4); return (unsigned) b[0] | (unsigned) b[1] << 8 | (unsigned) b[2] << 16 | (unsigned) b[3] << 24; };
+      auto u16 = [&]() { unsigned char b[2]; rd(b, 2); return (unsigned) (b[0] | b[1] << 8); };
+      char id[4]; rd(id, 4); if (memcmp(id, "RIFF", 4)) throw Error(DSR_E_IO, "Could not open file %s.", fn);
+      (void) u32(); rd(id, 4); if (memcmp(id, "WAVE", 4)) throw Error(DSR_E_IO, "Could not open file %s.", fn);
+      bool haveFmt = false, haveData = false; long dataBytes = 0;
+      while (!haveData) {
+        if (fread(id, 1, 4, fp) != 4) break;
+        const unsigned len = u32();
+        if (!memcmp(id, "fmt ", 4)) {
+          if (len < 16) throw Error(DSR_E_IO, "Could not open file %s.", fn);
+          const unsigned tag = u16(); nch = (int) u16(); rate = (int) u32(); (void) u32(); (void) u16(); bits = (int) u16();
+          if (tag != 1 && tag != 0xFFFE) throw Error(DSR_E_IO, "Could not open file %s.", fn);
+          if (len > 16) fseek(fp, (long) (len - 16 + (len & 1)), SEEK_CUR);
+          haveFmt = true;
+        } else if (!memcmp(id, "data", 4)) {
+          if (!haveFmt) throw Error(DSR_E_IO, "Could not open file %s.", fn);
+          dataBytes = (long) len; haveData = true;
+        } else fseek(fp, (long) (len + (len & 1)), SEEK_CUR);
+      }
+      if (!haveData || nch < 1) throw Error(DSR_E_IO, "Could not open file %s.", fn);
+      sw = (bits + 7) / 8;
+      if (sw < 1 || sw > 4) throw Error(DSR_E_IO, "sndfile error: unsupported sample width %d.", sw);
+      frames = dataBytes / ((long) sw * nch);
+      if (outsamplerate == -1) outsamplerate = rate;
+      if (to < 0 || to >= frames) to = (int) frames - 1;
+      if (cfrom < 0) cfrom = 0;
+      if (cfrom > to || cfrom > frames) throw Error(DSR_E_IO, "Cannot load samples from %d to %d.", cfrom, to);
+      const long n = (long) to - cfrom + 1;
+      fseek(fp, (long) cfrom * sw * nch, SEEK_CUR);
+      raw.resize((size_t) n * sw * nch);
+      const size_t got = fread(raw.data(), 1, raw.size(), fp); raw.resize(got - got % ((size_t) sw * nch));
+    } catch (...) { fclose(fp); throw; }
+    fclose(fp);
+    if (chX > nch || chX < 1) {
+      if (chX == 0) throw Error(DSR_E_CONSISTENCY, "Multi-channel read is not yet supported.");
+      throw Error(DSR_E_CONSISTENCY, "Selected channel out of range of available channels.");
+    }
+    const size_t nfr = raw.size() / ((size_t) sw * nch);
+    std::vector<float> x(nfr);
+    for (size_t i = 0; i < nfr; i++) {
+      const unsigned char* b = raw.data() + (i * nch + (size_t) (chX - 1)) * sw; long long v;
+      if (sw == 1) v = (long long) b[0] - 128;
+      else if (sw == 2) v = (short) (b[0] | b[1] << 8);
+      else if (sw == 3) { int t = b[0] | b[1] << 8 | b[2] << 16; if (t >= 1 << 23) t -= 1 << 24; v = t; }
+      else v = (int) ((unsigned) b[0] | (unsigned) b[1] << 8 | (unsigned) b[2] << 16 | (unsigned) b[3] << 24);
+      double d = (double) v;
+      if (norm != 0.0f) d = d / (double) (1LL << (8 * sw - 1));                            // libsndfile's float normalisation
+      x[i] = (float) d;
+    }
+    if (rate != outsamplerate) throw Error(DSR_E_ERROR, "sample rate conversion (%d -> %d) is not supported", rate, outsamplerate);
+    if (norm != 1.0f && norm != 0.0f) for (size_t i = 0; i < nfr; i++) x[i] *= norm;
+    q->samples.swap(x); q->sampleRate = rate; q->nChan = nch; q->reset();                  // _cur = 0; reset() (:386-388)
+    if (nread) *nread = (int) nfr;
+  });
+}
+int dsr_sample_feature_sample_rate(const dsr_stream* s) { const SampleSrc* q = dynamic_cast<const SampleSrc*>(s); return q ? q->sampleRate : 0; }
+
 dsr_status dsr_frame_source_create(int type, int size, const char* name, dsr_stream** out)
 {
   return guard([&] {

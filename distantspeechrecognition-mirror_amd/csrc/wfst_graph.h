@@ -13,6 +13,7 @@
 #include "common.h"
 #include <functional>
 #include <string>
+#include <unordered_map>
 
 namespace dsr {
 
@@ -23,18 +24,25 @@ struct WfstGraph {
   struct Node { uint32_t state; int final_; float cost; int firstArc; bool inNodes, inFinal; };
   struct Arc { int src, dst; uint32_t in, out; float cost; int next; };
   std::vector<Node> nodes; std::vector<Arc> arcs;
-  std::vector<int> nodeOf;             // state -> node id in _nodes/_final, -1 if none
+  std::unordered_map<uint32_t, int> nodeOf;   // state -> node id in _nodes / _final (the initial node is not in it: wfstFlyWeight.cc:94-118)
   int initial = -1;
   // text files may name states and symbols instead of numbering them: a field that does not start with a number is looked up in the state (0),
   // input (1) or output (2) lexicon (wfstFlyWeight.cc:311-347); unset: such a field is an error
   std::function<uint32_t(int, const char*)> symbolOf;
+  // the other direction, for write(useSymbols = true): which = 0 state, 1 input, 2 output lexicon; stateLexSize: statelex null or empty -> 0
+  std::function<std::string(int, uint32_t)> nameOf; std::function<size_t()> stateLexSize;
 
   int  findNode(uint32_t state, bool create);
   void addFinal(uint32_t state, float cost);
   void addArc(uint32_t s1, uint32_t s2, uint32_t in, uint32_t out, float cost, bool dropEpsSelf);
   void read(const char* file, bool binary);
   void readEx(const char* file, bool binary, bool noSelfLoops);
-  void write(const char* file, bool binary) const;
+  void write(const char* file, bool binary, bool useSymbols = false) const;
+  void reverse(const WfstGraph& src);                      // WFSTFlyWeight::reverse (wfstFlyWeight.cc:141-213)
+  void reverseRead(const char* file);                      // WFSTFlyWeight::reverseRead (:215-297)
+  void clear();                                            // _clear()
+  int  lookup(uint32_t state) const;                       // node id in _nodes / _final or -1 (no initial-node shortcut)
+  void addEdgeForce(int from, int to, uint32_t in, uint32_t out, float cost);   // Node::_addEdgeForce (:552-556): prepend
 
   // CSR in iteration order (node 0.. in creation order; the initial node is id `initial`)
   struct Csr { std::vector<int> off, dst; std::vector<uint32_t> in, out; std::vector<float> cost; std::vector<int> csrOf; };

@@ -16,7 +16,16 @@ class WFSTFlyWeightPtr(object):
         self._g.read(fileName, binary)
 
     def write(self, fileName, binary=True, useSymbols=False):
-        self._g.write(fileName, binary)
+        """wfstFlyWeight.cc:415-463; useSymbols: the arcs through the lexica (:499-516)"""
+        K.check(K.load().dsr_wfst_write_symbols(self._g.h, fileName.encode(), int(binary), int(useSymbols)))
+
+    def reverse(self, wfst):
+        """wfstFlyWeight.cc:141-213"""
+        K.check(K.load().dsr_wfst_reverse(self._g.h, wfst._g.h))
+
+    def reverseRead(self, fileName):
+        """wfstFlyWeight.cc:215-297"""
+        K.check(K.load().dsr_wfst_reverse_read(self._g.h, fileName.encode()))
 
     def hasFinalState(self):
         return bool(K.load().dsr_wfst_has_final_state(self._g.h))
@@ -62,6 +71,8 @@ class DecoderFlyWeightPtr(object):
         self._dec = K.Decoder(**self._cfg)
         K.check(K.load().dsr_decoder_set_symbols(self._dec.h, wfst._g.h, self._sil.encode(), self._eos.encode()))
         self._dec._g = wfst._g; self._wfst = wfst
+        if getattr(self, "_tokLimit", None) is not None:
+            K.check(K.load().dsr_decoder_set_token_memory_limit(self._dec.h, self._tokLimit))
 
     def setBeam(self, beam):
         self._cfg["beam"] = beam
@@ -117,7 +128,14 @@ class DecoderFlyWeightPtr(object):
         self._dec.writeGMM(0, conv, channel, spk, utt, cfrom, score, fileName, frameInterval)
 
     def writeCTM(self, *args, **kw):
-        raise K.DsrError(1, "'writeCTM' is not supported in _Decoder base class template.")       # decoder.h:399-401
+        """decoder.h:398-401: the base template CONSTRUCTS a j_error without throwing it -- the shipped call does nothing; so does this one."""
+        return None
+
+    def setTokenMemoryLimit(self, limit):
+        """decoder.h:396 (no token pool here: the value is kept, see dsr_decoder_set_token_memory_limit)"""
+        self._tokLimit = int(limit)
+        if self._dec:
+            K.check(K.load().dsr_decoder_set_token_memory_limit(self._dec.h, self._tokLimit))
 
     def bestArcs(self):
         return self._last["arcs"]

@@ -1,6 +1,5 @@
 """btk.feature: the MFCC operator chain with the SWIG constructor signatures of btk/feature/feature.i."""
 import ctypes as C
-import wave
 
 import numpy as np
 
@@ -23,55 +22,18 @@ class SampleFeaturePtr(FeatureStreamPtr):
 
     def read(self, fn, format=0, samplerate=16000, chX=1, chN=1, cfrom=0, to=-1, outsamplerate=-1, norm=0.0):
         """SampleFeature::read (feature.cc:243-393, feature.i:487-489).  The reference reads through libsndfile's sf_readf_float; here RIFF/WAV
-        PCM of 8, 16, 24 or 32 bits (Python's wave module).  norm == 0 keeps the file's integer scale (SFC_SET_NORM_FLOAT off), otherwise samples
+        PCM of 8, 16, 24 or 32 bits (the library's own reader, dsr_sample_feature_read: the C++ face reads the same way).  norm == 0 keeps the file's integer scale (SFC_SET_NORM_FLOAT off), otherwise samples
         are normalised to [-1, 1) and, for norm != 1, multiplied by norm.  The error branches are the reference's: chX == 0 and chX out of range
         are jconsistency errors, an empty range a jio error.  Sample-rate conversion (outsamplerate != the file's rate; SRCONV builds only) is
         refused.  Returns the number of frames read."""
-        try:
-            w = wave.open(fn, "rb")
-        except (IOError, OSError, wave.Error, EOFError) as e:
-            raise IOError("Could not open file %s." % fn)
-        try:
-            nch, sw, rate, frames = w.getnchannels(), w.getsampwidth(), w.getframerate(), w.getnframes()
-            if outsamplerate == -1:
-                outsamplerate = rate
-            if to < 0 or to >= frames:
-                to = frames - 1
-            if cfrom < 0:
-                cfrom = 0
-            if cfrom > to or cfrom > frames:
-                raise IOError("Cannot load samples from %d to %d." % (cfrom, to))
-            n = to - cfrom + 1
-            w.setpos(cfrom); raw = w.readframes(n)
-        finally:
-            w.close()
-        if sw == 1:
-            a = (np.frombuffer(raw, np.uint8).astype(np.int32) - 128)
-        elif sw == 2:
-            a = np.frombuffer(raw, "<i2").astype(np.int32)
-        elif sw == 3:
-            b = np.frombuffer(raw, np.uint8).reshape(-1, 3).astype(np.int32)
-            a = b[:, 0] | (b[:, 1] << 8) | (b[:, 2] << 16); a = np.where(a >= 1 << 23, a - (1 << 24), a)
-        elif sw == 4:
-            a = np.frombuffer(raw, "<i4").astype(np.int64)
-        else:
-            raise IOError("sndfile error: unsupported sample width %d." % sw)
-        a = a.reshape(-1, nch)
-        if chX > nch or chX < 1:
-            if chX == 0:
-                raise K.DsrError(4, "Multi-channel read is not yet supported.")
-            raise K.DsrError(4, "Selected channel out of range of available channels.")
-        x = a[:, chX - 1].astype(np.float64)
-        if norm != 0.0:
-            x = x / float(1 << (8 * sw - 1))                          # libsndfile's float normalisation
-        x = x.astype(np.float32)
-        if rate != outsamplerate:
-            raise K.DsrError(1, "sample rate conversion (%d -> %d) is not supported" % (rate, outsamplerate))
-        if norm != 1.0 and norm != 0.0:
-            x = x * np.float32(norm)
-        self._rate = rate
-        self.setSamples(x, rate)
-        return x.shape[0]
+        n = C.c_int(0)
+        st = lib().dsr_sample_feature_read(self._h, _b(fn), int(format), int(samplerate), int(chX), int(chN), int(cfrom), int(to), int(outsamplerate),
+                                           C.c_float(norm), C.byref(n))
+        if st == K.E_IO:
+            raise IOError((lib().dsr_last_error() or b"").decode(errors="replace"))
+        K.check(st)
+        self._rate = lib().dsr_sample_feature_sample_rate(self._h)
+        return n.value
 
     def setSamples(self, samples, sampleRate=16000):
         a = np.ascontiguousarray(samples, dtype=np.float32)

@@ -76,7 +76,12 @@ typedef std::shared_ptr<VectorComplexFeatureStream> VectorComplexFeatureStreamPt
 class SampleFeature : public VectorFloatFeatureStream {
  public:
   SampleFeature(const String& fn = "", unsigned blockLen = 320, unsigned shiftLen = 160, bool padZeros = false, const String& nm = "Sample")
-  { (void) fn; DSR_OP(SampleFeature, float, dsr_sample_feature_create((int) blockLen, (int) shiftLen, padZeros, nm.c_str(), &h)) }
+  { DSR_OP(SampleFeature, float, dsr_sample_feature_create((int) blockLen, (int) shiftLen, padZeros, nm.c_str(), &h)) if (fn != "") read(fn); }
+  // feature.cc:243-393 (what btk/src/superdirectiveBeamformer.cc:150-247 calls): RIFF/WAVE PCM through the library's own reader
+  unsigned read(const String& fn, int format = 0, int samplerate = 16000, int chX = 1, int chN = 1, int cfrom = 0, int to = -1, int outsamplerate = -1, float norm = 0.0) {
+    int n = 0; dsr_throw(dsr_sample_feature_read(_h, fn.c_str(), format, samplerate, chX, chN, cfrom, to, outsamplerate, norm, &n)); return (unsigned) n;
+  }
+  int getSampleRate() const { return dsr_sample_feature_sample_rate(_h); }
   void setSamples(const float* samples, size_t n, unsigned sampleRate) { dsr_throw(dsr_sample_feature_set_samples(_h, samples, n, sampleRate)); }
 };
 class PreemphasisFeature : public VectorFloatFeatureStream {
@@ -474,7 +479,9 @@ class WFSTFlyWeight {
   }
   ~WFSTFlyWeight() { dsr_wfst_destroy(_h); }
   void read(const String& fileName, bool binary = false) { dsr_throw(dsr_wfst_read(_h, fileName.c_str(), binary)); }
-  void write(const String& fileName, bool binary = true, bool useSymbols = false) { (void) useSymbols; dsr_throw(dsr_wfst_write(_h, fileName.c_str(), binary)); }
+  void write(const String& fileName, bool binary = true, bool useSymbols = false) { dsr_throw(dsr_wfst_write_symbols(_h, fileName.c_str(), binary, useSymbols)); }
+  void reverse(const std::shared_ptr<WFSTFlyWeight>& wfst) { dsr_throw(dsr_wfst_reverse(_h, wfst->handle())); }      // wfstFlyWeight.cc:141-213
+  void reverseRead(const String& fileName) { dsr_throw(dsr_wfst_reverse_read(_h, fileName.c_str())); }                // :215-297
   bool hasFinalState() const { return dsr_wfst_has_final_state(_h) != 0; }
   LexiconPtr& stateLexicon() { return _stateLexicon; }
   LexiconPtr& inputLexicon() { return _inputLexicon; }
@@ -593,9 +600,9 @@ class DecoderFlyWeight {
   void writeGMM(const String& conv, const String& channel, const String& spk, const String& utt, double cfrom, double score, const String& fileName = "", double frameInterval = 0.01) {
     dsr_throw(dsr_decoder_write_gmm(_h, 0, conv.c_str(), channel.c_str(), spk.c_str(), utt.c_str(), cfrom, score, fileName.c_str(), frameInterval));
   }
-  void writeCTM(const String&, const String&, const String&, const String&, double, double, const String& = "", double = 0.01) {
-    throw j_error(JERROR, "'writeCTM' is not supported in _Decoder base class template.");      // decoder.h:399-401
-  }
+  // decoder.h:398-401: the base template constructs a j_error and does not throw it -- a silent no-op in the shipped code, and here
+  void writeCTM(const String&, const String&, const String&, const String&, double, double, const String& = "", double = 0.01) {}
+  void setTokenMemoryLimit(unsigned limit) { dsr_throw(dsr_decoder_set_token_memory_limit(_h, limit)); }           // decoder.h:396
   void setBeam(double beam) { dsr_throw(dsr_decoder_set_beam(_h, beam)); }
   dsr_decoder* handle() const { return _h; }
  private:

@@ -251,6 +251,9 @@ dsr_status dsr_gmm_find_dist(const dsr_gmm*, const char* name, int* distX);
    (re-scored entries: mode 0's bits), never worse than 1e-3 */
 dsr_status dsr_gmm_score(dsr_gmm*, const float* x_dev, int64_t N, int mode, float* score_dev,
                          uint8_t* argmin_dev, void* stream);
+/* CodebookBasic::logLhood(frame, val) (asr/gaussian/codebookBasic.cc:557-609) for every (frame, codebook): the nearest Gaussian as _scoreOpt finds it,
+ * finished as that method does -- 0.5 * min, + val[argmin] when useVal (the reference's val != NULL), no codebook scale.  Bit exact (reference order). */
+dsr_status dsr_gmm_log_lhood(dsr_gmm*, const float* x_dev, int64_t N, int useVal, float* score_dev, uint8_t* argmin_dev, void* stream);
 
 /* =====================================================================================
  * 5. Static decoding graph + Viterbi token passing
@@ -287,6 +290,16 @@ dsr_status dsr_wfst_read(dsr_wfst*, const char* fileName, int binary);    /* WFS
    order as the fly-weight reader; noSelfLoops != 0 skips every self loop (:945).  Graph for Decoder (decoder.h:1107-1125). */
 dsr_status dsr_wfst_read_dynamic(dsr_wfst*, const char* fileName, int noSelfLoops);
 dsr_status dsr_wfst_write(const dsr_wfst*, const char* fileName, int binary);
+/* WFSTFlyWeight::write(fileName, binary, useSymbols) (asr/decoder/wfstFlyWeight.cc:415-463): useSymbols != 0 writes every arc through the lexica set with
+ * dsr_wfst_set_lexicons (Edge::write :499-516: "%25s  %25s  %10s  %20s" with a non-empty state lexicon, "%10d  %10d  %10s  %20s" without; a cost below
+ * 1e-4 in magnitude is left out); final-state lines -- and, with binary, the end marker -- stay numeric, as the reference writes them.  DSR_E_KEY without lexica. */
+dsr_status dsr_wfst_write_symbols(const dsr_wfst*, const char* fileName, int binary, int useSymbols);
+/* WFSTFlyWeight::reverse(wfst) (asr/decoder/wfstFlyWeight.cc:141-213): dst becomes src with every arc turned round -- a super-initial node (index
+ * _MaximumIndex - 3 = 536870908) with an epsilon arc to each of src's final nodes carrying that node's cost, src's initial state as the only final node.
+ * WFSTFlyWeight::reverseRead(fileName) (:215-297): the same from a text file (its first arc's source becomes the final node; a final-state line must come
+ * after the arcs that mention the state: DSR_E_KEY "No state %u exists." otherwise, as the reference's find() without create). */
+dsr_status dsr_wfst_reverse(dsr_wfst* dst, const dsr_wfst* src);
+dsr_status dsr_wfst_reverse_read(dsr_wfst*, const char* fileName);
 dsr_status dsr_wfst_add_arc(dsr_wfst*, unsigned s1, unsigned s2, unsigned input, unsigned output, float cost);
 dsr_status dsr_wfst_add_final(dsr_wfst*, unsigned state, float cost);
 int dsr_wfst_num_nodes(const dsr_wfst*);
@@ -313,6 +326,11 @@ dsr_status dsr_decoder_create(const dsr_decoder_cfg*, dsr_decoder** out);
 void       dsr_decoder_destroy(dsr_decoder*);
 dsr_status dsr_decoder_set(dsr_decoder*, const dsr_wfst*);               /* DecoderFlyWeight::set */
 dsr_status dsr_decoder_set_beam(dsr_decoder*, double beam);
+/* _Decoder::setTokenMemoryLimit(limit) (asr/decoder/decoder.h:396) caps the reference's Token memory pool.  Tokens here live in per-slot arrays sized by
+ * dsr_decoder_cfg (maxActive, maxCandidates, arenaTokens); an utterance that outgrows them gets DSR_E_ALLOCATION in its result.  There is no pool to
+ * limit: the value is accepted and kept (dsr_decoder_token_memory_limit) so that drivers that set it run unchanged. */
+dsr_status dsr_decoder_set_token_memory_limit(dsr_decoder*, unsigned limit);
+unsigned   dsr_decoder_token_memory_limit(const dsr_decoder*);
 /* DecoderFlyWeight::set(wfst) with the symbol look-ups of _Decoder::_set (decoder.h:740-745): silSymbol in the input lexicon (-> cfg.silenceX),
    eosSymbol in the output lexicon; a missing symbol is DSR_E_KEY as in the reference.  NULL symbols are not looked up. */
 dsr_status dsr_decoder_set_symbols(dsr_decoder*, const dsr_wfst*, const char* silSymbol, const char* eosSymbol);
@@ -600,6 +618,13 @@ void         dsr_stream_release(dsr_stream*);
 /* sources */
 dsr_status dsr_sample_feature_create(int blockLen, int shiftLen, int padZeros, const char* name, dsr_stream** out);
 dsr_status dsr_sample_feature_set_samples(dsr_stream*, const float* samples, size_t n, unsigned sampleRate);
+/* SampleFeature::read(fn, format, samplerate, chX, chN, cfrom, to, outsamplerate, norm) (btk/feature/feature.cc:243-393; feature.i:487-489;
+ * btk/src/superdirectiveBeamformer.cc:150-247 calls it from C++): RIFF/WAVE PCM of 8/16/24/32 bits; norm == 0 keeps the integer scale, otherwise
+ * [-1, 1) x norm; chX is 1-based (0: DSR_E_CONSISTENCY "Multi-channel read is not yet supported."); an empty range or an unreadable file is DSR_E_IO;
+ * sample-rate conversion is refused.  *nread = frames read; the stream is reset. */
+dsr_status dsr_sample_feature_read(dsr_stream*, const char* fileName, int format, int samplerate, int chX, int chN, int cfrom, int to, int outsamplerate,
+                                   float norm, int* nread);
+int        dsr_sample_feature_sample_rate(const dsr_stream*);
 /* PyFeatureStream equivalent (btk/stream/pyStream.h:44-130): a source whose frames the caller supplies;
    type is DSR_T_SHORT / DSR_T_FLOAT / DSR_T_DOUBLE / DSR_T_COMPLEX, data = nframes rows of `size` items */
 dsr_status dsr_frame_source_create(int type, int size, const char* name, dsr_stream** out);

@@ -608,6 +608,16 @@ def gmm_score_opt(cb, val, x, native=False):
     return score, arg
 
 
+def gmm_log_lhood(cb, val, x):
+    """CodebookBasic::logLhood (codebookBasic.cc:557-609); val None: the reference's val == NULL"""
+    x = _f32(x); T = x.shape[0]
+    score = np.zeros((T, cb.K), np.float32); arg = np.zeros((T, cb.K), np.int32)
+    s = cb.cstruct(); v = _f32(val) if val is not None else None
+    L = lib(); L.orc_gmm_log_lhood.argtypes = [c_vp, c_vp, c_vp, c_int, c_vp, c_vp]
+    L.orc_gmm_log_lhood(C.byref(s), _p(v) if v is not None else None, _p(x), T, _p(score), _p(arg))
+    return score, arg
+
+
 def gmm_score_all(cb, val, x):
     x = _f32(x); val = _f32(val); T = x.shape[0]
     score = np.zeros((T, cb.K), np.float32)

@@ -168,6 +168,7 @@ typedef struct {
 void orc_gmm_score_opt(const orc_cbset* cb, const float* val, const float* x, int T,
                        float* score, int32_t* argmin);
 void orc_gmm_score_all(const orc_cbset* cb, const float* val, const float* x, int T, float* score);
+void orc_gmm_log_lhood(const orc_cbset* cb, const float* val, const float* x, int T, float* score, int32_t* argmin);
 
 /* ---------------- WFST + decoder (asr/decoder) ---------------- */
 typedef struct orc_wfst orc_wfst;

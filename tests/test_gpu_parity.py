@@ -1408,3 +1408,49 @@ def test_wpe_multi_at_benchmark_size(dsr, oracle, cuda, monkeypatch, series_in_m
     def late(a):
         return np.mean([np.abs(np.vdot(a[0, :-k, 1], a[0, k:, 1])) for k in range(3, 10)]) / np.real(np.vdot(a[0, :, 1], a[0, :, 1]))
     assert late(out[0]) < 0.9 * late(Y[0].astype(np.complex128))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("K,R,D", [(64, 4, 39), (7, 5, 13), (3, 32, 40)])
+def test_gmm_log_lhood(dsr, oracle, cuda, K, R, D):
+    """CodebookBasic::logLhood (codebookBasic.cc:557-609) through dsr_gmm_log_lhood: the nearest Gaussian of _scoreOpt, finished as that method does
+    (0.5 * min + val[argmin], or 0.5 * min with val == NULL; no codebook scale) -- bit exact."""
+    import ctypes as C
+    import torch
+    m = synth.gmm_model(K, R, D, seed=21)
+    rng = np.random.default_rng(4)
+    x = (rng.standard_normal((1500, D)) * 1.3).astype(np.float32)
+    gm = dsr.Gmm(**m); xd = torch.from_numpy(x).to(cuda)
+    cb = oracle.Codebooks(m["refN"], m["mean"], m["ivar"], m["det"])
+    L = dsr.load()
+    for useVal in (1, 0):
+        sc = torch.empty((x.shape[0], K), dtype=torch.float32, device=cuda); am = torch.zeros((x.shape[0], K), dtype=torch.uint8, device=cuda)
+        dsr.check(L.dsr_gmm_log_lhood(gm.h, C.c_void_p(xd.data_ptr()), x.shape[0], useVal, C.c_void_p(sc.data_ptr()), C.c_void_p(am.data_ptr()), dsr.cur_stream()))
+        ref, arg = oracle.gmm_log_lhood(cb, m["val"] if useVal else None, x)
+        assert np.array_equal(sc.cpu().numpy().view(np.uint32), ref.view(np.uint32))
+        assert np.array_equal(am.cpu().numpy().astype(np.int32), arg)
+    s0, a0 = gm.score(xd, mode=0)
+    assert torch.equal(a0, am)                                             # the same Gaussian as _scoreOpt
+    # (with unit codebook scale the two finishes are the same number: halving commutes with the rounding of the sum, 0.5 (min + 2 val) == 0.5 min + val)
+    ref1, _ = oracle.gmm_log_lhood(cb, m["val"], x)
+    assert np.array_equal(s0.cpu().numpy().view(np.uint32), ref1.view(np.uint32))
+    # a codebook scale enters _scoreOpt only
+    scale = np.full(K, 1.5, np.float32)
+    gs = dsr.Gmm(scale=scale, **m)
+    s1, _ = gs.score(xd, mode=0)
+    sc2 = torch.empty((x.shape[0], K), dtype=torch.float32, device=cuda)
+    dsr.check(L.dsr_gmm_log_lhood(gs.h, C.c_void_p(xd.data_ptr()), x.shape[0], 1, C.c_void_p(sc2.data_ptr()), None, dsr.cur_stream()))
+    assert np.array_equal(sc2.cpu().numpy().view(np.uint32), ref1.view(np.uint32)) and not torch.equal(s1, sc2)
+
+
+@pytest.mark.gpu
+def test_decoder_small_boundary_methods(dsr, cuda):
+    """_Decoder::setTokenMemoryLimit (decoder.h:396: accepted and kept, there is no token pool here) and writeCTM (decoder.h:398-401: the shipped
+    base-template body constructs a j_error without throwing it -- a no-op)."""
+    from dsr.asr import decoder as D
+    L = dsr.load()
+    dec = dsr.Decoder(beam=50.0, lmScale=12.0, maxActive=1024, streams=1)
+    dsr.check(L.dsr_decoder_set_token_memory_limit(dec.h, 123456))
+    assert L.dsr_decoder_token_memory_limit(dec.h) == 123456
+    d = D.DecoderFlyWeightPtr.__new__(D.DecoderFlyWeightPtr)
+    assert D.DecoderFlyWeightPtr.writeCTM(d, "conv", "A", "spk", "utt", 0.0, 1.0, "/nonexistent/dir/file.ctm") is None
