@@ -67,7 +67,7 @@ struct GraphDev {
 };
 
 struct DecDev {
-  double beam, lmScale, lmPenalty, silPenalty; uint32_t silenceX;
+  double beam, lmScale, lmPenalty, silPenalty; uint32_t silenceX; int noPen;
   int maxTok, maxCand; long arenaCap;
   // per-slot scratch (slot s at base + s*stride)
   TokA* tokA; TokB* tokB; TokA* ctok; Side* side; int fastOK; int* tokOff; int* tokCnt; int* owner; int* rank; int* chead; CandA* cA; CandB* cB; unsigned* first; unsigned* tags; Bp* arena;
@@ -482,7 +482,10 @@ __global__ __launch_bounds__(kThreads) void k_viterbi(const VitArgs argsInKernar
             const TokA t = *at32<TokA>(ctk, ekk * 16u);
             ac = t.ac; lm = t.lm; rec += (int) (t.xs & 0x7FFFFFFFu); ekk |= (t.xs >> 31) << 29;
           };
-          auto expandR = [&](const int g8, float* ac8, float* lm8, int* rec8, unsigned* ek8) __attribute__((always_inline)) {
+          auto expandR = [&](auto NOPEN, const int g8, float* ac8, float* lm8, int* rec8, unsigned* ek8) __attribute__((always_inline)) {
+            // NP: both penalty products are zero and no placement's lm can be -0.0 (checked on the host, DecoderState::noPen): "l + 0.0" is then
+            // the identity and the four conditional additions of a placement -- an add and two selects each -- are left out
+            constexpr bool NP = decltype(NOPEN)::value;
             int4 xr[kB]; int2 xd[kB]; bool tsil[kB];
 #pragma unroll
             for (int i = 0; i < kB; i++) { tsil[i] = (ek8[i] >> 29) & 1u; ek8[i] &= 0x1FFFu; }
@@ -505,8 +508,10 @@ __global__ __launch_bounds__(kThreads) void k_viterbi(const VitArgs argsInKernar
                 double lmNode;
                 {                                                              // first epsilon hop (decoder.h:979-983): its cost travels with the record
                   double l = __dadd_rn(lm0, __dmul_rn(lmS, (double) e1));
-                  const double l1 = __dadd_rn(l, lsPen); l = (xmeta & 0x20000u) ? l1 : l;
-                  const double l2 = __dadd_rn(l, lsSil); l = (sil0 && (prevNull0 || !tsil[i])) ? l2 : l;     // prevIn != silenceX <=> the token's edge was no silence edge
+                  if (!NP) {
+                    const double l1 = __dadd_rn(l, lsPen); l = (xmeta & 0x20000u) ? l1 : l;
+                    const double l2 = __dadd_rn(l, lsSil); l = (sil0 && (prevNull0 || !tsil[i])) ? l2 : l;   // prevIn != silenceX <=> the token's edge was no silence edge
+                  }
                   lmNode = has ? (double) (float) l : lm0;
                 }
                 const bool pnull = has ? false : prevNull0;
@@ -518,7 +523,7 @@ __global__ __launch_bounds__(kThreads) void k_viterbi(const VitArgs argsInKernar
                     for (int h = 1; h < plen; h++) {                           // hop costs: inline (two hops) or one independent load per hop
                       const float ch = (plen == 2) ? __int_as_float(xd[i].y) : (h == 1 ? hc0 : h == 2 ? hc1 : h == 3 ? hc2 : pathCost[xd[i].y + h - 1]);
                       double l = __dadd_rn(lmNode, __dmul_rn(lmS, (double) ch));
-                      if ((xmeta >> (17 + h)) & 1u) l = __dadd_rn(l, lsPen);
+                      if (!NP && ((xmeta >> (17 + h)) & 1u)) l = __dadd_rn(l, lsPen);
                       lmNode = (double) (float) l;                              // (the edge before is an epsilon edge: no silence penalty possible here)
                     }
                   } else {
@@ -526,15 +531,15 @@ __global__ __launch_bounds__(kThreads) void k_viterbi(const VitArgs argsInKernar
                     for (int h = 1; h < plen; h++) {
                       const int a = pp[h];
                       double l = __dadd_rn(lmNode, __dmul_rn(lmS, (double) ka->G.arcCost[a]));
-                      if (ka->G.arcOut[a] != 0) l = __dadd_rn(l, lsPen);
+                      if (!NP && ka->G.arcOut[a] != 0) l = __dadd_rn(l, lsPen);
                       lmNode = (double) (float) l;
                     }
                   }
                 }
                 double lm = __dadd_rn(lmNode, __dmul_rn(lmS, (double) xcost));
-                { const double lm1 = __dadd_rn(lm, lsPen); lm = (xmeta & 0x10000u) ? lm1 : lm; }
+                if (!NP) { const double lm1 = __dadd_rn(lm, lsPen); lm = (xmeta & 0x10000u) ? lm1 : lm; }
                 const bool silArc = ((uint32_t) (xdist + 1) == silenceX);
-                { const double lm2 = __dadd_rn(lm, lsSil); lm = (silArc && (pnull || !pinSil)) ? lm2 : lm; }
+                if (!NP) { const double lm2 = __dadd_rn(lm, lsSil); lm = (silArc && (pnull || !pinSil)) ? lm2 : lm; }
                 float rowv;                                                    // (two branches, not "useLdsRow ? srow[..] : rowG[..]": that is one FLAT load)
                 if (useLdsRow) { rowv = ((const lds_float_t*) srow)[xdist]; DSR_NO_MERGE(); } else rowv = rowG[xdist];
                 const double ac = __dadd_rn((double) ac8[i], (double) rowv);
@@ -551,17 +556,15 @@ __global__ __launch_bounds__(kThreads) void k_viterbi(const VitArgs argsInKernar
               }
             }
           };
-          auto expand8 = [&](const int g8, float* ac8, float* lm8, int* rec8, unsigned* ek8) __attribute__((always_inline)) {
+          auto expand8 = [&](auto NOPEN, const int g8, float* ac8, float* lm8, int* rec8, unsigned* ek8) __attribute__((always_inline)) {
 #pragma unroll
             for (int i = 0; i < kB; i++) locate(g8 + i, rec8[i], ek8[i]);
             if (PROF) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); TICK(26); }
 #pragma unroll
             for (int i = 0; i < kB; i++) tokload(ac8[i], lm8[i], rec8[i], ek8[i]);
             if (PROF) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); TICK(27); }
-            expandR(g8, ac8, lm8, rec8, ek8);
+            expandR(NOPEN, g8, ac8, lm8, rec8, ek8);
           };
-#pragma unroll
-          for (int g8 = 0; g8 < kFastK; g8 += kB) if (g8 < K) expand8(g8, &qac[g8], &qlm[g8], &qrec[g8], &ek[g8]);
           auto park_store = [&](const int kb, const float* oac, const float* olm, const int* orec, const unsigned* oek) __attribute__((always_inline)) {
 #pragma unroll
             for (int i = 0; i < kB; i++) { const int c = (kb + i) * nthr + tq; if (c < C) ovf[c - kFastK * nthr] = make_uint4(__float_as_uint(oac[i]), __float_as_uint(olm[i]), (unsigned) orec[i], oek[i]); }
@@ -574,10 +577,15 @@ __global__ __launch_bounds__(kThreads) void k_viterbi(const VitArgs argsInKernar
               oac[i] = __uint_as_float(v.x); olm[i] = __uint_as_float(v.y); orec[i] = (int) v.z; oek[i] = v.w;
             }
           };
-          for (int kb = kFastK; kb < K; kb += kB) {
-            float oac[kB], olm[kB]; int orec[kB]; unsigned oek[kB];
-            expand8(kb, oac, olm, orec, oek); park_store(kb, oac, olm, orec, oek);
-          }
+          auto runP3 = [&](auto NOPEN) __attribute__((always_inline)) {
+#pragma unroll
+            for (int g8 = 0; g8 < kFastK; g8 += kB) if (g8 < K) expand8(NOPEN, g8, &qac[g8], &qlm[g8], &qrec[g8], &ek[g8]);
+            for (int kb = kFastK; kb < K; kb += kB) {
+              float oac[kB], olm[kB]; int orec[kB]; unsigned oek[kB];
+              expand8(NOPEN, kb, oac, olm, orec, oek); park_store(kb, oac, olm, orec, oek);
+            }
+          };
+          if (ka->D.noPen) runP3(std::true_type{}); else runP3(std::false_type{});
           TICK(2);
           locMin = wave_min_d_uni(locMin); locMag = wave_max_f_uni(locMag);
           if (lq == 0) { s_waveMin[wq] = locMin; s_waveMag[wq] = locMag; }
@@ -1317,6 +1325,7 @@ struct DecoderState {
   DevBuf<TokA> d_tokA, d_ctok; DevBuf<TokB> d_tokB; DevBuf<Side> d_side; DevBuf<XRecD> d_xrecD; int fastOK = 0; int maxCnt = 0; DevBuf<int> d_tokOff, d_tokCnt, d_owner, d_rank, d_chead; DevBuf<unsigned> d_tags; DevBuf<CandA> d_cA; DevBuf<CandB> d_cB; DevBuf<unsigned> d_first; DevBuf<Bp> d_arena;
   DevBuf<long long> d_prof; DevBuf<dsr_decode_result> d_res; DevBuf<int> d_arcs; DevBuf<unsigned> d_words;
   long arenaCap = 0; int initial = 0; unsigned tokenMemoryLimit = 0;
+  bool costNegZero = false; double costMinAbs = HUGE_VAL;      // over the arcs of the transducer set last: a cost of -0.0; the smallest non-zero |cost|
   // lattice bookkeeping of the last decode (cfg.latticeTokens > 0), per utterance
   DevBuf<uint4> d_lat; DevBuf<double> d_latTtl; DevBuf<long> d_latFrameOff; DevBuf<int> d_arenaLat; DevBuf<int4> d_latFinal; DevBuf<int> d_latInfo;
   int latU = 0, latTmax = 0; long latArenaCap = 0; WfstGraph graphCopy; DevBuf<TokA> d_tokA3; DevBuf<TokB> d_tokB3;
@@ -1452,6 +1461,12 @@ dsr_status dsr_decoder_set(dsr_decoder* d, const dsr_wfst* g)
     }
     { std::vector<ERec> e = d->tab.erec; if (e.empty()) e.push_back(ERec{0, 0, 0, 0}); d->d_erec.upload(e); }
     d->d_arcCost.upload(d->csr.cost); d->d_arcOut.upload(d->csr.out); d->d_arcIn.upload(d->csr.in);
+    d->costNegZero = false; d->costMinAbs = HUGE_VAL;
+    for (size_t a = 0; a < d->csr.cost.size(); a++) {
+      const float c = d->csr.cost[a]; uint32_t bits; memcpy(&bits, &c, 4);
+      if (bits == 0x80000000u) d->costNegZero = true;
+      if (c != 0.0f && std::fabs((double) c) < d->costMinAbs) d->costMinAbs = std::fabs((double) c);
+    }
     d->d_nodeFinal.upload(nf); d->d_nodeCost.upload(nc);
     d->haveGraph = true; d->nSlots = 0;    // scratch is (re)allocated by the first decode
   });
@@ -1603,6 +1618,10 @@ dsr_status dsr_decoder_decode_launch(dsr_decoder* d, const float* score, const i
     G.xpathOff = d->d_xpathOff.p; G.eoff = d->d_eoff.p; G.erec = d->d_erec.p; G.path = d->d_path.p; G.pathCost = d->d_pathCost.p; G.arcCost = d->d_arcCost.p;
     G.arcOut = d->d_arcOut.p; G.arcIn = d->d_arcIn.p; G.nodeFinal = d->d_nodeFinal.p; G.nodeCost = d->d_nodeCost.p;
     DecDev D; D.beam = d->cfg.beam; D.lmScale = d->cfg.lmScale; D.lmPenalty = d->cfg.lmPenalty; D.silPenalty = d->cfg.silPenalty;
+    // penalty-free expansion (k_viterbi, expandR): both penalty products zero, and no placement's lm can be -0.0 -- lmScale > 0, no arc cost of -0.0, and every
+    // non-zero lmScale x cost at least 2^-60 in magnitude (a sum float + double of that size is 0 or at least 2^-112: it cannot round to -0.0f)
+    D.noPen = (d->cfg.lmScale > 0.0 && std::isfinite(d->cfg.lmScale) && d->cfg.lmScale * d->cfg.lmPenalty == 0.0 && d->cfg.lmScale * d->cfg.silPenalty == 0.0 &&
+               !d->costNegZero && (d->costMinAbs == HUGE_VAL || d->cfg.lmScale * d->costMinAbs >= 0x1p-60) && !getenv("DSR_VITERBI_PEN")) ? 1 : 0;
     D.silenceX = d->cfg.silenceX; D.maxTok = d->cfg.maxActive; D.maxCand = d->cfg.maxCandidates; D.arenaCap = d->arenaCap;
     D.tokA = d->d_tokA.p; D.tokB = d->d_tokB.p; D.ctok = d->d_ctok.p; D.side = d->d_side.p; D.fastOK = d->fastOK; D.tokOff = d->d_tokOff.p; D.owner = d->d_owner.p; D.rank = d->d_rank.p; D.cA = d->d_cA.p; D.cB = d->d_cB.p;
     D.first = d->d_first.p; D.tags = d->d_tags.p; D.tokCnt = d->d_tokCnt.p; D.chead = d->d_chead.p; D.arena = d->d_arena.p; D.queue = d->d_queue.p;
