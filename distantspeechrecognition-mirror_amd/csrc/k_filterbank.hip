@@ -559,6 +559,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
       // ---- even/odd split, one frame at a time: bins lane, lane + 64 (+ bin N by lane 0).
       // X[f] = (E + w O) g  with  E = (Z[f] + conj Z[N-f]) / 2,  O = -j (Z[f] - conj Z[N-f]) / 2  -- the halves and the gain are
       // one exact scale factor, zero for the rows past the end of the utterance.
+      // (Measured and dropped, round 3: the quad's four rows packed in the strip and stored as ONE 16-byte-aligned run of 4128 bytes instead of four
+      // 8-byte-aligned rows + four single-lane stores of bin N -- exact, 4.30 against 4.06 ms: the extra LDS traffic costs more than the aligned stores
+      // save.  The kernel is LDS-bound: SQ_LDS_IDX_ACTIVE = 72 % of the CU-busy cycles, SQ_WAIT_INST_LDS = 18 % of the wave cycles (profiles/r03_fb_pmc.txt).)
 #pragma unroll
       for (int fq = 0; fq < 4 * NQ; fq++) {
         const int t = t0 + tl + fq;
