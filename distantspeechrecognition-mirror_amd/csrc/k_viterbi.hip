@@ -26,6 +26,7 @@
 #include "wfst_graph.h"
 #include "lattice.h"
 #include "lexicon.h"
+#include "wordtrace.h"
 #include <algorithm>
 #include <cmath>
 #include <type_traits>
@@ -1325,6 +1326,8 @@ struct DecoderState {
   DevBuf<TokA> d_tokA, d_ctok; DevBuf<TokB> d_tokB; DevBuf<Side> d_side; DevBuf<XRecD> d_xrecD; int fastOK = 0; int maxCnt = 0; DevBuf<int> d_tokOff, d_tokCnt, d_owner, d_rank, d_chead; DevBuf<unsigned> d_tags; DevBuf<CandA> d_cA; DevBuf<CandB> d_cB; DevBuf<unsigned> d_first; DevBuf<Bp> d_arena;
   DevBuf<long long> d_prof; DevBuf<dsr_decode_result> d_res; DevBuf<int> d_arcs; DevBuf<unsigned> d_words;
   long arenaCap = 0; int initial = 0; unsigned tokenMemoryLimit = 0;
+  // DecoderWordTrace mode (cfg.wordTrace): scratch of k_wordtrace.hip
+  DevBuf<WTok> w_tok; DevBuf<WCand> w_cand; DevBuf<int> w_tokOff, w_rank; DevBuf<unsigned long long> w_best; DevBuf<unsigned> w_first; DevBuf<int4> w_traces; size_t w_tablesFor = 0;
   bool costNegZero = false; double costMinAbs = HUGE_VAL;      // over the arcs of the transducer set last: a cost of -0.0; the smallest non-zero |cost|
   // lattice bookkeeping of the last decode (cfg.latticeTokens > 0), per utterance
   DevBuf<uint4> d_lat; DevBuf<double> d_latTtl; DevBuf<long> d_latFrameOff; DevBuf<int> d_arenaLat; DevBuf<int4> d_latFinal; DevBuf<int> d_latInfo;
@@ -1349,6 +1352,10 @@ struct dsr_decoder : DecoderState {};
 extern "C" {
 
 dsr_status dsr_wfst_create(dsr_wfst** out) { return guard([&] { if (!out) throw Error(DSR_E_PARAMETER, "null argument"); *out = new dsr_wfst(); }); }
+// WFSTFlyWeightSortedOutput(statelex, inlex, outlex) (decoder.i; wfstFlyWeight.h:403-424): the same container with every node's arcs kept ordered by
+// (output, input); call on an empty transducer
+dsr_status dsr_wfst_set_sorted_output(dsr_wfst* g, int on)
+{ return guard([&] { if (!g) throw Error(DSR_E_PARAMETER, "null argument"); if (!g->arcs.empty()) throw Error(DSR_E_CONSISTENCY, "the transducer already has arcs"); g->sortedOutput = on != 0; }); }
 void dsr_wfst_destroy(dsr_wfst* g) { delete g; }
 dsr_status dsr_wfst_read(dsr_wfst* g, const char* f, int binary) { return guard([&] { if (!g) throw Error(DSR_E_PARAMETER, "null argument"); g->read(f, binary != 0); }); }
 dsr_status dsr_wfst_read_dynamic(dsr_wfst* g, const char* f, int noSelfLoops) { return guard([&] { if (!g) throw Error(DSR_E_PARAMETER, "null argument"); g->readEx(f, false, noSelfLoops != 0); }); }
@@ -1405,7 +1412,8 @@ dsr_lexicon* dsr_wfst_output_lexicon(const dsr_wfst* g) { return g ? g->lexOut :
 int dsr_wfst_has_final_state(const dsr_wfst* g) { if (!g) return 0; for (size_t i = 0; i < g->nodes.size(); i++) if (g->nodes[i].final_) return 1; return 0; }
 
 void dsr_decoder_default_cfg(dsr_decoder_cfg* c)
-{ memset(c, 0, sizeof(*c)); c->beam = 100.0; c->lmScale = 12.0; c->lmPenalty = 0.0; c->silPenalty = 0.0; c->silenceX = 0xFFFFFFFFu; }
+{ memset(c, 0, sizeof(*c)); c->beam = 100.0; c->lmScale = 12.0; c->lmPenalty = 0.0; c->silPenalty = 0.0; c->silenceX = 0xFFFFFFFFu;
+  c->propagateN = 5; c->wordTraceLattice = 1; }                            // DecoderWordTrace's defaults (decoder.i:201-260; only read when wordTrace != 0)
 
 dsr_status dsr_decoder_create(const dsr_decoder_cfg* cfg, dsr_decoder** out)
 {
@@ -1597,6 +1605,43 @@ dsr_status dsr_decoder_decode_launch(dsr_decoder* d, const float* score, const i
     if (d->pendingU > 0) throw Error(DSR_E_CONSISTENCY, "a decode is already in flight on this decoder: collect it first");
     if (U <= 0) return;
     hipStream_t st = (hipStream_t) stream;
+    if (d->cfg.wordTrace) {
+      // DecoderWordTrace (decoder.h:1146-1304).  With generateLattice -- the reference's default -- _placeOnList merges the worse chains of two tokens and reads
+      // wordTrace()->wordSequenceX() of each (decoder.cc:239); a token that has not crossed a word boundary has a null word trace: undefined behaviour in the
+      // reference on any transducer whose first arcs carry no output symbol.  That search is not built; the 1-best search (generateLattice = false) is.
+      if (d->cfg.wordTraceLattice) throw Error(DSR_E_CONSISTENCY, "DecoderWordTrace with generateLattice: not built (the shipped _placeOnList dereferences the null word trace of "
+                                               "every token that has not crossed a word boundary, decoder.cc:239); construct it with generateLattice = false");
+      if (d->cfg.topN > 0 || d->cfg.latticeTokens > 0 || d->dumpOn) throw Error(DSR_E_PARAMETER, "DecoderWordTrace: no topN (its frame loop has no such branch, decoder.cc:147-183), lattice bookkeeping or dump");
+      for (size_t a = 0; a < d->csr.in.size(); a++) if (d->csr.in[a] > (uint32_t) nDist) throw Error(DSR_E_INDEX, "arc input %u has no distribution (nDist=%d)", d->csr.in[a], nDist);
+      int slots = d->cfg.streams; if (slots > U) slots = U;
+      const dsr_decoder_cfg& c = d->cfg; const size_t S = (size_t) slots;
+      const long maxTraces = c.wordTraces > 0 ? (long) c.wordTraces : (long) 1 << 20;
+      d->w_tok.reserve(S * 2 * c.maxActive); d->w_cand.reserve(S * c.maxCandidates); d->w_tokOff.reserve(S * (c.maxActive + 1)); d->w_rank.reserve(S * c.maxCandidates);
+      d->w_traces.reserve((size_t) U * maxTraces); d->d_queue.reserve(1); d->d_res.reserve(U);
+      if (d->w_tablesFor != S * d->nNodes) {                               // the per-state tables are all ones between frames: set once, the kernel restores them
+        d->w_best.reserve(S * d->nNodes); d->w_first.reserve(S * d->nNodes); d->w_tablesFor = S * d->nNodes;
+        DSR_HIP(hipMemsetAsync(d->w_best.p, 0xFF, sizeof(unsigned long long) * S * d->nNodes, st)); DSR_HIP(hipMemsetAsync(d->w_first.p, 0xFF, sizeof(unsigned) * S * d->nNodes, st));
+      }
+      if (maxPath < 1) maxPath = 1;
+      d->d_arcs.reserve((size_t) U * maxPath); d->d_words.reserve((size_t) U * maxPath);
+      DSR_HIP(hipMemsetAsync(d->d_queue.p, 0, sizeof(int), st));
+      WtArgs A; A.nNodes = d->nNodes; A.initial = d->initial; A.xoff = d->d_xoff.p; A.xrec = d->d_xrec.p; A.xarc = d->d_xarc.p; A.xpathOff = d->d_xpathOff.p; A.eoff = d->d_eoff.p;
+      A.erec = d->d_erec.p; A.path = d->d_path.p; A.arcCost = d->d_arcCost.p; A.arcOut = d->d_arcOut.p; A.arcIn = d->d_arcIn.p; A.nodeFinal = d->d_nodeFinal.p; A.nodeCost = d->d_nodeCost.p;
+      A.beam = c.beam; A.lmScale = c.lmScale; A.lmPenalty = c.lmPenalty; A.silPenalty = c.silPenalty; A.silenceX = c.silenceX; A.insertSilence = c.insertSilence;
+      A.maxTok = c.maxActive; A.maxCand = c.maxCandidates; A.maxTraces = maxTraces;
+      A.tok = d->w_tok.p; A.cand = d->w_cand.p; A.tokOff = d->w_tokOff.p; A.rank = d->w_rank.p; A.bestKey = d->w_best.p; A.firstSlot = d->w_first.p; A.traces = d->w_traces.p; A.queue = d->d_queue.p;
+      A.scores = score; A.nframes = nframes; A.U = U; A.Tmax = Tmax; A.nDist = nDist; A.res = d->d_res.p; A.arcsOut = d->d_arcs.p; A.wordsOut = d->d_words.p; A.maxPath = maxPath;
+      wordtrace_launch(A, slots, st);
+      const size_t nPath = want_paths ? (size_t) U * maxPath : 0;
+      d->h_res.reserve(U); d->h_arcs.reserve(nPath ? nPath : 1); d->h_words.reserve(nPath ? nPath : 1);
+      DSR_HIP(hipMemcpyAsync(d->h_res.p, d->d_res.p, sizeof(dsr_decode_result) * U, hipMemcpyDeviceToHost, st));
+      if (nPath) DSR_HIP(hipMemcpyAsync(d->h_arcs.p, d->d_arcs.p, sizeof(int) * nPath, hipMemcpyDeviceToHost, st));
+      if (nPath) DSR_HIP(hipMemcpyAsync(d->h_words.p, d->d_words.p, sizeof(unsigned) * nPath, hipMemcpyDeviceToHost, st));
+      if (!d->evDone) DSR_HIP(hipEventCreateWithFlags(&d->evDone, hipEventDisableTiming));
+      DSR_HIP(hipEventRecord(d->evDone, st));
+      d->pendingU = U; d->pendingPath = nPath; d->pendingSlots = slots; d->pendingProf = nullptr; d->latU = 0;
+      return;
+    }
     int32_t* arcs_out = want_paths ? (int32_t*) 1 : nullptr; uint32_t* words_out = want_paths ? (uint32_t*) 1 : nullptr;     // (only tested for null below)
     // every input symbol must name a distribution (decoder.h:985: _dist->find(distX-1))
     for (size_t a = 0; a < d->csr.in.size(); a++) if (d->csr.in[a] > (uint32_t) nDist) throw Error(DSR_E_INDEX, "arc input %u has no distribution (nDist=%d)", d->csr.in[a], nDist);

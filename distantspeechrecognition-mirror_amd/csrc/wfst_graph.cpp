@@ -35,8 +35,13 @@ void WfstGraph::addFinal(uint32_t state, float cost)
 
 void WfstGraph::addEdgeForce(int from, int to, uint32_t in, uint32_t out, float cost)
 {
-  Arc a{from, to, in, out, cost, nodes[from].firstArc};
-  arcs.push_back(a); nodes[from].firstArc = (int) arcs.size() - 1;
+  if (!sortedOutput) { Arc a{from, to, in, out, cost, nodes[from].firstArc}; arcs.push_back(a); nodes[from].firstArc = (int) arcs.size() - 1; return; }
+  int ptr = nodes[from].firstArc, old = ptr;                        // WFSTFlyWeightSortedOutput::Node::_addEdgeForce (wfstFlyWeight.cc:754-776)
+  while (ptr >= 0 && arcs[ptr].out < out) { old = ptr; ptr = arcs[ptr].next; }
+  while (ptr >= 0 && arcs[ptr].out == out && arcs[ptr].in < in) { old = ptr; ptr = arcs[ptr].next; }
+  Arc a{from, to, in, out, cost, -1}; arcs.push_back(a); const int id = (int) arcs.size() - 1;
+  if (ptr == old) { arcs[id].next = nodes[from].firstArc; nodes[from].firstArc = id; }
+  else { arcs[id].next = ptr; arcs[old].next = id; }
 }
 
 void WfstGraph::addArc(uint32_t s1, uint32_t s2, uint32_t in, uint32_t out, float cost, bool dropEpsSelf)

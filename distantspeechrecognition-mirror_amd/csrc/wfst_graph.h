@@ -26,6 +26,9 @@ struct WfstGraph {
   std::vector<Node> nodes; std::vector<Arc> arcs;
   std::unordered_map<uint32_t, int> nodeOf;   // state -> node id in _nodes / _final (the initial node is not in it: wfstFlyWeight.cc:94-118)
   int initial = -1;
+  // WFSTFlyWeightSortedOutput (wfstFlyWeight.h:403-424): a node keeps its arcs ordered by (output, input); a new arc goes in front of the first arc that
+  // is not smaller (Node::_addEdgeForce, wfstFlyWeight.cc:754-776).  The container DecoderWordTrace searches (decoder.h:1146-1149).
+  bool sortedOutput = false;
   // text files may name states and symbols instead of numbering them: a field that does not start with a number is looked up in the state (0),
   // input (1) or output (2) lexicon (wfstFlyWeight.cc:311-347); unset: such a field is an error
   std::function<uint32_t(int, const char*)> symbolOf;

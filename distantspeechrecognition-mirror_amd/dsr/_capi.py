@@ -43,7 +43,8 @@ class MfccCfg(C.Structure):
 
 class DecoderCfg(C.Structure):
     _fields_ = [("beam", f64), ("lmScale", f64), ("lmPenalty", f64), ("silPenalty", f64), ("silenceX", u32),
-                ("maxActive", C.c_int), ("maxCandidates", C.c_int), ("arenaTokens", i64), ("streams", C.c_int), ("topN", C.c_int), ("latticeTokens", i64)]
+                ("maxActive", C.c_int), ("maxCandidates", C.c_int), ("arenaTokens", i64), ("streams", C.c_int), ("topN", C.c_int), ("latticeTokens", i64),
+                ("wordTrace", C.c_int), ("propagateN", C.c_int), ("fastHash", C.c_int), ("insertSilence", C.c_int), ("wordTraceLattice", C.c_int), ("wordTraces", i64)]
 
 
 class DecodeResult(C.Structure):
@@ -729,8 +730,10 @@ class Decoder:
     """DecoderFlyWeight (asr/decoder/decoder.i:147-199) for batches of score matrices."""
 
     def __init__(self, beam=100.0, lmScale=12.0, lmPenalty=0.0, silPenalty=0.0, silenceX=0xFFFFFFFF, maxActive=0,
-                 maxCandidates=0, arenaTokens=0, streams=0, latticeTokens=0, topN=0):
+                 maxCandidates=0, arenaTokens=0, streams=0, latticeTokens=0, topN=0, wordTrace=0, generateLattice=True, propagateN=5, fastHash=False,
+                 insertSilence=False, wordTraces=0):
         L = load(); c = DecoderCfg(); L.dsr_decoder_default_cfg(C.byref(c))
+        c.wordTrace, c.wordTraceLattice, c.propagateN, c.fastHash, c.insertSilence, c.wordTraces = int(wordTrace), int(generateLattice), propagateN, int(fastHash), int(insertSilence), wordTraces
         c.beam, c.lmScale, c.lmPenalty, c.silPenalty, c.silenceX = beam, lmScale, lmPenalty, silPenalty, silenceX
         c.maxActive, c.maxCandidates, c.arenaTokens, c.streams, c.latticeTokens, c.topN = maxActive, maxCandidates, arenaTokens, streams, latticeTokens, topN
         self.h = vp(); check(L.dsr_decoder_create(C.byref(c), C.byref(self.h))); self._g = None
@@ -764,7 +767,7 @@ class Decoder:
             r = res[u]
             out.append(dict(status=r.status, score=r.score, ac=r.ac, lm=r.lm, frames=r.frames, reachedFinal=bool(r.reachedFinal),
                             arcs=arcs[u, :min(r.nArcs, maxPath)].copy(), words=words[u, :min(r.nWords, maxPath)].copy(),
-                            activeHypos=r.activeHypos, maxActive=r.maxActiveSeen, placements=r.placements, registerFrames=r.registerFrames))
+                            activeHypos=r.activeHypos, maxActive=r.maxActiveSeen, placements=r.placements, registerFrames=r.registerFrames, finalStatesN=r.finalStatesN))
         return out
 
     def lattice(self, u=0, eosX=0):

@@ -40,6 +40,15 @@ class WFSTFlyWeightPtr(object):
         return self._out
 
 
+class WFSTFlyWeightSortedOutputPtr(WFSTFlyWeightPtr):
+    """WFSTFlyWeightSortedOutput (asr/decoder/wfstFlyWeight.h:403-424): every node keeps its arcs ordered by (output, input) -- the container
+    DecoderWordTrace searches"""
+
+    def __init__(self, statelex=None, inlex=None, outlex=None, name="WFSTFlyWeight"):
+        WFSTFlyWeightPtr.__init__(self, statelex, inlex, outlex, name)
+        K.check(K.load().dsr_wfst_set_sorted_output(self._g.h, 1))
+
+
 class WFSTransducerPtr(WFSTFlyWeightPtr):
     """The dynamic container (asr/fsm/fsm.h WFSTransducer): read(fileName, noSelfLoops) per asr/fsm/fsm.cc:901-986.  Node and arc
     order (initial node of its own, arcs prepended, epsilon:epsilon self loops dropped) are those of the fly-weight reader."""
@@ -143,3 +152,25 @@ class DecoderFlyWeightPtr(object):
 
 class DecoderPtr(DecoderFlyWeightPtr):
     """Decoder (decoder.h:1107-1125): the same _Decoder<> search over the dynamic WFSTransducer container."""
+
+
+class DecoderWordTracePtr(DecoderFlyWeightPtr):
+    """DecoderWordTrace (asr/decoder/decoder.h:1146-1304; decoder.i): the constructor of the reference, set() takes a WFSTFlyWeightSortedOutputPtr.
+    generateLattice defaults to True as in the reference -- that search reads the word trace of tokens that have none (decoder.cc:239) and is not
+    built: decode() then fails with JCONSISTENCY; with generateLattice=False the 1-best search runs on the device.  bestHypo() returns what the
+    shipped class returns (its tokens have no prev(): the last edge's symbol); wordTrace() gives the words along the best token's word traces.
+    epsilon / validEndN (early stop, decoder.cc:172-182): epsilon must be 0."""
+
+    def __init__(self, dist, beam=100.0, lmScale=12.0, lmPenalty=0.0, silPenalty=0.0, silSymbol="SIL-m", eosSymbol="</s>", heapSize=5000, topN=0,
+                 epsilon=0.0, validEndN=30, generateLattice=True, propagateN=5, fastHash=False, insertSilence=False, maxActive=0):
+        if epsilon != 0.0:
+            raise K.DsrError(13, "DecoderWordTrace: epsilon > 0 (early stop) is not built")
+        DecoderFlyWeightPtr.__init__(self, dist, beam, lmScale, lmPenalty, silPenalty, silSymbol, eosSymbol, heapSize, 0, False, 0, maxActive)
+        self._cfg.update(wordTrace=1, generateLattice=bool(generateLattice), propagateN=int(propagateN), fastHash=bool(fastHash), insertSilence=bool(insertSilence))
+
+    def wordTrace(self):
+        """output-lexicon indices of the words along the best token's word traces, first word first"""
+        return [int(w) for w in self._last["words"]]
+
+    def lattice(self):
+        raise K.DsrError(4, "Must enable lattice generation during decoding.")                  # decoder.h:807-808

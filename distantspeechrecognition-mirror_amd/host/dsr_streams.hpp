@@ -492,6 +492,13 @@ class WFSTFlyWeight {
   LexiconPtr _stateLexicon, _inputLexicon, _outputLexicon; String _name; dsr_wfst* _h;
 };
 typedef std::shared_ptr<WFSTFlyWeight> WFSTFlyWeightPtr;
+// asr/decoder/wfstFlyWeight.h:403-424: every node keeps its arcs ordered by (output, input); what DecoderWordTrace::set takes
+class WFSTFlyWeightSortedOutput : public WFSTFlyWeight {
+ public:
+  WFSTFlyWeightSortedOutput(LexiconPtr& statelex, LexiconPtr& inlex, LexiconPtr& outlex, const String& name = "WFSTFlyWeight")
+    : WFSTFlyWeight(statelex, inlex, outlex, name) { dsr_throw(dsr_wfst_set_sorted_output(handle(), 1)); }
+};
+typedef std::shared_ptr<WFSTFlyWeightSortedOutput> WFSTFlyWeightSortedOutputPtr;
 
 typedef std::vector<String> DistribPath;                       // asr/path/distribPath.h:34-60: the distribution names along a path
 // asr/lattice Lattice(statelex, inlex, outlex) (lattice.i:79-135, lattice.h:188-330): what _Decoder::lattice() returns, or an object to read() into
@@ -610,3 +617,40 @@ class DecoderFlyWeight {
   DistribSetPtr _dist; WFSTFlyWeightPtr _wfst; String _sil, _eos; dsr_decoder* _h; double _score;
 };
 typedef std::shared_ptr<DecoderFlyWeight> DecoderFlyWeightPtr;
+
+// asr/decoder/decoder.h:1146-1304 (constructor :1227-1232).  generateLattice defaults to true as in the reference; that search reads the word trace of tokens
+// that have none (decoder.cc:239) and is not built: decode() then throws jconsistency_error.  With generateLattice = false the 1-best search runs on the device.
+class DecoderWordTrace {
+ public:
+  DecoderWordTrace(DistribSetPtr& dist, double beam = 100.0, double lmScale = 12.0, double lmPenalty = 0.0, double silPenalty = 0.0, const String& silSymbol = "SIL-m",
+                   const String& eosSymbol = "</s>", unsigned heapSize = 5000, unsigned topN = 0, double epsilon = 0.0, unsigned validEndN = 30,
+                   bool generateLattice = true, unsigned propagateN = 5, bool fastHash = false, bool insertSilence = false)
+    : _dist(dist), _sil(silSymbol), _eos(eosSymbol), _h(0) {
+    (void) heapSize; (void) topN; (void) validEndN;
+    if (epsilon != 0.0) throw j_error(JPARAMETER, "DecoderWordTrace: epsilon > 0 (early stop, decoder.cc:172-182) is not built");
+    dsr_decoder_cfg c; dsr_decoder_default_cfg(&c);
+    c.beam = beam; c.lmScale = lmScale; c.lmPenalty = lmPenalty; c.silPenalty = silPenalty; c.streams = 1;
+    c.wordTrace = 1; c.wordTraceLattice = generateLattice; c.propagateN = (int) propagateN; c.fastHash = fastHash; c.insertSilence = insertSilence;
+    dsr_throw(dsr_decoder_create(&c, &_h));
+  }
+  ~DecoderWordTrace() { dsr_decoder_destroy(_h); }
+  void set(WFSTFlyWeightSortedOutputPtr& wfst) { dsr_throw(dsr_decoder_set_symbols(_h, wfst->handle(), _sil.c_str(), _eos.c_str())); _wfst = wfst; }
+  double decode(bool verbose = false) {
+    (void) verbose;
+    dsr_decode_result r; std::vector<int32_t> arcs(16); _words.assign((size_t) 1 << 16, 0u);
+    dsr_throw(dsr_decoder_decode_stream(_h, _dist->handle(), &r, arcs.data(), _words.data(), (int) _words.size()));
+    _words.resize((size_t) r.nWords); return r.score;
+  }
+  String bestHypo(bool useInputSymbols = false) {                       // (the shipped class's tokens have no prev(): one symbol)
+    size_t need = 0; dsr_throw(dsr_decoder_best_hypo(_h, 0, useInputSymbols, 0, 0, &need));
+    std::vector<char> b(need); dsr_throw(dsr_decoder_best_hypo(_h, 0, useInputSymbols, b.data(), b.size(), &need)); return String(b.data());
+  }
+  const std::vector<uint32_t>& wordTrace() const { return _words; }     // the words along the best token's word traces
+  unsigned finalStatesN() const { int n = 0; dsr_throw(dsr_decoder_final_states_n(_h, 0, &n)); return (unsigned) n; }
+  bool traceBackSucceeded() const { int ok = 0; dsr_throw(dsr_decoder_trace_back_succeeded(_h, 0, &ok)); return ok != 0; }
+  void setBeam(double beam) { dsr_throw(dsr_decoder_set_beam(_h, beam)); }
+ private:
+  DecoderWordTrace(const DecoderWordTrace&); DecoderWordTrace& operator=(const DecoderWordTrace&);
+  DistribSetPtr _dist; WFSTFlyWeightSortedOutputPtr _wfst; String _sil, _eos; dsr_decoder* _h; std::vector<uint32_t> _words;
+};
+typedef std::shared_ptr<DecoderWordTrace> DecoderWordTracePtr;

@@ -284,6 +284,9 @@ dsr_lexicon* dsr_wfst_state_lexicon(const dsr_wfst*);
 dsr_lexicon* dsr_wfst_input_lexicon(const dsr_wfst*);
 dsr_lexicon* dsr_wfst_output_lexicon(const dsr_wfst*);
 int        dsr_wfst_has_final_state(const dsr_wfst*);
+/* WFSTFlyWeightSortedOutput (asr/decoder/wfstFlyWeight.h:403-424, Node::_addEdgeForce wfstFlyWeight.cc:754-776): every node keeps its arcs ordered by
+ * (output, input), a new arc in front of the first one that is not smaller.  The container DecoderWordTrace takes.  Call on an empty transducer. */
+dsr_status dsr_wfst_set_sorted_output(dsr_wfst*, int on);
 void       dsr_wfst_destroy(dsr_wfst*);
 dsr_status dsr_wfst_read(dsr_wfst*, const char* fileName, int binary);    /* WFSTFlyWeight::read */
 /* the dynamic container's text reader, WFSTransducer::read(fileName, noSelfLoops) (asr/fsm/fsm.cc:901-986): same node/arc
@@ -319,6 +322,15 @@ typedef struct {
                                (SortedIterator, decoder.h:298-320; ties in list order, which std::sort leaves open) and applies no beam (:571-581) */
   int64_t latticeTokens;    /* generateLattice (decoder.i:199): > 0 keeps every placement of every frame, at most this many per utterance, for
                                dsr_decoder_lattice(); 0 (default here; the reference always builds its 'worse' chains, decoder.h:1113-1114) = 1-best only */
+  /* DecoderWordTrace (asr/decoder/decoder.h:1146-1304, decoder.cc:126-470; decoder.i:201-260), wordTrace != 0: the search over a WFSTFlyWeightSortedOutput
+   * whose tokens carry word traces instead of back pointers (float scores compared after rounding, decoder.cc:213-267; the end expansion's float final
+   * costs, :185-201).  Results: score / ac / lm / finalStatesN / activeHypos as usual; arcs_out holds the best token's own arc (bestHypo walks prev(), which
+   * these tokens do not have: one symbol); words_out / nWords the words along its word traces.  wordTraceLattice = the reference's generateLattice
+   * (default 1, as in the reference): that search dereferences a null word trace in the shipped code (:239) and is refused at decode (DSR_E_CONSISTENCY);
+   * set it to 0 for the 1-best search.  propagateN / fastHash only steer the refused merge and are kept for the signature; insertSilence: :414-416;
+   * wordTraces: word-trace records per utterance (0 = 2^20). */
+  int wordTrace, propagateN, fastHash, insertSilence, wordTraceLattice;
+  int64_t wordTraces;
 } dsr_decoder_cfg;
 void dsr_decoder_default_cfg(dsr_decoder_cfg*);
 typedef struct dsr_decoder dsr_decoder;

@@ -65,7 +65,25 @@ def _g12(x):
     return "%12g" % x
 
 
+class SortedOutputNode(Node):
+    """WFSTFlyWeightSortedOutput::Node::_addEdgeForce (wfstFlyWeight.cc:754-776): arcs ordered by (output, input), a new one before the first not smaller"""
+    __slots__ = ()
+
+    def add_edge_force(self, e):
+        ptr = self.edges; old = ptr
+        while ptr is not None and ptr.output < e.output:
+            old = ptr; ptr = ptr.link
+        while ptr is not None and ptr.output == e.output and ptr.input < e.input:
+            old = ptr; ptr = ptr.link
+        if ptr is old:
+            e.link = self.edges; self.edges = e
+        else:
+            e.link = ptr; old.link = e
+
+
 class FlyWeight(object):
+    NodeT = Node
+
     def __init__(self, statelex=None, inlex=None, outlex=None):
         """lexica: lists of symbols (index = position) or None"""
         self.statelex, self.inlex, self.outlex = statelex, inlex, outlex
@@ -80,7 +98,7 @@ class FlyWeight(object):
             raise ConsistencyErrorJ("Automaton already has final node %d." % state)
         nd = self.nodes.pop(state, None)
         if nd is None:
-            nd = Node(state)
+            nd = self.NodeT(state)
         nd.cost = _f32(cost); nd.final = True
         self.final[state] = nd
 
@@ -93,7 +111,7 @@ class FlyWeight(object):
             return self.final[state]
         if not create:
             raise KeyErrorJ("No state %u exists." % state)
-        self.nodes[state] = Node(state)
+        self.nodes[state] = self.NodeT(state)
         return self.nodes[state]
 
     def _field(self, lex, tok):
@@ -139,7 +157,7 @@ class FlyWeight(object):
             elif n == 4 or n == 5:
                 s2 = self._field(self.statelex, tok[1])
                 if self.initial is None:
-                    self.initial = frm = Node(s1)
+                    self.initial = frm = self.NodeT(s1)
                 else:
                     frm = self.find(s1, True)
                 to = self.find(s2, True)
@@ -153,7 +171,7 @@ class FlyWeight(object):
 
     def reverse(self, wfst):
         self._clear()
-        self.initial = rinitial = Node(MAXIMUM_INDEX - 3)
+        self.initial = rinitial = self.NodeT(MAXIMUM_INDEX - 3)
         self._add_final(wfst.initial.index, 0.0)
         rfinal = self.find(wfst.initial.index)
         for e in wfst.initial.iter_edges():                          # from the final (i.e. initial) node
@@ -171,7 +189,7 @@ class FlyWeight(object):
 
     def reverse_read(self, path):
         self._clear()
-        self.initial = rinitial = Node(MAXIMUM_INDEX - 3)
+        self.initial = rinitial = self.NodeT(MAXIMUM_INDEX - 3)
         initial_flag = False
         for line in open(path):
             tok = line.split()[:6]
@@ -242,3 +260,22 @@ def _i32(u):
 def _scanf_f(tok):
     """sscanf(tok, "%f", &cost)"""
     return _f32(float(tok))
+
+
+class FlyWeightSortedOutput(FlyWeight):
+    """WFSTFlyWeightSortedOutput (wfstFlyWeight.h:403-424)"""
+    NodeT = SortedOutputNode
+
+    def add_arc(self, s1, s2, inp, out, cost=0.0):
+        """what _readText does for one arc line (wfstFlyWeight.cc:325-358)"""
+        if self.initial is None:
+            self.initial = frm = self.NodeT(s1)
+        else:
+            frm = self.find(s1, True)
+        to = self.find(s2, True)
+        if s1 == s2 and inp == 0 and out == 0:
+            return
+        frm.add_edge_force(Edge(frm, to, inp, out, cost))
+
+    def add_final(self, s, cost=0.0):
+        self._add_final(s, cost)
