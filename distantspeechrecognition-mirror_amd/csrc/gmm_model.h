@@ -30,4 +30,9 @@ struct GmmModel {
   PerStream<GmmTieScratch> tie;
 };
 
+// k_gmm_sp.hip: the software-pipelined MFMA shape for codebooks of four Gaussians
+int gmm_sp_frames();
+size_t gmm_sp_lds(const GmmModel& m);
+bool gmm_sp_launch(GmmModel& m, const float* x, long N, float* score, unsigned char* argmin, unsigned long long* tieList, unsigned* tieCount, unsigned cap, hipStream_t st);
+
 }  // namespace dsr

@@ -465,17 +465,22 @@ void gmm_score_mfma(GmmModel& m, const float* x, long N, float* score, unsigned 
     // is settled in place
     GmmTieScratch& ts = m.tie.at(st);                           // this stream's own (two pipes may score with one model on two streams)
     DevBuf<unsigned long long>& tieList = ts.list; DevBuf<unsigned>& tieCount = ts.count;
-    const unsigned nBlk = (unsigned) cdiv(N, FT);
+    // four Gaussians a codebook, unit scales, the -log w table in LDS: the software-pipelined shape (k_gmm_sp.hip)
+    const bool sp = R == 4 && unitScale && gmm_sp_lds(m) <= (size_t) 160 * 1024 - 64 && !(getenv("DSR_GMM_SP") && atoi(getenv("DSR_GMM_SP")) == 0);
+    const int FTG = sp ? gmm_sp_frames() : FT;                    // frames per workgroup (the tie list is segmented by workgroup)
+    const unsigned nBlk = (unsigned) cdiv(N, FTG);
     // per workgroup (256 frames x K codebooks): room for 1 near tie in 32 (measured: 1 in a thousand); a full segment is settled in place
-    const unsigned cap = (unsigned) std::min<size_t>(std::max<size_t>((size_t) FT * (size_t) m.K / 32, 256), ((size_t) 1 << 30) / nBlk);
+    unsigned cap = (unsigned) std::min<size_t>(std::max<size_t>((size_t) FTG * (size_t) m.K / 32, 256), ((size_t) 1 << 30) / nBlk);
     tieList.reserve((size_t) nBlk * cap); tieCount.reserve(nBlk);
-    dim3 gridR(cdiv(N, FT));
+    if (getenv("DSR_GMM_TIECAP")) cap = std::min<unsigned>(cap, (unsigned) atoi(getenv("DSR_GMM_TIECAP")));   // (tests: a list that fills up, entries settled in place)
+    dim3 gridR(nBlk);
     const int dbg = getenv("DSR_GMM_DBG") ? atoi(getenv("DSR_GMM_DBG")) : 0;
 #define LR(SS, RR) { DSR_HIP(hipFuncSetAttribute((const void*) k_gmm_mfma_reg<SS, RR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) ldsR)); \
   hipLaunchKernelGGL((k_gmm_mfma_reg<SS, RR>), gridR, dim3(256), ldsR, st, x, N, m.D, m.Dp, m.K, m.G, m.GT, m.d_bn.p, m.d_mean.p, m.d_ivar.p, m.d_cst.p, m.d_val.p, m.d_scale.p, unitScale, \
                      score, argmin, tieList.p, tieCount.p, cap, valInLds, dbg, 2.0f * m.ivMax, m.termMax); }
 #define LRS(RR) switch (S4) { case 4: LR(4, RR) break; case 5: LR(5, RR) break; case 9: LR(9, RR) break; case 10: LR(10, RR) break; case 12: LR(12, RR) break; default: LR(17, RR) break; }
-    if (R == 4) LRS(4) else if (R == 8) LRS(8) else if (R == 16) LRS(16) else LRS(32)
+    if (sp && gmm_sp_launch(m, x, N, score, argmin, tieList.p, tieCount.p, cap, st)) { }
+    else if (R == 4) LRS(4) else if (R == 8) LRS(8) else if (R == 16) LRS(16) else LRS(32)
 #undef LRS
 #undef LR
     DSR_HIP(hipGetLastError());

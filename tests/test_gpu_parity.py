@@ -642,6 +642,31 @@ def test_gmm_mfma_mode(dsr, oracle, cuda, K, R, D):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("K,D,N,tiecap", [(7, 39, 1000, None), (9, 13, 129, None), (17, 39, 700, None), (100, 20, 513, None), (41, 39, 2000, 3), (1024, 39, 640, 16), (16, 5, 1, None)])
+def test_gmm_mfma_four_gaussian_codebooks(dsr, oracle, cuda, monkeypatch, K, D, N, tiecap):
+    """Codebooks of four Gaussians go through the software-pipelined shape (k_gmm_sp.hip): a last chunk of fewer than eight codebooks, an odd chunk
+    count (a phantom chunk closes the pair), frame counts that end inside a tile / a wave / a workgroup, a strip of fewer than 32 codebooks, every
+    contraction depth the kernel is instantiated for -- and a tie list that fills up (entries settled in place).  Argmin = the reference's on every
+    frame, scores within the stated tolerance; both shapes (DSR_GMM_SP=0: two waves per SIMD) give each other's bits."""
+    import torch
+    m = synth.gmm_model(K, 4, D, seed=12 + K)
+    rng = np.random.default_rng(K)
+    x = rng.standard_normal((N, D)).astype(np.float32)
+    gm = dsr.Gmm(**m)
+    if tiecap is not None:
+        monkeypatch.setenv("DSR_GMM_TIECAP", str(tiecap))
+    xd = torch.from_numpy(x).to(cuda)
+    sc, am = gm.score(xd, mode=2)
+    monkeypatch.setenv("DSR_GMM_SP", "0")
+    sc_b, am_b = gm.score(xd, mode=2)
+    cb = oracle.Codebooks(m["refN"], m["mean"], m["ivar"], m["det"])
+    ref, arg = oracle.gmm_score_opt(cb, m["val"], x)
+    assert np.array_equal(am.cpu().numpy().astype(np.int32), arg)
+    assert (np.abs(sc.cpu().numpy() - ref) / np.maximum(np.abs(ref), 1.0)).max() < 1e-5
+    assert torch.equal(am, am_b) and torch.equal(sc, sc_b)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("K,R,D,mu0,sigma", [(64, 4, 39, 50.0, 0.1), (32, 16, 39, 50.0, 0.1), (24, 8, 13, -300.0, 0.05), (7, 5, 20, 50.0, 0.1), (64, 4, 39, 5.0, 0.5)])
 def test_gmm_mfma_mode_offset_means(dsr, oracle, cuda, K, R, D, mu0, sigma):
     """Means far from zero with small variances (|mu| / sigma ~ 1e3): the terms the expanded form cancels are ~1e6 times the distance, so its
