@@ -647,7 +647,8 @@ def test_gmm_mfma_four_gaussian_codebooks(dsr, oracle, cuda, monkeypatch, K, D, 
     """Codebooks of four Gaussians go through the software-pipelined shape (k_gmm_sp.hip): a last chunk of fewer than eight codebooks, an odd chunk
     count (a phantom chunk closes the pair), frame counts that end inside a tile / a wave / a workgroup, a strip of fewer than 32 codebooks, every
     contraction depth the kernel is instantiated for -- and a tie list that fills up (entries settled in place).  Argmin = the reference's on every
-    frame, scores within the stated tolerance; both shapes (DSR_GMM_SP=0: two waves per SIMD) give each other's bits."""
+    frame, scores within the stated tolerance; the other shape (DSR_GMM_SP=0: two waves per SIMD) gives the same argmins and scores within the same
+    tolerance (an entry on the edge of the trust radius may be re-scored exactly by one shape and not by the other)."""
     import torch
     m = synth.gmm_model(K, 4, D, seed=12 + K)
     rng = np.random.default_rng(K)
@@ -663,7 +664,7 @@ def test_gmm_mfma_four_gaussian_codebooks(dsr, oracle, cuda, monkeypatch, K, D, 
     ref, arg = oracle.gmm_score_opt(cb, m["val"], x)
     assert np.array_equal(am.cpu().numpy().astype(np.int32), arg)
     assert (np.abs(sc.cpu().numpy() - ref) / np.maximum(np.abs(ref), 1.0)).max() < 1e-5
-    assert torch.equal(am, am_b) and torch.equal(sc, sc_b)
+    assert torch.equal(am, am_b) and float(((sc - sc_b).abs() / sc_b.abs().clamp(min=1.0)).max()) < 1e-5
 
 
 @pytest.mark.gpu
