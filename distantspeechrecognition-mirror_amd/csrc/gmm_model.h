@@ -8,7 +8,7 @@ namespace dsr {
 
 // what the MFMA scoring path hands from its contraction kernel to its near-tie kernel: owned by the model, ONE PER STREAM (two pipes on two
 // HIP streams may score with the same model at the same time; within a stream the two launches are ordered)
-struct GmmTieScratch { DevBuf<unsigned long long> list; DevBuf<unsigned> count; };
+struct GmmTieScratch { DevBuf<unsigned long long> list; DevBuf<unsigned> count; DevBuf<unsigned> masks; };
 
 struct GmmModel {
   int K = 0, D = 0, G = 0, maxRef = 0;
@@ -33,6 +33,6 @@ struct GmmModel {
 // k_gmm_sp.hip: the software-pipelined MFMA shape for codebooks of four Gaussians
 int gmm_sp_frames();
 size_t gmm_sp_lds(const GmmModel& m);
-bool gmm_sp_launch(GmmModel& m, const float* x, long N, float* score, unsigned char* argmin, unsigned long long* tieList, unsigned* tieCount, unsigned cap, hipStream_t st);
+bool gmm_sp_launch(GmmModel& m, const float* x, long N, float* score, unsigned char* argmin, DevBuf<unsigned>& masks, unsigned long long* tieList, unsigned* tieCount, unsigned cap, hipStream_t st);
 
 }  // namespace dsr

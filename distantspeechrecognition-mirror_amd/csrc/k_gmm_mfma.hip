@@ -479,7 +479,7 @@ void gmm_score_mfma(GmmModel& m, const float* x, long N, float* score, unsigned 
   hipLaunchKernelGGL((k_gmm_mfma_reg<SS, RR>), gridR, dim3(256), ldsR, st, x, N, m.D, m.Dp, m.K, m.G, m.GT, m.d_bn.p, m.d_mean.p, m.d_ivar.p, m.d_cst.p, m.d_val.p, m.d_scale.p, unitScale, \
                      score, argmin, tieList.p, tieCount.p, cap, valInLds, dbg, 2.0f * m.ivMax, m.termMax); }
 #define LRS(RR) switch (S4) { case 4: LR(4, RR) break; case 5: LR(5, RR) break; case 9: LR(9, RR) break; case 10: LR(10, RR) break; case 12: LR(12, RR) break; default: LR(17, RR) break; }
-    if (sp && gmm_sp_launch(m, x, N, score, argmin, tieList.p, tieCount.p, cap, st)) { }
+    if (sp && gmm_sp_launch(m, x, N, score, argmin, ts.masks, tieList.p, tieCount.p, cap, st)) { }
     else if (R == 4) LRS(4) else if (R == 8) LRS(8) else if (R == 16) LRS(16) else LRS(32)
 #undef LRS
 #undef LR
