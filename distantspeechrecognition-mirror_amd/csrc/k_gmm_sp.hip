@@ -93,14 +93,18 @@ __global__ __launch_bounds__(256, 1) void k_gmm_mfma_sp(const float* __restrict_
   }
 #pragma unroll
   for (int k = 0; k < NSRCH; k++) if (n0 + 32 * (k % NT) + col < N) liveBits |= 1u << k;
-  float thrS[NT], thrK[NT];                                      // 1e-5 S per frame (k_gmm_mfma.hip header); a thousand times that
+  // The trust radius per frame: 1.1e-5 S, S = 2 ivMax |x|^2 + termMax (k_gmm_mfma.hip header: each distance is off by at most (n + 2) 2^-24 S =
+  // 4.83e-6 S, n = 81 terms; the index in the low bits moves a compared value by < 2^-22 |d| <= 2.4e-7 S; two distances further apart than twice
+  // the sum keep their order).  Nothing else is added to it: k_gmm_mfma_reg's extra 1e-4 (|d| + 1) predates the bound and only lengthens the list
+  // (1.0 M entries of 1.03e9 at the pipe's shape with it, 0.4 M without).  thrK: a thousand times the radius ("the bound is no longer small against d").
+  float thrS[NT], thrK[NT];
 #pragma unroll
   for (int t = 0; t < NT; t++) {
     float xx = 0.0f;
 #pragma unroll
     for (int s = 0; s < S2; s++) if (2 * s + kh < D) xx += b[t][s];
     xx += __shfl_xor(xx, 32, 64);
-    thrS[t] = 1e-5f * (ivMax2 * xx + termMax); thrK[t] = 1000.0f * thrS[t];
+    thrS[t] = 1.1e-5f * (ivMax2 * xx + termMax); thrK[t] = 1000.0f * (1e-5f * (ivMax2 * xx + termMax));
   }
   // the wave's rows of the two outputs as buffers: what lies beyond its live frames (or beyond K: offset INV) is dropped by the range check
   const long nfr = N - n0; const int frames = nfr <= 0 ? 0 : (nfr < FTW ? (int) nfr : FTW);
@@ -159,7 +163,7 @@ __global__ __launch_bounds__(256, 1) void k_gmm_mfma_sp(const float* __restrict_
         const unsigned a1 = __float_as_uint(m) & 3u;
         pendV[k & 1] = val3[vBase + 8 * q + a1]; pendM[k & 1] = m1;
         ab3[wrA + 32 * t * ACP + 2 * q] = (unsigned char) a1;
-        const bool tf = (m2 - m1 <= vmax(__builtin_fmaf(fabsf(m1), 1e-4f, 1e-4f), thrS[t])) || (fabsf(m1) < thrK[t]);
+        const bool tf = (m2 - m1 <= thrS[t]) || (fabsf(m1) < thrK[t]);
         tieMask |= tf ? (1u << k) : 0u;
       }
       __builtin_amdgcn_sched_barrier(0);
