@@ -67,8 +67,15 @@ struct GraphDev {
   const int* nodeFinal; const float* nodeCost;
 };
 
+// Time slicing (segFrames > 0): a work item is one SEGMENT of an utterance -- segFrames frames -- and the items are taken in the order segment-major, utterance-minor,
+// so all utterances of a batch advance together and end together.  (Run to completion, a workgroup per utterance, the workgroups end over a span of one utterance's
+// duration once the queue is empty: 11 % of the launch at 1000 utterances on 256 CUs.)  Between its segments an utterance is its token list + these scalars.
+struct SegState { int n, status, maxActive, pad; long arenaOff, chunkEnd; double thresh; long long stat[3]; };
+static constexpr long kArenaChunk = 32768;         // back-pointer records an utterance takes from the pool at a time (time slicing: one pool, no arena per slot)
+
 struct DecDev {
   double beam, lmScale, lmPenalty, silPenalty; uint32_t silenceX; int noPen;
+  int segFrames, segCount, segQueues; long poolCap; unsigned long long* poolNext; SegState* segState; int* segDone; TokA* saveA; TokB* saveB;
   int maxTok, maxCand; long arenaCap;
   // per-slot scratch (slot s at base + s*stride)
   TokA* tokA; TokB* tokB; TokA* ctok; Side* side; int fastOK; int* tokOff; int* tokCnt; int* owner; int* rank; int* chead; CandA* cA; CandB* cB; unsigned* first; unsigned* tags; Bp* arena;
@@ -95,6 +102,11 @@ __device__ __forceinline__ unsigned ld_u32(const unsigned* p) { return __hip_ato
 __device__ __forceinline__ int ld_i32(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void st_u32(unsigned* p, unsigned v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void st_i32(int* p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// What an utterance carries from one CU to another (time slicing) is READ with device-scope loads (past the reader's L1).  The utterance never leaves its XCD --
+// every XCD has its own queue -- so the L2 both CUs share is the point of coherence and the writes stay plain (the L1 writes through).  Measured alternatives: release /
+// acquire fences at device scope write back and invalidate a whole L2 per hand-over (0.1 ms each); write-through stores for the back-pointer records cost 2 % of the launch.
+__device__ __forceinline__ void st_u64_dev(void* p, unsigned long long v) { __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ unsigned long long ld_u64_dev(const void* p) { return __hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 // inclusive prefix sum over the wave: four row shifts inside every 16-lane row, then the row totals are handed on
 // (row_bcast:15 into rows 1 and 3, row_bcast:31 into rows 2 and 3) -- six DPP adds, no LDS round trips
@@ -253,7 +265,7 @@ __global__ __launch_bounds__(kThreads) void k_viterbi(const VitArgs argsInKernar
   if (PROF && threadIdx.x < 32) s_prof[threadIdx.x] = 0;
 #define TICK(ix) do { if (PROF && tid == 0) { const long long tn = (long long) wall_clock64(); s_prof[ix] += tn - s_tlast; s_tlast = tn; } } while (0)
   constexpr int nthr = kThreads, nw = kWaves;
-  __shared__ int s_u;
+  __shared__ int s_u; __shared__ long long s_chunk;
 
   const int tid = threadIdx.x;
   const int slot = blockIdx.x;
@@ -275,7 +287,7 @@ __global__ __launch_bounds__(kThreads) void k_viterbi(const VitArgs argsInKernar
   // needs resetting; the table is wiped when the 8-bit tag runs out (and on the very first use of a slot)
   if (tid == 0) s_tag = ka->D.tags[slot];
   // back pointers: one arena per slot (lattice mode: one per utterance -- they outlive the slot: the host builds the lattice from them)
-#define arena (ka->D.arena + (size_t) ((EXTRA && ka->D.latOn) ? u : slot) * ka->D.arenaCap)
+#define arena (ka->D.arena + (size_t) ((EXTRA && ka->D.latOn) ? u : (ka->D.segFrames > 0 ? 0 : slot)) * ka->D.arenaCap)
 #define sc (ka->scores + (size_t) u * ka->Tmax * nDist)
   constexpr int fastCapC = ((kFastK + 32) * nthr < kFastC) ? (kFastK + 32) * nthr : kFastC;
   constexpr int fastCapN = kP1 * 64 * nw;                                   // kP1 rounds of 64 tokens per wave
@@ -283,29 +295,54 @@ __global__ __launch_bounds__(kThreads) void k_viterbi(const VitArgs argsInKernar
   // capacities that follow from the LDS budget of this launch: table (load <= 0.75 per pass), slot offsets, LDS side records
   const int tableC = (hashN >> 1) + (hashN >> 2), eCap = kFastE, sideLds = regionB >> 5;
 
+  // time slicing: the XCD this workgroup runs on (HW_REG_XCC_ID, bits 3:0) picks its queue and its share of the utterances (u = xcd mod 8)
+  // (segQueues == 1: one queue, any workgroup may take any utterance up -- the hand-over then pays device-scope fences; small grids and the tests)
+  const int nq = (EXTRA || ka->D.segFrames <= 0) ? 1 : ka->D.segQueues;
+  const int xcd = nq == 8 ? (int) (__builtin_amdgcn_s_getreg((3 << 11) | 20) & 7u) : 0;
   for (;;) {
     __syncthreads();
-    if (tid == 0) s_u = atomicAdd(ka->D.queue, 1);
+    if (tid == 0) s_u = atomicAdd(ka->D.queue + xcd, 1);
     __syncthreads();
     RELOAD();
-    const int u = s_u;
-    if (u >= ka->U) break;
+    const int item = s_u, segS = EXTRA ? 0 : ka->D.segFrames;               // segS > 0: time slicing (never with the lattice / topN / dump modes)
+    const int Ux = (ka->U - xcd + nq - 1) / nq;                               // utterances of this queue: u = xcd mod nq
+    if (item >= (segS > 0 ? ka->D.segCount * Ux : Ux)) break;
+    const int u = segS > 0 ? xcd + nq * (item % Ux) : item, seg = segS > 0 ? item / Ux : 0;
+    const int T = ka->nframesArr[u] < ka->Tmax ? ka->nframesArr[u] : ka->Tmax;
+    const int fr0 = seg * segS, frEnd = segS > 0 ? fr0 + segS : 0x7FFFFFFF;   // this item: frames fr0 .. frEnd-1 (the end expansion is "frame" T)
+    if (fr0 > T) continue;                                                     // the utterance ended in an earlier segment
     if (EXTRA && ka->D.latOn && tid == 0) ka->D.latFrameOff[(size_t) u * (ka->Tmax + 3)] = 0;
     if (PROF && tid == 0) { const long long tn = (long long) wall_clock64(); if (s_prof[15]) s_prof[10] += tn - s_prof[15]; s_tlast = tn; }
-    const int T = ka->nframesArr[u] < ka->Tmax ? ka->nframesArr[u] : ka->Tmax;
 #define dump (EXTRA && ka->D.dumpOn && slot == 0)
-    if (tid == 0) { s_stat[0] = 0; s_stat[1] = 0; s_stat[2] = 0; s_maxActive = 0; s_latOff = 0; }
 
     int status = DSR_OK;
     if (T <= 0) status = DSR_E_ITERATOR;         // no frame at all: the exception escapes decode() (decoder.h:691)
 
     int bufCur = 0, bufNxt = 1, bufSpr = 2;
-    int n = 1; long arenaOff = 0;
+    int n = 1; long arenaOff = 0, chunkEnd = 0;
     double thresh = HUGE_VAL, topScore = HUGE_VAL;
     for (int i = tid; i < 2 * hashN; i += nthr) hkey[i] = (i < hashN) ? 0u : 0xFFFFFFFFu;
-    if (tid == 0) {
-      TokA t0; t0.ac = 0.0f; t0.lm = 0.0f; t0.bp = kNone; t0.xs = (uint32_t) ka->G.xoff[ka->G.initial]; curA[0] = t0;
-      TokB b0; b0.node = ka->G.initial; b0.cnt = ka->G.xoff[ka->G.initial + 1] - ka->G.xoff[ka->G.initial]; curB[0] = b0;
+    if (seg == 0) {
+      if (tid == 0) {
+        s_stat[0] = 0; s_stat[1] = 0; s_stat[2] = 0; s_maxActive = 0; s_latOff = 0;
+        TokA t0; t0.ac = 0.0f; t0.lm = 0.0f; t0.bp = kNone; t0.xs = (uint32_t) ka->G.xoff[ka->G.initial]; curA[0] = t0;
+        TokB b0; b0.node = ka->G.initial; b0.cnt = ka->G.xoff[ka->G.initial + 1] - ka->G.xoff[ka->G.initial]; curB[0] = b0;
+      }
+    } else {
+      // the segment before may still be running on another CU: wait for it, then take the utterance over (token list into buffer 0, scalars)
+      if (tid == 0) { while (ld_i32(&ka->D.segDone[u]) < seg) __builtin_amdgcn_s_sleep(16); }
+      __syncthreads();
+      if (nq == 1) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      const SegState* const sst = ka->D.segState + u;
+      status = ld_i32(&sst->status);
+      if (status != DSR_OK) continue;                                          // it failed there: its result is written
+      n = ld_i32(&sst->n); arenaOff = (long) ld_u64_dev(&sst->arenaOff); chunkEnd = (long) ld_u64_dev(&sst->chunkEnd); thresh = __longlong_as_double((long long) ld_u64_dev(&sst->thresh));
+      if (tid == 0) { s_stat[0] = (long long) ld_u64_dev(&sst->stat[0]); s_stat[1] = (long long) ld_u64_dev(&sst->stat[1]); s_stat[2] = (long long) ld_u64_dev(&sst->stat[2]); s_maxActive = ld_i32(&sst->maxActive); s_latOff = 0; }
+      const TokA* const svA = ka->D.saveA + (size_t) u * ka->D.maxTok; const TokB* const svB = ka->D.saveB + (size_t) u * ka->D.maxTok;
+      for (int i = tid; i < n; i += nthr) {
+        const unsigned long long a0 = ld_u64_dev(&svA[i]), a1 = ld_u64_dev(reinterpret_cast<const unsigned long long*>(&svA[i]) + 1), b0 = ld_u64_dev(&svB[i]);
+        unsigned long long* da = reinterpret_cast<unsigned long long*>(&curA[i]); da[0] = a0; da[1] = a1; *reinterpret_cast<unsigned long long*>(&curB[i]) = b0;
+      }
     }
     __syncthreads();
 
@@ -313,10 +350,11 @@ __global__ __launch_bounds__(kThreads) void k_viterbi(const VitArgs argsInKernar
     int preC = -1;                                                             // >= 0: the frame before has already laid out this frame's slots (bitmap, group table): preC placements
     const bool preRow = useLdsRow && nDist <= 2 * nthr;
     float rowNext[2] = {0.0f, 0.0f};
-    if (preRow && T > 0) { if (tid < nDist) rowNext[0] = sc[tid]; if (tid + nthr < nDist) rowNext[1] = sc[tid + nthr]; }
+    if (preRow && fr0 < T) { const float* r0 = sc + (size_t) fr0 * nDist; if (tid < nDist) rowNext[0] = r0[tid]; if (tid + nthr < nDist) rowNext[1] = r0[tid + nthr]; }
     TICK(11);
-    // frames 0..T-1 (mode 0), then the end expansion (mode 1)
-    for (int fr = 0; fr <= T && status == DSR_OK; fr++) {
+    // frames 0..T-1 (mode 0), then the end expansion (mode 1) -- with time slicing: this segment's share of them
+    int fr = fr0;
+    for (; fr <= T && fr < frEnd && status == DSR_OK; fr++) {
       RELOAD();
       // the thread index behind an opaque copy, once per frame: nothing derived from it (lane masks, per-thread addresses of any
       // phase or of the memory path) can be hoisted out of the frame loop, where it would sit in scratch memory and be re-read
@@ -820,7 +858,15 @@ __global__ __launch_bounds__(kThreads) void k_viterbi(const VitArgs argsInKernar
           numNew = uni(s_waveTot[0]);
           { const int a = (lq < nw) ? s_waveTotE[lq] : 0; numStat = __builtin_amdgcn_readlane(wave_incl_scan(a, lq), 63); }
           RELOAD();
-          if (numNew > ka->D.maxTok || arenaOff + numNew > ka->D.arenaCap) { status = DSR_E_ALLOCATION; break; }
+          if (numNew > ka->D.maxTok || (segS == 0 && arenaOff + numNew > ka->D.arenaCap)) { status = DSR_E_ALLOCATION; break; }
+          if (segS > 0 && arenaOff + numNew > chunkEnd) {                      // (uniform) the utterance's next run of back-pointer records from the pool
+            const long need = numNew > kArenaChunk ? (long) numNew : kArenaChunk;
+            __syncthreads();
+            if (tid == 0) s_chunk = (long long) atomicAdd(ka->D.poolNext, (unsigned long long) need);
+            __syncthreads();
+            arenaOff = (long) s_chunk; chunkEnd = arenaOff + need;
+            if (chunkEnd > ka->D.poolCap) { status = DSR_E_ALLOCATION; break; }
+          }
           const XRecD* const xrecW = ka->G.xrecD; TokA* const outA = nxtA; TokB* const outB = nxtB; Bp* const outBp = arena + arenaOff;
           // ---- P6: the new list in reverse first-arrival order + back pointers; the state table is wiped for the next frame
           auto write4 = [&](auto NB, const int g4, const float* ac4, const float* lm4, const int* rec4, const unsigned* ek4) __attribute__((always_inline)) {
@@ -1135,7 +1181,15 @@ __global__ __launch_bounds__(kThreads) void k_viterbi(const VitArgs argsInKernar
       __syncthreads();
       numStat = 0;
       for (int w = 0; w < nw; w++) { numNew += s_waveTot[w]; numStat += s_waveTotE[w]; }
-      if (numNew > ka->D.maxTok || arenaOff + numNew > ka->D.arenaCap) { status = DSR_E_ALLOCATION; break; }
+      if (numNew > ka->D.maxTok || (segS == 0 && arenaOff + numNew > ka->D.arenaCap)) { status = DSR_E_ALLOCATION; break; }
+      if (segS > 0 && arenaOff + numNew > chunkEnd) {
+        const long need = numNew > kArenaChunk ? (long) numNew : kArenaChunk;
+        __syncthreads();
+        if (tid == 0) s_chunk = (long long) atomicAdd(ka->D.poolNext, (unsigned long long) need);
+        __syncthreads();
+        arenaOff = (long) s_chunk; chunkEnd = arenaOff + need;
+        if (chunkEnd > ka->D.poolCap) { status = DSR_E_ALLOCATION; break; }
+      }
       // ---------------- phase C2: write the new token list (reverse first-arrival order) + back pointers
       {
         int wbase = 0; for (int q = 0; q < wave; q++) wbase += s_waveTot[q];
@@ -1156,7 +1210,7 @@ __global__ __launch_bounds__(kThreads) void k_viterbi(const VitArgs argsInKernar
                 if (bw.rec & 0x40000000) na.xs |= 0x80000000u;
                 bp.prev = bw.prevBp; bp.rec = (uint32_t) recW;
               } else {
-                if (bw.rec == (int) 0x7FFFFFFE) { const Bp o = arena[bw.prevBp]; bp = o; }     // replaces the token in its chain
+                if (bw.rec == (int) 0x7FFFFFFE) { if (segS > 0) { const unsigned long long v = ld_u64_dev(&arena[bw.prevBp]); bp.prev = (uint32_t) v; bp.rec = (uint32_t) (v >> 32); } else { const Bp o = arena[bw.prevBp]; bp = o; } }     // replaces the token in its chain
                 else { bp.prev = bw.prevBp; bp.rec = (uint32_t) bw.rec; }
               }
               nxtA[pos] = na; nxtB[pos] = nb; arena[arenaOff + pos] = bp;
@@ -1228,7 +1282,10 @@ __global__ __launch_bounds__(kThreads) void k_viterbi(const VitArgs argsInKernar
           if (k != ~0ull) {
             const TokA bt = ld_tok(&lst[(unsigned) (k & 0xFFFFFFFFu)]);
             r.ac = bt.ac; r.lm = bt.lm; r.score = __dadd_rn((double) bt.ac, (double) bt.lm);
-            for (uint32_t bq = bt.bp; bq != kNone && nH < hopCap; ) { const uint2 e = *reinterpret_cast<const uint2*>(&arena[bq]); hopRec[nH++] = (int) e.y; bq = e.x; }
+            for (uint32_t bq = bt.bp; bq != kNone && nH < hopCap; ) {          // (time slicing: the records were written on other CUs -- read past this XCD's L2)
+              uint2 e; if (segS > 0) { const unsigned long long v = ld_u64_dev(&arena[bq]); e.x = (unsigned) v; e.y = (unsigned) (v >> 32); } else e = *reinterpret_cast<const uint2*>(&arena[bq]);
+              hopRec[nH++] = (int) e.y; bq = e.x;
+            }
           } else r.status = DSR_E_CONSISTENCY;
           s_tb[0] = nH; s_tb[1] = 0;
         }
@@ -1291,9 +1348,28 @@ __global__ __launch_bounds__(kThreads) void k_viterbi(const VitArgs argsInKernar
 
     RELOAD();
     if (PROF && tid == 0) s_prof[15] = (long long) wall_clock64();
+    if (segS > 0 && status == DSR_OK && fr <= T) {
+      // the segment is done and the utterance is not: it is put down -- list and scalars to memory, visible to the whole device, THEN the segment count
+      TokA* const svA = ka->D.saveA + (size_t) u * ka->D.maxTok; TokB* const svB = ka->D.saveB + (size_t) u * ka->D.maxTok;
+      for (int i = tid; i < n; i += nthr) { svA[i] = curA[i]; svB[i] = curB[i]; }
+      if (tid == 0) {
+        SegState* const sst = ka->D.segState + u;
+        st_i32(&sst->n, n); st_i32(&sst->status, DSR_OK); st_i32(&sst->maxActive, s_maxActive); st_u64_dev(&sst->arenaOff, (unsigned long long) arenaOff); st_u64_dev(&sst->chunkEnd, (unsigned long long) chunkEnd);
+        st_u64_dev(&sst->thresh, (unsigned long long) __double_as_longlong(thresh));
+        st_u64_dev(&sst->stat[0], (unsigned long long) s_stat[0]); st_u64_dev(&sst->stat[1], (unsigned long long) s_stat[1]); st_u64_dev(&sst->stat[2], (unsigned long long) s_stat[2]);
+      }
+      if (nq == 1) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      else __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");                // every thread's stores have reached the L2 (s_waitcnt vmcnt(0): the L1 writes through)
+      __syncthreads();
+      if (tid == 0) st_i32(&ka->D.segDone[u], seg + 1);
+      continue;
+    }
     if (status != DSR_OK) {
       // abort: the tagged state table needs no cleaning
-      if (tid == 0) { dsr_decode_result* const res = ka->res; clear_result(&res[u]); res[u].status = status; res[u].frames = T - 1; }
+      if (tid == 0) {
+        dsr_decode_result* const res = ka->res; clear_result(&res[u]); res[u].status = status; res[u].frames = T - 1;
+        if (segS > 0) { st_i32(&ka->D.segState[u].status, status); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); st_i32(&ka->D.segDone[u], 0x7FFFFFFF); }   // later segments pass by
+      }
     }
   }
   RELOAD();
@@ -1326,6 +1402,7 @@ struct DecoderState {
   DevBuf<TokA> d_tokA, d_ctok; DevBuf<TokB> d_tokB; DevBuf<Side> d_side; DevBuf<XRecD> d_xrecD; int fastOK = 0; int maxCnt = 0; DevBuf<int> d_tokOff, d_tokCnt, d_owner, d_rank, d_chead; DevBuf<unsigned> d_tags; DevBuf<CandA> d_cA; DevBuf<CandB> d_cB; DevBuf<unsigned> d_first; DevBuf<Bp> d_arena;
   DevBuf<long long> d_prof; DevBuf<dsr_decode_result> d_res; DevBuf<int> d_arcs; DevBuf<unsigned> d_words;
   long arenaCap = 0; int initial = 0; unsigned tokenMemoryLimit = 0;
+  DevBuf<SegState> d_segState; DevBuf<int> d_segDone; DevBuf<unsigned long long> d_poolNext; DevBuf<TokA> d_saveA; DevBuf<TokB> d_saveB;   // time slicing (DecDev::segFrames)
   // DecoderWordTrace mode (cfg.wordTrace): scratch of k_wordtrace.hip
   DevBuf<WTok> w_tok; DevBuf<WCand> w_cand; DevBuf<int> w_tokOff, w_rank; DevBuf<unsigned long long> w_best; DevBuf<unsigned> w_first; DevBuf<int4> w_traces; size_t w_tablesFor = 0;
   bool costNegZero = false; double costMinAbs = HUGE_VAL;      // over the arcs of the transducer set last: a cost of -0.0; the smallest non-zero |cost|
@@ -1573,6 +1650,24 @@ dsr_status dsr_decoder_set_beam(dsr_decoder* d, double beam) { return guard([&] 
 
 dsr_status dsr_decoder_enable_dump(dsr_decoder* d, int en) { return guard([&] { if (!d) throw Error(DSR_E_PARAMETER, "null argument"); d->dumpOn = en; }); }
 
+// Which XCD a workgroup lands on: HW_REG_XCC_ID of workgroup i of a 64-workgroup grid.  The XCD-bound queues of the time-sliced decode rest on two properties of the
+// dispatcher that are checked here once per process instead of assumed: eight XCDs numbered 0..7, and workgroup i of a grid on XCD (i mod 8) -- so that a grid of 8 k
+// workgroups serves every queue.
+__global__ void k_xcc_probe(int* out) { if (threadIdx.x == 0) out[blockIdx.x] = (int) (__builtin_amdgcn_s_getreg((3 << 11) | 20) & 15u); }
+static bool xcd_round_robin(hipStream_t st)
+{
+  static int known = -1;
+  if (known >= 0) return known == 1;
+  DevBuf<int> o; o.reserve(64); int h[64];
+  hipLaunchKernelGGL(k_xcc_probe, dim3(64), dim3(64), 0, st, o.p);
+  DSR_HIP(hipMemcpyAsync(h, o.p, sizeof(h), hipMemcpyDeviceToHost, st)); DSR_HIP(hipStreamSynchronize(st));
+  bool ok = true; unsigned seen = 0;
+  for (int i = 0; i < 64; i++) { if (h[i] < 0 || h[i] > 7 || h[i] != h[i & 7]) ok = false; }
+  for (int i = 0; i < 8 && ok; i++) seen |= 1u << h[i];
+  known = (ok && seen == 0xFFu) ? 1 : 0;
+  return known == 1;
+}
+
 static void ensure_scratch(dsr_decoder* d, int slots, int Tmax, int arenas)
 {
   const dsr_decoder_cfg& c = d->cfg;
@@ -1589,7 +1684,7 @@ static void ensure_scratch(dsr_decoder* d, int slots, int Tmax, int arenas)
   d->d_first.reserve(S * d->nNodes); d->d_tokCnt.reserve(S * (c.maxActive + 1)); d->d_chead.reserve(S * c.maxCandidates);
   d->d_tags.reserve(S); DSR_HIP(hipMemset(d->d_tags.p, 0, S * sizeof(unsigned)));          // tag 0 = wipe the table on first use
   d->d_arena.reserve((size_t) (arenas > slots ? arenas : slots) * (size_t) arena);
-  d->d_queue.reserve(1);
+  d->d_queue.reserve(8);
   d->nSlots = slots; d->arenaCap = arena;
 }
 
@@ -1617,14 +1712,14 @@ dsr_status dsr_decoder_decode_launch(dsr_decoder* d, const float* score, const i
       const dsr_decoder_cfg& c = d->cfg; const size_t S = (size_t) slots;
       const long maxTraces = c.wordTraces > 0 ? (long) c.wordTraces : (long) 1 << 20;
       d->w_tok.reserve(S * 2 * c.maxActive); d->w_cand.reserve(S * c.maxCandidates); d->w_tokOff.reserve(S * (c.maxActive + 1)); d->w_rank.reserve(S * c.maxCandidates);
-      d->w_traces.reserve((size_t) U * maxTraces); d->d_queue.reserve(1); d->d_res.reserve(U);
+      d->w_traces.reserve((size_t) U * maxTraces); d->d_queue.reserve(8); d->d_res.reserve(U);
       if (d->w_tablesFor != S * d->nNodes) {                               // the per-state tables are all ones between frames: set once, the kernel restores them
         d->w_best.reserve(S * d->nNodes); d->w_first.reserve(S * d->nNodes); d->w_tablesFor = S * d->nNodes;
         DSR_HIP(hipMemsetAsync(d->w_best.p, 0xFF, sizeof(unsigned long long) * S * d->nNodes, st)); DSR_HIP(hipMemsetAsync(d->w_first.p, 0xFF, sizeof(unsigned) * S * d->nNodes, st));
       }
       if (maxPath < 1) maxPath = 1;
       d->d_arcs.reserve((size_t) U * maxPath); d->d_words.reserve((size_t) U * maxPath);
-      DSR_HIP(hipMemsetAsync(d->d_queue.p, 0, sizeof(int), st));
+      DSR_HIP(hipMemsetAsync(d->d_queue.p, 0, 8 * sizeof(int), st));
       WtArgs A; A.nNodes = d->nNodes; A.initial = d->initial; A.xoff = d->d_xoff.p; A.xrec = d->d_xrec.p; A.xarc = d->d_xarc.p; A.xpathOff = d->d_xpathOff.p; A.eoff = d->d_eoff.p;
       A.erec = d->d_erec.p; A.path = d->d_path.p; A.arcCost = d->d_arcCost.p; A.arcOut = d->d_arcOut.p; A.arcIn = d->d_arcIn.p; A.nodeFinal = d->d_nodeFinal.p; A.nodeCost = d->d_nodeCost.p;
       A.beam = c.beam; A.lmScale = c.lmScale; A.lmPenalty = c.lmPenalty; A.silPenalty = c.silPenalty; A.silenceX = c.silenceX; A.insertSilence = c.insertSilence;
@@ -1648,11 +1743,30 @@ dsr_status dsr_decoder_decode_launch(dsr_decoder* d, const float* score, const i
     int slots = d->cfg.streams; if (slots > U) slots = U; if (d->dumpOn) slots = 1;
     const bool latOn = d->cfg.latticeTokens > 0;
     if (latOn && d->dumpOn) throw Error(DSR_E_PARAMETER, "lattice bookkeeping and the token dump are separate debugging aids: enable one");
-    ensure_scratch(d, slots, Tmax, latOn ? U : 0);
+    // Time slicing (DecDev): when there are more utterances than workgroups, in the plain decode mode.  DSR_VITERBI_SEG = frames per segment (0: run every utterance to completion).
+    int segFrames = 0;
+    if (!latOn && !d->dumpOn && d->cfg.topN <= 0 && U > slots) {
+      segFrames = getenv("DSR_VITERBI_SEG") ? atoi(getenv("DSR_VITERBI_SEG")) : 125;
+      if (segFrames < 0 || 2 * segFrames > Tmax + 1) segFrames = 0;
+    }
+    // XCD-bound queues (the cheap hand-over) need workgroups on every XCD: grids of 8 k >= 64 workgroups on a device that deals workgroups out round robin.
+    // Anything else decodes every utterance in one go -- unless DSR_VITERBI_SEG_ANY asks for the one-queue form (device-scope fences at every hand-over: the tests).
+    int segQueues = 8;
+    if (segFrames > 0 && !(slots >= 64 && slots % 8 == 0 && xcd_round_robin((hipStream_t) stream))) { if (getenv("DSR_VITERBI_SEG_ANY")) segQueues = 1; else segFrames = 0; }
+    if (segFrames > 0 && getenv("DSR_VITERBI_SEG_ANY") && atoi(getenv("DSR_VITERBI_SEG_ANY")) == 2) segQueues = 1;
+    // (sliced: one pool of back-pointer records for the batch instead of an arena per slot -- 1536 records per utterance and frame on average, at least what the slots had)
+    const long arenaPer = d->cfg.arenaTokens > 0 ? (long) d->cfg.arenaTokens : (long) 8192 * (long) (Tmax + 2);
+    int poolArenas = 0;
+    if (segFrames > 0) {
+      const double want = (double) U * 1536.0 * (double) (Tmax + 2) / (double) arenaPer;
+      poolArenas = (int) std::min<double>(std::ceil(want), (double) (0xFFFFFFF0u / (unsigned long long) arenaPer));
+      if ((unsigned long long) std::max(poolArenas, slots) * (unsigned long long) arenaPer > 0xFFFFFFF0ull) segFrames = 0;      // back pointers are 32-bit pool indices
+    }
+    ensure_scratch(d, slots, Tmax, latOn ? U : (segFrames > 0 ? poolArenas : 0));
     d->d_res.reserve(U);
     if (maxPath < 0) maxPath = 0;
     if (arcs_out || words_out) { d->d_arcs.reserve((size_t) U * (maxPath > 0 ? maxPath : 1)); d->d_words.reserve((size_t) U * (maxPath > 0 ? maxPath : 1)); }
-    DSR_HIP(hipMemsetAsync(d->d_queue.p, 0, sizeof(int), st));
+    DSR_HIP(hipMemsetAsync(d->d_queue.p, 0, 8 * sizeof(int), st));
     if (d->dumpOn) {
       d->dumpCap = (long) d->cfg.maxActive * 64 < (long) 1 << 26 ? (long) 1 << 24 : (long) 1 << 26;
       d->d_dumpFrameOff.reserve(Tmax + 2); d->d_dumpCount.reserve(2);
@@ -1670,6 +1784,16 @@ dsr_status dsr_decoder_decode_launch(dsr_decoder* d, const float* score, const i
     D.silenceX = d->cfg.silenceX; D.maxTok = d->cfg.maxActive; D.maxCand = d->cfg.maxCandidates; D.arenaCap = d->arenaCap;
     D.tokA = d->d_tokA.p; D.tokB = d->d_tokB.p; D.ctok = d->d_ctok.p; D.side = d->d_side.p; D.fastOK = d->fastOK; D.tokOff = d->d_tokOff.p; D.owner = d->d_owner.p; D.rank = d->d_rank.p; D.cA = d->d_cA.p; D.cB = d->d_cB.p;
     D.first = d->d_first.p; D.tags = d->d_tags.p; D.tokCnt = d->d_tokCnt.p; D.chead = d->d_chead.p; D.arena = d->d_arena.p; D.queue = d->d_queue.p;
+    if (getenv("DSR_VITERBI_SEG_VERBOSE")) fprintf(stderr, "[dsr viterbi] %d utterances on %d workgroups: %s\n", U, slots, segFrames > 0 ? (segQueues == 8 ? "time-sliced, XCD-bound queues" : "time-sliced, one queue") : "run to completion");
+    D.segQueues = segQueues; D.segFrames = segFrames; D.segCount = segFrames > 0 ? (Tmax + segFrames) / segFrames : 1;            // segments cover frames 0 .. Tmax (the end expansion is "frame" T)
+    D.poolCap = 0; D.poolNext = nullptr; D.segState = nullptr; D.segDone = nullptr; D.saveA = nullptr; D.saveB = nullptr;
+    if (segFrames > 0) {
+      d->d_segState.reserve(U); d->d_segDone.reserve(U); d->d_poolNext.reserve(1);
+      d->d_saveA.reserve((size_t) U * d->cfg.maxActive); d->d_saveB.reserve((size_t) U * d->cfg.maxActive);
+      DSR_HIP(hipMemsetAsync(d->d_segDone.p, 0, sizeof(int) * (size_t) U, st)); DSR_HIP(hipMemsetAsync(d->d_poolNext.p, 0, sizeof(unsigned long long), st));
+      D.poolCap = (long) ((size_t) std::max(poolArenas, slots) * (size_t) d->arenaCap); if (D.poolCap > (long) 0xFFFFFFF0L) D.poolCap = (long) 0xFFFFFFF0L;
+      D.poolNext = d->d_poolNext.p; D.segState = d->d_segState.p; D.segDone = d->d_segDone.p; D.saveA = d->d_saveA.p; D.saveB = d->d_saveB.p;
+    }
     D.prof = nullptr;
     if (getenv("DSR_VITERBI_PROF")) { d->d_prof.reserve((size_t) slots * 32); D.prof = d->d_prof.p; }
     D.dumpOn = d->dumpOn; D.dumpCap = d->dumpCap; D.dumpFrameOff = d->d_dumpFrameOff.p; D.dumpNode = d->d_dumpNode.p; D.dumpAc = d->d_dumpAc.p;

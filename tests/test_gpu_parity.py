@@ -455,6 +455,50 @@ def test_viterbi_long_epsilon_paths(dsr, oracle, cuda):
         assert (out[0]["registerFrames"] > 0) == (env is None)
 
 
+@pytest.mark.parametrize("seg,streams,path,U", [(7, 3, "register", 29), (5, 8, "register", 29), (16, 9, "register", 29), (7, 3, "memory", 29), (6, 256, "register", 700), (9, 64, "register", 150)])
+def test_viterbi_time_sliced(dsr, oracle, cuda, monkeypatch, seg, streams, path, U):
+    """More utterances than workgroups: the decode is time-sliced (DSR_VITERBI_SEG frames a segment; an utterance is put down after its segment -- token list and
+    scalars in memory, back-pointer records in the batch's pool -- and taken up by whichever workgroup comes next: of its XCD (grids of 8 k >= 64 workgroups, the
+    hand-over stays inside one L2) or, on small grids and only when DSR_VITERBI_SEG_ANY asks for it, any (device-scope fences).  Ragged lengths (utterances that end
+    in different segments, one of a single frame, one without frames), utterances that fail in a late segment (their capacity runs out) while their neighbours carry
+    on: every result equals the run-to-completion decode (DSR_VITERBI_SEG=0) field for field and the oracle's bits."""
+    import torch
+    arcs, fin = synth.random_wfst(1500, 48, seed=31, eps_frac=0.2)
+    go, gd = _graphs(dsr, oracle, arcs, fin)
+    rng = np.random.default_rng(77)
+    T = 45
+    monkeypatch.setenv("DSR_VITERBI_SEG_ANY", "1")
+    sc = rng.uniform(0, 8, (U, T, 48)).astype(np.float32)
+    nfr = [int(v) for v in rng.integers(2, T + 1, U)]
+    nfr[0] = T; nfr[3] = 1; nfr[5] = 0; nfr[9] = seg; nfr[10] = seg + 1; nfr[11] = 2 * seg - 1
+    if path == "memory":
+        monkeypatch.setenv("DSR_VITERBI_NOFAST", "1")
+
+    def run(segv, **dkw):
+        monkeypatch.setenv("DSR_VITERBI_SEG", str(segv))
+        dec = dsr.Decoder(beam=22.0, lmScale=12.0, streams=streams, **dkw); dec.set(gd)
+        return dec.decode_batch(torch.from_numpy(sc).to(cuda), torch.tensor(nfr, dtype=torch.int32, device=cuda))
+    a = run(seg, maxActive=8192); b = run(0, maxActive=8192)
+    keys = ["status", "score", "ac", "lm", "frames", "reachedFinal", "activeHypos", "maxActive", "placements", "registerFrames", "finalStatesN"]
+    for u in range(U):
+        assert [a[u][k] for k in keys] == [b[u][k] for k in keys], (u, nfr[u])
+        assert np.array_equal(a[u]["arcs"], b[u]["arcs"]) and np.array_equal(a[u]["words"], b[u]["words"]), u
+        if nfr[u] == 0:
+            assert a[u]["status"] == 9
+        elif u < 40:
+            ro = go.decode(sc[u, :nfr[u]], beam=22.0, lmScale=12.0)
+            assert ro["rc"] == 0
+            _check_decode(ro, a[u])
+    # a capacity that some utterances outgrow after a few segments: those fail (DSR_E_ALLOCATION) exactly where the unsliced decode fails them, the others are untouched
+    small = max(8, int(np.percentile([r["maxActive"] for r in a if r["status"] == 0], 60)))
+    c = run(seg, maxActive=small); d = run(0, maxActive=small)
+    assert sorted(set(r["status"] for r in c)) == [0, 2, 9] or sorted(set(r["status"] for r in c)) == [2, 9]
+    for u in range(U):
+        assert c[u]["status"] == d[u]["status"], u
+        if c[u]["status"] == 0:
+            assert [c[u][k] for k in keys] == [a[u][k] for k in keys] and np.array_equal(c[u]["words"], a[u]["words"])
+
+
 def test_viterbi_errors(dsr, oracle, cuda):
     import torch
     arcs, fin = synth.random_wfst(100, 8, seed=1)
