@@ -71,11 +71,12 @@ struct GraphDev {
 // so all utterances of a batch advance together and end together.  (Run to completion, a workgroup per utterance, the workgroups end over a span of one utterance's
 // duration once the queue is empty: 11 % of the launch at 1000 utterances on 256 CUs.)  Between its segments an utterance is its token list + these scalars.
 struct SegState { int n, status, maxActive, pad; long arenaOff, chunkEnd; double thresh; long long stat[3]; };
-static constexpr long kArenaChunk = 32768;         // back-pointer records an utterance takes from the pool at a time (time slicing: one pool, no arena per slot)
 
 struct DecDev {
   double beam, lmScale, lmPenalty, silPenalty; uint32_t silenceX; int noPen;
-  int segFrames, segCount, segQueues; long poolCap; unsigned long long* poolNext; SegState* segState; int* segDone; TokA* saveA; TokB* saveB;
+  // time slicing: frames per segment (0: off), segments per utterance, queues (8: one per XCD, 1: one for all), the pool of back-pointer records and how many of
+  // them an utterance takes at a time (a barrier pair and a device atomic each time: 9 us)
+  int segFrames, segCount, segQueues; long poolCap, poolChunk; unsigned long long* poolNext; SegState* segState; int* segDone; TokA* saveA; TokB* saveB;
   int maxTok, maxCand; long arenaCap;
   // per-slot scratch (slot s at base + s*stride)
   TokA* tokA; TokB* tokB; TokA* ctok; Side* side; int fastOK; int* tokOff; int* tokCnt; int* owner; int* rank; int* chead; CandA* cA; CandB* cB; unsigned* first; unsigned* tags; Bp* arena;
@@ -860,7 +861,7 @@ __global__ __launch_bounds__(kThreads) void k_viterbi(const VitArgs argsInKernar
           RELOAD();
           if (numNew > ka->D.maxTok || (segS == 0 && arenaOff + numNew > ka->D.arenaCap)) { status = DSR_E_ALLOCATION; break; }
           if (segS > 0 && arenaOff + numNew > chunkEnd) {                      // (uniform) the utterance's next run of back-pointer records from the pool
-            const long need = numNew > kArenaChunk ? (long) numNew : kArenaChunk;
+            const long need = numNew > ka->D.poolChunk ? (long) numNew : ka->D.poolChunk;
             __syncthreads();
             if (tid == 0) s_chunk = (long long) atomicAdd(ka->D.poolNext, (unsigned long long) need);
             __syncthreads();
@@ -1183,7 +1184,7 @@ __global__ __launch_bounds__(kThreads) void k_viterbi(const VitArgs argsInKernar
       for (int w = 0; w < nw; w++) { numNew += s_waveTot[w]; numStat += s_waveTotE[w]; }
       if (numNew > ka->D.maxTok || (segS == 0 && arenaOff + numNew > ka->D.arenaCap)) { status = DSR_E_ALLOCATION; break; }
       if (segS > 0 && arenaOff + numNew > chunkEnd) {
-        const long need = numNew > kArenaChunk ? (long) numNew : kArenaChunk;
+        const long need = numNew > ka->D.poolChunk ? (long) numNew : ka->D.poolChunk;
         __syncthreads();
         if (tid == 0) s_chunk = (long long) atomicAdd(ka->D.poolNext, (unsigned long long) need);
         __syncthreads();
@@ -1786,12 +1787,13 @@ dsr_status dsr_decoder_decode_launch(dsr_decoder* d, const float* score, const i
     D.first = d->d_first.p; D.tags = d->d_tags.p; D.tokCnt = d->d_tokCnt.p; D.chead = d->d_chead.p; D.arena = d->d_arena.p; D.queue = d->d_queue.p;
     if (getenv("DSR_VITERBI_SEG_VERBOSE")) fprintf(stderr, "[dsr viterbi] %d utterances on %d workgroups: %s\n", U, slots, segFrames > 0 ? (segQueues == 8 ? "time-sliced, XCD-bound queues" : "time-sliced, one queue") : "run to completion");
     D.segQueues = segQueues; D.segFrames = segFrames; D.segCount = segFrames > 0 ? (Tmax + segFrames) / segFrames : 1;            // segments cover frames 0 .. Tmax (the end expansion is "frame" T)
-    D.poolCap = 0; D.poolNext = nullptr; D.segState = nullptr; D.segDone = nullptr; D.saveA = nullptr; D.saveB = nullptr;
+    D.poolCap = 0; D.poolChunk = 0; D.poolNext = nullptr; D.segState = nullptr; D.segDone = nullptr; D.saveA = nullptr; D.saveB = nullptr;
     if (segFrames > 0) {
       d->d_segState.reserve(U); d->d_segDone.reserve(U); d->d_poolNext.reserve(1);
       d->d_saveA.reserve((size_t) U * d->cfg.maxActive); d->d_saveB.reserve((size_t) U * d->cfg.maxActive);
       DSR_HIP(hipMemsetAsync(d->d_segDone.p, 0, sizeof(int) * (size_t) U, st)); DSR_HIP(hipMemsetAsync(d->d_poolNext.p, 0, sizeof(unsigned long long), st));
       D.poolCap = (long) ((size_t) std::max(poolArenas, slots) * (size_t) d->arenaCap); if (D.poolCap > (long) 0xFFFFFFF0L) D.poolCap = (long) 0xFFFFFFF0L;
+      D.poolChunk = std::min<long>(262144, std::max<long>(4096, D.poolCap / (4 * (long) U)));      // (what an utterance leaves unused of its last run: at most a quarter of the pool in all)
       D.poolNext = d->d_poolNext.p; D.segState = d->d_segState.p; D.segDone = d->d_segDone.p; D.saveA = d->d_saveA.p; D.saveB = d->d_saveB.p;
     }
     D.prof = nullptr;
