@@ -70,7 +70,7 @@ struct GraphDev {
 // Time slicing (segFrames > 0): a work item is one SEGMENT of an utterance -- segFrames frames -- and the items are taken in the order segment-major, utterance-minor,
 // so all utterances of a batch advance together and end together.  (Run to completion, a workgroup per utterance, the workgroups end over a span of one utterance's
 // duration once the queue is empty: 11 % of the launch at 1000 utterances on 256 CUs.)  Between its segments an utterance is its token list + these scalars.
-struct SegState { int n, status, maxActive, pad; long arenaOff, chunkEnd; double thresh; long long stat[3]; };
+struct SegState { int n, status, maxActive, pad; long arenaOff, chunkEnd, arenaUsed; double thresh; long long stat[3]; };
 
 struct DecDev {
   double beam, lmScale, lmPenalty, silPenalty; uint32_t silenceX; int noPen;
@@ -320,7 +320,7 @@ __global__ __launch_bounds__(kThreads) void k_viterbi(const VitArgs argsInKernar
     if (T <= 0) status = DSR_E_ITERATOR;         // no frame at all: the exception escapes decode() (decoder.h:691)
 
     int bufCur = 0, bufNxt = 1, bufSpr = 2;
-    int n = 1; long arenaOff = 0, chunkEnd = 0;
+    int n = 1; long arenaOff = 0, chunkEnd = 0, arenaUsed = 0;             // arenaUsed: back-pointer records of the utterance so far (time slicing: its runs of the pool are not contiguous)
     double thresh = HUGE_VAL, topScore = HUGE_VAL;
     for (int i = tid; i < 2 * hashN; i += nthr) hkey[i] = (i < hashN) ? 0u : 0xFFFFFFFFu;
     if (seg == 0) {
@@ -337,7 +337,7 @@ __global__ __launch_bounds__(kThreads) void k_viterbi(const VitArgs argsInKernar
       const SegState* const sst = ka->D.segState + u;
       status = ld_i32(&sst->status);
       if (status != DSR_OK) continue;                                          // it failed there: its result is written
-      n = ld_i32(&sst->n); arenaOff = (long) ld_u64_dev(&sst->arenaOff); chunkEnd = (long) ld_u64_dev(&sst->chunkEnd); thresh = __longlong_as_double((long long) ld_u64_dev(&sst->thresh));
+      n = ld_i32(&sst->n); arenaOff = (long) ld_u64_dev(&sst->arenaOff); chunkEnd = (long) ld_u64_dev(&sst->chunkEnd); arenaUsed = (long) ld_u64_dev(&sst->arenaUsed); thresh = __longlong_as_double((long long) ld_u64_dev(&sst->thresh));
       if (tid == 0) { s_stat[0] = (long long) ld_u64_dev(&sst->stat[0]); s_stat[1] = (long long) ld_u64_dev(&sst->stat[1]); s_stat[2] = (long long) ld_u64_dev(&sst->stat[2]); s_maxActive = ld_i32(&sst->maxActive); s_latOff = 0; }
       const TokA* const svA = ka->D.saveA + (size_t) u * ka->D.maxTok; const TokB* const svB = ka->D.saveB + (size_t) u * ka->D.maxTok;
       for (int i = tid; i < n; i += nthr) {
@@ -859,7 +859,7 @@ __global__ __launch_bounds__(kThreads) void k_viterbi(const VitArgs argsInKernar
           numNew = uni(s_waveTot[0]);
           { const int a = (lq < nw) ? s_waveTotE[lq] : 0; numStat = __builtin_amdgcn_readlane(wave_incl_scan(a, lq), 63); }
           RELOAD();
-          if (numNew > ka->D.maxTok || (segS == 0 && arenaOff + numNew > ka->D.arenaCap)) { status = DSR_E_ALLOCATION; break; }
+          if (numNew > ka->D.maxTok || (segS > 0 ? arenaUsed : arenaOff) + numNew > ka->D.arenaCap) { status = DSR_E_ALLOCATION; break; }
           if (segS > 0 && arenaOff + numNew > chunkEnd) {                      // (uniform) the utterance's next run of back-pointer records from the pool
             const long need = numNew > ka->D.poolChunk ? (long) numNew : ka->D.poolChunk;
             __syncthreads();
@@ -1182,7 +1182,7 @@ __global__ __launch_bounds__(kThreads) void k_viterbi(const VitArgs argsInKernar
       __syncthreads();
       numStat = 0;
       for (int w = 0; w < nw; w++) { numNew += s_waveTot[w]; numStat += s_waveTotE[w]; }
-      if (numNew > ka->D.maxTok || (segS == 0 && arenaOff + numNew > ka->D.arenaCap)) { status = DSR_E_ALLOCATION; break; }
+      if (numNew > ka->D.maxTok || (segS > 0 ? arenaUsed : arenaOff) + numNew > ka->D.arenaCap) { status = DSR_E_ALLOCATION; break; }
       if (segS > 0 && arenaOff + numNew > chunkEnd) {
         const long need = numNew > ka->D.poolChunk ? (long) numNew : ka->D.poolChunk;
         __syncthreads();
@@ -1249,7 +1249,7 @@ __global__ __launch_bounds__(kThreads) void k_viterbi(const VitArgs argsInKernar
         if (numStat < 0) numStat = numNew;                                     // memory path: every new token is written
         if (numStat == 0 || numNew == 0) { status = DSR_E_CONSISTENCY; break; } // no token can be expanded in the next frame: the reference never terminates from here
         { const int t = bufCur; bufCur = bufNxt; bufNxt = t; }
-        n = numNew; arenaOff += numNew;
+        n = numNew; arenaOff += numNew; arenaUsed += numNew;
         if (tid == nthr - 1) { s_stat[0] += numStat; s_stat[1] += Cfr; if (fast) s_stat[2] += 1; if (numStat > s_maxActive) s_maxActive = numStat; }   // (off wave 0's path: it carries the prefix sums)
         thresh = __dadd_rn(topScore, ka->D.beam);
       } else {
@@ -1355,7 +1355,7 @@ __global__ __launch_bounds__(kThreads) void k_viterbi(const VitArgs argsInKernar
       for (int i = tid; i < n; i += nthr) { svA[i] = curA[i]; svB[i] = curB[i]; }
       if (tid == 0) {
         SegState* const sst = ka->D.segState + u;
-        st_i32(&sst->n, n); st_i32(&sst->status, DSR_OK); st_i32(&sst->maxActive, s_maxActive); st_u64_dev(&sst->arenaOff, (unsigned long long) arenaOff); st_u64_dev(&sst->chunkEnd, (unsigned long long) chunkEnd);
+        st_i32(&sst->n, n); st_i32(&sst->status, DSR_OK); st_i32(&sst->maxActive, s_maxActive); st_u64_dev(&sst->arenaOff, (unsigned long long) arenaOff); st_u64_dev(&sst->chunkEnd, (unsigned long long) chunkEnd); st_u64_dev(&sst->arenaUsed, (unsigned long long) arenaUsed);
         st_u64_dev(&sst->thresh, (unsigned long long) __double_as_longlong(thresh));
         st_u64_dev(&sst->stat[0], (unsigned long long) s_stat[0]); st_u64_dev(&sst->stat[1], (unsigned long long) s_stat[1]); st_u64_dev(&sst->stat[2], (unsigned long long) s_stat[2]);
       }
@@ -1403,6 +1403,7 @@ struct DecoderState {
   DevBuf<TokA> d_tokA, d_ctok; DevBuf<TokB> d_tokB; DevBuf<Side> d_side; DevBuf<XRecD> d_xrecD; int fastOK = 0; int maxCnt = 0; DevBuf<int> d_tokOff, d_tokCnt, d_owner, d_rank, d_chead; DevBuf<unsigned> d_tags; DevBuf<CandA> d_cA; DevBuf<CandB> d_cB; DevBuf<unsigned> d_first; DevBuf<Bp> d_arena;
   DevBuf<long long> d_prof; DevBuf<dsr_decode_result> d_res; DevBuf<int> d_arcs; DevBuf<unsigned> d_words;
   long arenaCap = 0; int initial = 0; unsigned tokenMemoryLimit = 0;
+  long lastPoolCap = 0;
   DevBuf<SegState> d_segState; DevBuf<int> d_segDone; DevBuf<unsigned long long> d_poolNext; DevBuf<TokA> d_saveA; DevBuf<TokB> d_saveB;   // time slicing (DecDev::segFrames)
   // DecoderWordTrace mode (cfg.wordTrace): scratch of k_wordtrace.hip
   DevBuf<WTok> w_tok; DevBuf<WCand> w_cand; DevBuf<int> w_tokOff, w_rank; DevBuf<unsigned long long> w_best; DevBuf<unsigned> w_first; DevBuf<int4> w_traces; size_t w_tablesFor = 0;
@@ -1796,6 +1797,7 @@ dsr_status dsr_decoder_decode_launch(dsr_decoder* d, const float* score, const i
       D.poolChunk = std::min<long>(262144, std::max<long>(4096, D.poolCap / (4 * (long) U)));      // (what an utterance leaves unused of its last run: at most a quarter of the pool in all)
       D.poolNext = d->d_poolNext.p; D.segState = d->d_segState.p; D.segDone = d->d_segDone.p; D.saveA = d->d_saveA.p; D.saveB = d->d_saveB.p;
     }
+    d->lastPoolCap = D.poolCap;
     D.prof = nullptr;
     if (getenv("DSR_VITERBI_PROF")) { d->d_prof.reserve((size_t) slots * 32); D.prof = d->d_prof.p; }
     D.dumpOn = d->dumpOn; D.dumpCap = d->dumpCap; D.dumpFrameOff = d->d_dumpFrameOff.p; D.dumpNode = d->d_dumpNode.p; D.dumpAc = d->d_dumpAc.p;
@@ -1859,6 +1861,10 @@ dsr_status dsr_decoder_decode_collect(dsr_decoder* d, dsr_decode_result* res, in
     memcpy(res, d->h_res.p, sizeof(dsr_decode_result) * U);
     if (arcs_out && nPath) memcpy(arcs_out, d->h_arcs.p, sizeof(int) * nPath);
     if (words_out && nPath) memcpy(words_out, d->h_words.p, sizeof(unsigned) * nPath);
+    if (getenv("DSR_VITERBI_SEG_VERBOSE") && d->d_poolNext.p && d->lastPoolCap > 0) {
+      unsigned long long used = 0; DSR_HIP(hipMemcpy(&used, d->d_poolNext.p, sizeof(used), hipMemcpyDeviceToHost));
+      fprintf(stderr, "[dsr viterbi] pool of back-pointer records: %.1f M of %.1f M taken\n", used / 1e6, d->lastPoolCap / 1e6);
+    }
     if (prof) {
       std::vector<long long> hp((size_t) slots * 32); DSR_HIP(hipMemcpy(hp.data(), prof, hp.size() * sizeof(long long), hipMemcpyDeviceToHost));
       double acc[32] = {0}; for (int s2 = 0; s2 < slots; s2++) for (int i = 0; i < 32; i++) acc[i] += (double) hp[(size_t) s2 * 32 + i];

@@ -377,7 +377,11 @@ typedef struct {
 } dsr_decode_result;
 /* Batched decode.  score_dev [U][Tmax][nDist] fp32 costs (row t = Distrib::score(t)), nframes_dev [U].
  * Host outputs: res[U]; arcs_out [U][maxPath] (export arc ids, first..last), words_out [U][maxPath]
- * (bestHypo output ids).  arcs_out/words_out may be NULL. */
+ * (bestHypo output ids).  arcs_out/words_out may be NULL.
+ * Scheduling (results do not depend on it): a batch of more utterances than the device has compute units is decoded in segments of 125 frames, all
+ * utterances advancing together, so that they end together (DSR_VITERBI_SEG=<frames> changes the segment, 0 decodes every utterance in one go);
+ * a capacity that runs out is per utterance either way (DSR_E_ALLOCATION in its status) -- cfg.arenaTokens then bounds the batch's POOL of
+ * back-pointer records, U/8 x (arenaTokens or 8192 x (Tmax+2)) at least, instead of one utterance's. */
 dsr_status dsr_decoder_decode_batch(dsr_decoder*, const float* score_dev, const int32_t* nframes_dev, int U,
                                     int Tmax, int nDist, dsr_decode_result* res, int32_t* arcs_out,
                                     uint32_t* words_out, int maxPath, void* stream);

@@ -497,6 +497,11 @@ def test_viterbi_time_sliced(dsr, oracle, cuda, monkeypatch, seg, streams, path,
         assert c[u]["status"] == d[u]["status"], u
         if c[u]["status"] == 0:
             assert [c[u][k] for k in keys] == [a[u][k] for k in keys] and np.array_equal(c[u]["words"], a[u]["words"])
+    # the same with the back-pointer records: cfg.arenaTokens bounds an utterance's records in both forms (sliced, they come in runs from the batch's pool)
+    cap = int(np.percentile([r["activeHypos"] for r in a if r["status"] == 0], 50) / 4)          # (records are the tokens WRITTEN: a fraction of the active ones)
+    e = run(seg, maxActive=8192, arenaTokens=cap); f = run(0, maxActive=8192, arenaTokens=cap)
+    assert [r["status"] for r in e] == [r["status"] for r in f], (cap, [r["status"] for r in e], [r["status"] for r in f])
+    assert 2 in [r["status"] for r in e] and 0 in [r["status"] for r in e], (cap, [r["status"] for r in e])
 
 
 def test_viterbi_errors(dsr, oracle, cuda):
