@@ -33,6 +33,7 @@ struct GmmModel {
 // k_gmm_sp.hip: the software-pipelined MFMA shape for codebooks of four Gaussians
 int gmm_sp_frames();
 size_t gmm_sp_lds(const GmmModel& m);
-bool gmm_sp_launch(GmmModel& m, const float* x, long N, float* score, unsigned char* argmin, DevBuf<unsigned>& masks, unsigned long long* tieList, unsigned* tieCount, unsigned cap, hipStream_t st);
+bool gmm_sp_has(int S4, int R);
+bool gmm_sp_launch(GmmModel& m, int R, const float* x, long N, float* score, unsigned char* argmin, DevBuf<unsigned>& masks, unsigned long long* tieList, unsigned* tieCount, unsigned cap, hipStream_t st);
 
 }  // namespace dsr

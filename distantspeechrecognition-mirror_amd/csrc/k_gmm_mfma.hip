@@ -465,8 +465,8 @@ void gmm_score_mfma(GmmModel& m, const float* x, long N, float* score, unsigned 
     // is settled in place
     GmmTieScratch& ts = m.tie.at(st);                           // this stream's own (two pipes may score with one model on two streams)
     DevBuf<unsigned long long>& tieList = ts.list; DevBuf<unsigned>& tieCount = ts.count;
-    // four Gaussians a codebook, unit scales, the -log w table in LDS: the software-pipelined shape (k_gmm_sp.hip)
-    const bool sp = R == 4 && unitScale && gmm_sp_lds(m) <= (size_t) 160 * 1024 - 64 && !(getenv("DSR_GMM_SP") && atoi(getenv("DSR_GMM_SP")) == 0);
+    // unit scales, the -log w table in LDS, a shape k_gmm_sp.hip is instantiated for: one wave per SIMD, MFMAs back to back, the short search
+    const bool sp = gmm_sp_has(S4, R) && unitScale && gmm_sp_lds(m) <= (size_t) 160 * 1024 - 64 && !(getenv("DSR_GMM_SP") && atoi(getenv("DSR_GMM_SP")) == 0);
     const int FTG = sp ? gmm_sp_frames() : FT;                    // frames per workgroup (the tie list is segmented by workgroup)
     const unsigned nBlk = (unsigned) cdiv(N, FTG);
     // per workgroup (256 frames x K codebooks): room for 1 near tie in 32 (measured: 1 in a thousand); a full segment is settled in place
@@ -479,7 +479,7 @@ void gmm_score_mfma(GmmModel& m, const float* x, long N, float* score, unsigned 
   hipLaunchKernelGGL((k_gmm_mfma_reg<SS, RR>), gridR, dim3(256), ldsR, st, x, N, m.D, m.Dp, m.K, m.G, m.GT, m.d_bn.p, m.d_mean.p, m.d_ivar.p, m.d_cst.p, m.d_val.p, m.d_scale.p, unitScale, \
                      score, argmin, tieList.p, tieCount.p, cap, valInLds, dbg, 2.0f * m.ivMax, m.termMax); }
 #define LRS(RR) switch (S4) { case 4: LR(4, RR) break; case 5: LR(5, RR) break; case 9: LR(9, RR) break; case 10: LR(10, RR) break; case 12: LR(12, RR) break; default: LR(17, RR) break; }
-    if (sp && gmm_sp_launch(m, x, N, score, argmin, ts.masks, tieList.p, tieCount.p, cap, st)) { }
+    if (sp && gmm_sp_launch(m, R, x, N, score, argmin, ts.masks, tieList.p, tieCount.p, cap, st)) { }
     else if (R == 4) LRS(4) else if (R == 8) LRS(8) else if (R == 16) LRS(16) else LRS(32)
 #undef LRS
 #undef LR

@@ -1,4 +1,4 @@
-// csrc/k_gmm_sp.hip -- mode 2 of dsr_gmm_score for codebooks of four Gaussians: the frame x Gaussian contraction of k_gmm_mfma.hip
+// csrc/k_gmm_sp.hip -- mode 2 of dsr_gmm_score for codebooks of 4, 8, 16 or 32 Gaussians: the frame x Gaussian contraction of k_gmm_mfma.hip
 // (same operands, same trust radius, same tie list -- read its header first) with the vector work cut down to what the matrix pipe leaves room for.
 //
 // What the shape rests on (tools/probes/mfma_valu_overlap.hip, mfma_valu_two_waves.hip, measured on gfx950): an fp32 MFMA and a VALU instruction
@@ -39,10 +39,10 @@ __device__ __forceinline__ float vmax(float a, float b) { float r; asm("v_max_f3
 __device__ __forceinline__ float vmin3(float a, float b, float c) { float r; asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
 
 // a full tie list: the codebook is settled where it stands, in the reference's operation order (cold: a call keeps it out of the loop's instruction stream)
-__device__ __noinline__ unsigned long long gmm_sp_settle(const float* __restrict__ xr, const float* __restrict__ mu, const float* __restrict__ iv, const float* __restrict__ cst, int D, int Dp)
+__device__ __noinline__ unsigned long long gmm_sp_settle(const float* __restrict__ xr, const float* __restrict__ mu, const float* __restrict__ iv, const float* __restrict__ cst, int D, int Dp, int R)
 {
   float best = 0.0f; int ba = 0;
-  for (int r = 0; r < 4; r++) {
+  for (int r = 0; r < R; r++) {
     float d = cst[r];
     for (int i = 0; i < D; i++) { const float df = __fsub_rn(mu[(size_t) r * Dp + i], xr[i]); d = __fadd_rn(d, __fmul_rn(__fmul_rn(df, df), iv[(size_t) r * Dp + i])); }
     if (r == 0 || d < best) { best = d; ba = r; }
@@ -51,7 +51,10 @@ __device__ __noinline__ unsigned long long gmm_sp_settle(const float* __restrict
 }
 
 // DBG (measurement only, DSR_GMM_SPDBG): bit 0 no searches (the accumulators are still produced), bit 1 no strip flush, bit 2 no tie hand-over
-template <int S4, int NT, int DBG = 0>   // S4 = KP/8: contraction steps in groups of four; NT column tiles (32 frames each) per wave
+// Codebooks of R = 8, 16, 32 Gaussians lie across the two lanes (col, kh = 0 / 1) that hold a column of the 32 x 32 tile: each takes best, runner-up and exact
+// best of its R/2 accumulator registers (the same network, log2(R/2) index bits), one v_permlane32_swap per value puts the two halves side by side in both
+// lanes, and both close the codebook (same values to the same LDS words; the tie flag is kept by the kh = 0 lane).
+template <int S4, int NT, int R = 4, int DBG = 0>   // S4 = KP/8: contraction steps in groups of four; NT column tiles (32 frames each) per wave; R Gaussians a codebook
 __global__ __launch_bounds__(256, 1) void k_gmm_mfma_sp(const float* __restrict__ x, long N, int D, int Dp, int K, int G, int nChunks,
                                                         const float* __restrict__ Apack, const float* __restrict__ mean, const float* __restrict__ ivar,
                                                         const float* __restrict__ cst, const float* __restrict__ val,
@@ -60,7 +63,10 @@ __global__ __launch_bounds__(256, 1) void k_gmm_mfma_sp(const float* __restrict_
 {
   constexpr int S2 = 4 * S4;                                     // MFMA groups per chunk (one group: the NT tiles' MFMAs of one contraction step)
   constexpr int FTW = 32 * NT, SCP = 36, ACP = 36;               // frames of a wave; pitch of a strip row (32 staged codebooks, rows 16-byte aligned), of an argmin row (bytes)
-  constexpr int NSRCH = 4 * NT;                                  // searches of a chunk: (tile, register group)
+  constexpr int CPC = 32 / R, RH = R / 2;                        // codebooks of a 32-row chunk; accumulator registers of a codebook in one lane (R >= 8)
+  constexpr int NSRCH = (R == 4 ? 4 : CPC) * NT;                 // searches of a chunk: (tile, register group) -- R = 4: a lane's own codebook, else a lane pair's
+  constexpr int SPC = R;                                         // chunks of a strip of 32 codebooks (32 / (R == 4 ? 8 : CPC))
+  static_assert(R == 4 || R == 8 || R == 16 || R == 32, "codebook size");
   constexpr unsigned INV = 0x7F000000u;                          // a buffer offset beyond every range: the store is dropped
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, col = lane & 31, kh = lane >> 5;
@@ -92,7 +98,9 @@ __global__ __launch_bounds__(256, 1) void k_gmm_mfma_sp(const float* __restrict_
     }
   }
 #pragma unroll
-  for (int k = 0; k < NSRCH; k++) if (n0 + 32 * (k % NT) + col < N) liveBits |= 1u << k;
+  for (int k = 0; k < NSRCH; k++) if (n0 + 32 * (k % NT) + col < N && (R == 4 || kh == 0)) liveBits |= 1u << k;
+  // which half of a lane pair the first result of a swap shows (R >= 8)
+  unsigned khA = 0u; if constexpr (R != 4) khA = __builtin_amdgcn_permlane32_swap((unsigned) kh, (unsigned) kh, false, false)[0];
   // The trust radius per frame: 1.1e-5 S, S = 2 ivMax |x|^2 + termMax (k_gmm_mfma.hip header: each distance is off by at most (n + 2) 2^-24 S =
   // 4.83e-6 S, n = 81 terms; the index in the low bits moves a compared value by < 2^-22 |d| <= 2.4e-7 S; two distances further apart than twice
   // the sum keep their order).  Nothing else is added to it: k_gmm_mfma_reg's extra 1e-4 (|d| + 1) predates the bound and only lengthens the list
@@ -110,10 +118,10 @@ __global__ __launch_bounds__(256, 1) void k_gmm_mfma_sp(const float* __restrict_
   const long nfr = N - n0; const int frames = nfr <= 0 ? 0 : (nfr < FTW ? (int) nfr : FTW);
   const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*) (score + (frames ? n0 * K : 0)), 0, frames * K * 4, 0x00020000);
   const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*) (argmin ? argmin + (frames ? n0 * K : 0) : (unsigned char*) score), 0, argmin ? frames * K : 0, 0x00020000);
-  const int rowS = col * SCP + kh, rowA = col * ACP + kh;        // this lane's place in a tile's rows of the strip / of the argmin bytes
+  const int rowS = col * SCP + (R == 4 ? kh : 0), rowA = col * ACP + (R == 4 ? kh : 0);   // this lane's place in a tile's rows of the strip / of the argmin bytes
 
   unsigned tieMask = 0u;
-  const int phase = getPhase ? (wave + (int) blockIdx.x) & 3 : 0;
+  const int phase = getPhase ? ((wave + (int) blockIdx.x) & 3) * (SPC / 4) : 0;       // in chunks
   // ---- chunk ch: all its MFMAs, then its vector work.  The Gaussian operand is replaced in place: entry s4 is re-loaded for the next chunk right
   // after its last MFMA group, a whole chunk ahead of its use.
   const f32x4* Ap4 = reinterpret_cast<const f32x4*>(Apack) + lane;
@@ -137,9 +145,10 @@ __global__ __launch_bounds__(256, 1) void k_gmm_mfma_sp(const float* __restrict_
     // ---- the searches.  Search k = (tile t, register group q) closes codebook ch 8 + 2 q + kh for frame 32 t + col.
     // Strips of four chunks, their boundaries shifted by `phase` from wave to wave and workgroup to workgroup: all waves of the grid run in step, and
     // with common boundaries the whole output would leave in bursts (21 MB every fourth chunk, nothing in between: measured 1 ms of stalled stores).
-    const int chs = ch + phase, c4 = chs & 3;                    // the chunk's place in its strip
-    const int st = (chs & ~3) - phase < 0 ? 0 : (chs & ~3) - phase;   // the strip's first chunk (the first strip of a shifted wave is short)
-    const int wrS = rowS + (ch - st) * 8, wrA = rowA + (ch - st) * 8, vBase = (ch * 8 + kh) * 4;
+    constexpr int CPS = 32 / SPC;                                // codebooks a chunk adds to the strip (8 for R = 4)
+    const int chs = ch + phase, c4 = chs & (SPC - 1);            // the chunk's place in its strip
+    const int st = (chs & ~(SPC - 1)) - phase < 0 ? 0 : (chs & ~(SPC - 1)) - phase;   // the strip's first chunk (the first strip of a shifted wave is short)
+    const int wrS = rowS + (ch - st) * CPS, wrA = rowA + (ch - st) * CPS, vBase = R == 4 ? (ch * 8 + kh) * 4 : ch * 32;
     // The winner's -log w is a dependent LDS read: it is consumed two searches later (an in-order wave would stand still for it), the order pinned.
     float pendM[2] = {0.0f, 0.0f}, pendV[2] = {0.0f, 0.0f};      // searches k - 1 and k - 2: best distance, -log w (on its way from LDS)
     if constexpr (DBG & 1) {
@@ -150,9 +159,39 @@ __global__ __launch_bounds__(256, 1) void k_gmm_mfma_sp(const float* __restrict_
       constexpr int k = decltype(KK)::value, t = k % NT, q = k / NT;
       if constexpr (k >= 2) {                                    // search k - 2 is closed: 0.5 (d + 2 v) = 0.5 d + v, one rounding either way
         constexpr int tp = (k - 2) % NT, qp = (k - 2) / NT;
-        sb3[wrS + 32 * tp * SCP + 2 * qp] = __builtin_fmaf(0.5f, pendM[k & 1], pendV[k & 1]);
+        sb3[wrS + 32 * tp * SCP + (R == 4 ? 2 : 1) * qp] = __builtin_fmaf(0.5f, pendM[k & 1], pendV[k & 1]);
       }
-      if constexpr (k < NSRCH) {
+      if constexpr (k < NSRCH && R != 4) {
+        // ---- a lane pair's codebook q of the chunk: registers RH q .. RH q + RH - 1 of both lanes
+        float lo[RH / 2], sx[RH / 2], ex[RH / 2];                  // per pair of registers: smaller / larger of the tagged values, smaller of the exact ones
+#pragma unroll
+        for (int j = 0; j < RH / 2; j++) {
+          const float da = acc[t][RH * q + 2 * j], db = acc[t][RH * q + 2 * j + 1];
+          const float ua = __uint_as_float((__float_as_uint(da) & ~(unsigned) (RH - 1)) | (unsigned) (2 * j)), ub = __uint_as_float((__float_as_uint(db) & ~(unsigned) (RH - 1)) | (unsigned) (2 * j + 1));
+          lo[j] = vmin(ua, ub); sx[j] = vmax(ua, ub); ex[j] = vmin(da, db);
+        }
+#pragma unroll
+        for (int w = RH / 2; w > 1; w >>= 1)                     // tournament: best of two bests; runner-up = the smallest of the two runners-up and the beaten best
+#pragma unroll
+          for (int j = 0; j < w / 2; j++) {
+            const float l0 = lo[2 * j], l1 = lo[2 * j + 1];
+            sx[j] = vmin3(sx[2 * j], sx[2 * j + 1], vmax(l0, l1)); lo[j] = vmin(l0, l1); ex[j] = vmin(ex[2 * j], ex[2 * j + 1]);
+          }
+        const auto rm = __builtin_amdgcn_permlane32_swap(__float_as_uint(lo[0]), __float_as_uint(lo[0]), false, false);
+        const auto r2 = __builtin_amdgcn_permlane32_swap(__float_as_uint(sx[0]), __float_as_uint(sx[0]), false, false);
+        const auto rx = __builtin_amdgcn_permlane32_swap(__float_as_uint(ex[0]), __float_as_uint(ex[0]), false, false);
+        const float mA = __uint_as_float(rm[0]), mB = __uint_as_float(rm[1]);
+        const float m = vmin(mA, mB), m2 = vmin3(__uint_as_float(r2[0]), __uint_as_float(r2[1]), vmax(mA, mB));
+        const float m1 = vmin(__uint_as_float(rx[0]), __uint_as_float(rx[1]));
+        const unsigned khW = (mB < mA) ? (khA ^ 1u) : khA;       // the half the winner sits in
+        const unsigned il = __float_as_uint(m) & (unsigned) (RH - 1);
+        const unsigned a1 = ((il >> 2) << 3) | (khW << 2) | (il & 3u);   // its row in the codebook: 8 (i / 4) + 4 kh + i % 4
+        pendV[k & 1] = val3[vBase + R * q + a1]; pendM[k & 1] = m1;
+        ab3[wrA + 32 * t * ACP + q] = (unsigned char) a1;
+        const bool tf = (m2 - m1 <= thrS[t]) || (fabsf(m1) < thrK[t]);
+        tieMask |= tf ? (1u << k) : 0u;
+      }
+      if constexpr (k < NSRCH && R == 4) {
         const float d0 = acc[t][4 * q], d1 = acc[t][4 * q + 1], d2 = acc[t][4 * q + 2], d3 = acc[t][4 * q + 3];
         // the Gaussian's index in the two lowest bits: ordered as floats, the first of equals wins as in the reference (what differs only there is a near tie)
         const float u0 = __uint_as_float(__float_as_uint(d0) & ~3u), u1 = __uint_as_float((__float_as_uint(d1) & ~3u) | 1u);
@@ -172,16 +211,16 @@ __global__ __launch_bounds__(256, 1) void k_gmm_mfma_sp(const float* __restrict_
     // into the list k_gmm_ties works from.  (Serving the list here -- an LDS atomic with its answer awaited, a 64-bit address, a loop that runs as
     // long as the busiest lane's -- cost 0.5 ms of 6.7: an in-order wave has nothing to put behind any of it.)
     tieMask &= liveBits;
-    if (ch * 8 + 8 > K) {                                        // the last chunk of a K that is no multiple of eight: its codebooks beyond K
+    if (R == 4 ? ch * 8 + 8 > K : (ch + 1) * CPC > K) {          // the last chunk of a K that does not fill it: its codebooks beyond K
 #pragma unroll
-      for (int q = 0; q < 4; q++) if (ch * 8 + 2 * q + kh >= K) tieMask &= ~(((1u << NT) - 1u) << (q * NT));
+      for (int q = 0; q < NSRCH / NT; q++) if ((R == 4 ? ch * 8 + 2 * q + kh : ch * CPC + q) >= K) tieMask &= ~(((1u << NT) - 1u) << (q * NT));
     }
     if constexpr (!(DBG & 4)) myMasks[(size_t) ch * 64] = tieMask;
     tieMask = 0u;
     // ---- the strip is complete (32 codebooks staged, or the last chunk): 128-byte runs of scores, 32-byte runs of argmins
-    if (!(DBG & 2) && (c4 == 3 || ch + 1 == nChunks)) {
+    if (!(DBG & 2) && (c4 == SPC - 1 || ch + 1 == nChunks)) {
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
-      const int kF = st * 8; const int cnt = K - kF < (ch - st + 1) * 8 ? K - kF : (ch - st + 1) * 8;
+      const int kF = st * CPS; const int cnt = K - kF < (ch - st + 1) * CPS ? K - kF : (ch - st + 1) * CPS;
       const unsigned o = (unsigned) (kF + col + kh * K);
       const unsigned sOff = col < cnt ? o * 4u : INV, aOff = col < cnt ? o : INV;      // (the whole offset in the VGPR: the range check does not see an SGPR offset)
       if ((K & 3) == 0) {
@@ -216,7 +255,7 @@ __global__ __launch_bounds__(256, 1) void k_gmm_mfma_sp(const float* __restrict_
 // The flag words of one scoring workgroup (4 waves x nChunks x 64 lanes; bit k = q NT + t of lane (col, kh) in chunk ch: frame 32 t + col of the wave,
 // codebook 8 ch + 2 q + kh) become entries (frame << 32 | codebook) of the workgroup's segment of the tie list; what does not fit is settled here.
 template <int NT>
-__global__ __launch_bounds__(256) void k_gmm_tie_compact(const unsigned* __restrict__ masks, int nChunks, long N, int D, int Dp, int K,
+__global__ __launch_bounds__(256) void k_gmm_tie_compact(const unsigned* __restrict__ masks, int nChunks, long N, int D, int Dp, int K, int R,
                                                          const float* __restrict__ x, const float* __restrict__ mean, const float* __restrict__ ivar,
                                                          const float* __restrict__ cst, const float* __restrict__ val,
                                                          float* __restrict__ score, unsigned char* __restrict__ argmin,
@@ -234,13 +273,13 @@ __global__ __launch_bounds__(256) void k_gmm_tie_compact(const unsigned* __restr
     const int lane = w & 63, ch = (w >> 6) % nChunks, wave = (w >> 6) / nChunks, col = lane & 31, kh = lane >> 5;
     while (mk) {
       const int k = __ffs(mk) - 1; mk &= mk - 1u;
-      const int t = k % NT, q = k / NT; const int kcb = ch * 8 + 2 * q + kh;
+      const int t = k % NT, q = k / NT; const int kcb = R == 4 ? ch * 8 + 2 * q + kh : ch * (32 / R) + q;      // (R >= 8: codebook q of the chunk, flagged by the kh = 0 lane)
       const long nme = (long) blockIdx.x * (4 * 32 * NT) + wave * (32 * NT) + 32 * t + col;
       const unsigned slot = atomicAdd(&s_tie, 1u);
       if (slot < tieCap) myList[slot] = ((unsigned long long) nme << 32) | (unsigned long long) (unsigned) kcb;
       else {                                                     // list full: settle it here, in the reference's operation order
-        const int cb = kcb * 4;
-        const unsigned long long r = gmm_sp_settle(x + nme * D, mean + (size_t) cb * Dp, ivar + (size_t) cb * Dp, cst + cb, D, Dp);
+        const int cb = kcb * R;
+        const unsigned long long r = gmm_sp_settle(x + nme * D, mean + (size_t) cb * Dp, ivar + (size_t) cb * Dp, cst + cb, D, Dp, R);
         const unsigned ba = (unsigned) r;
         score[nme * K + kcb] = 0.5f * (__uint_as_float((unsigned) (r >> 32)) + 2.0f * val[cb + ba]);
         if (argmin) argmin[nme * K + kcb] = (unsigned char) ba;
@@ -259,33 +298,32 @@ int gmm_sp_frames() { return 4 * 32 * kSpNT; }
 
 size_t gmm_sp_lds(const GmmModel& m) { return sizeof(float) * ((size_t) ((m.G + 3) & ~3) + (size_t) 4 * 32 * kSpNT * 36) + (size_t) 4 * 32 * kSpNT * 36 + 16; }
 
+// the shapes there is an instantiation for: four Gaussians a codebook at every contraction depth, 8 / 16 / 32 at the depths of 13- and 39-dimensional features
+bool gmm_sp_has(int S4, int R) { return (R == 4 && (S4 == 4 || S4 == 5 || S4 == 9 || S4 == 10 || S4 == 12 || S4 == 17)) || ((R == 8 || R == 16 || R == 32) && (S4 == 4 || S4 == 10)); }
+
 // launches the scoring kernel (the caller runs k_gmm_ties over the list afterwards); false when the model's shape has no instantiation
-bool gmm_sp_launch(GmmModel& m, const float* x, long N, float* score, unsigned char* argmin, DevBuf<unsigned>& masks, unsigned long long* tieList, unsigned* tieCount, unsigned cap, hipStream_t st)
+bool gmm_sp_launch(GmmModel& m, int R, const float* x, long N, float* score, unsigned char* argmin, DevBuf<unsigned>& masks, unsigned long long* tieList, unsigned* tieCount, unsigned cap, hipStream_t st)
 {
   const int S4 = m.KP / 8; const size_t lds = gmm_sp_lds(m);
-  if (lds > 160 * 1024) return false;
+  if (lds > 160 * 1024 || !gmm_sp_has(S4, R)) return false;
   dim3 grid((unsigned) cdiv(N, (long) gmm_sp_frames()));
   const int stagger = getenv("DSR_GMM_STAGGER") ? atoi(getenv("DSR_GMM_STAGGER")) : 1;
   masks.reserve((size_t) grid.x * 4 * (size_t) m.GT * 64);       // one flag word per lane and chunk
-#define LS(SS) { DSR_HIP(hipFuncSetAttribute((const void*) k_gmm_mfma_sp<SS, kSpNT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds)); \
-  hipLaunchKernelGGL((k_gmm_mfma_sp<SS, kSpNT>), grid, dim3(256), lds, st, x, N, m.D, m.Dp, m.K, m.G, m.GT, m.d_bn.p, m.d_mean.p, m.d_ivar.p, m.d_cst.p, m.d_val.p, \
+#define LSD(SS, RR, DD) { DSR_HIP(hipFuncSetAttribute((const void*) k_gmm_mfma_sp<SS, kSpNT, RR, DD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds)); \
+  hipLaunchKernelGGL((k_gmm_mfma_sp<SS, kSpNT, RR, DD>), grid, dim3(256), lds, st, x, N, m.D, m.Dp, m.K, m.G, m.GT, m.d_bn.p, m.d_mean.p, m.d_ivar.p, m.d_cst.p, m.d_val.p, \
                      score, argmin, masks.p, 2.0f * m.ivMax, m.termMax, stagger); }
-  if (S4 == 10 && getenv("DSR_GMM_SPDBG")) {
-#define LD(DD) { DSR_HIP(hipFuncSetAttribute((const void*) k_gmm_mfma_sp<10, kSpNT, DD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds)); \
-  hipLaunchKernelGGL((k_gmm_mfma_sp<10, kSpNT, DD>), grid, dim3(256), lds, st, x, N, m.D, m.Dp, m.K, m.G, m.GT, m.d_bn.p, m.d_mean.p, m.d_ivar.p, m.d_cst.p, m.d_val.p, \
-                     score, argmin, masks.p, 2.0f * m.ivMax, m.termMax, stagger); }
-    if (atoi(getenv("DSR_GMM_SPDBG")) & 4) DSR_HIP(hipMemsetAsync(masks.p, 0, sizeof(unsigned) * (size_t) grid.x * 4 * (size_t) m.GT * 64, st));   // (no flag words written)
-    switch (atoi(getenv("DSR_GMM_SPDBG"))) { case 1: LD(1) break; case 2: LD(2) break; case 4: LD(4) break; case 6: LD(6) break; case 7: LD(7) break; default: LD(0) break; }
-#undef LD
-    DSR_HIP(hipGetLastError());
-    hipLaunchKernelGGL((k_gmm_tie_compact<kSpNT>), grid, dim3(256), 0, st, masks.p, m.GT, N, m.D, m.Dp, m.K, x, m.d_mean.p, m.d_ivar.p, m.d_cst.p, m.d_val.p, score, argmin, tieList, tieCount, cap);
-    DSR_HIP(hipGetLastError());
-    return true;
-  }
-  switch (S4) { case 4: LS(4) break; case 5: LS(5) break; case 9: LS(9) break; case 10: LS(10) break; case 12: LS(12) break; case 17: LS(17) break; default: return false; }
-#undef LS
+  const int dbg = (S4 == 10 && R == 4 && getenv("DSR_GMM_SPDBG")) ? atoi(getenv("DSR_GMM_SPDBG")) : 0;
+  if (dbg) {
+    if (dbg & 4) DSR_HIP(hipMemsetAsync(masks.p, 0, sizeof(unsigned) * (size_t) grid.x * 4 * (size_t) m.GT * 64, st));   // (no flag words written)
+    switch (dbg) { case 1: LSD(10, 4, 1) break; case 2: LSD(10, 4, 2) break; case 4: LSD(10, 4, 4) break; case 6: LSD(10, 4, 6) break; case 7: LSD(10, 4, 7) break; default: LSD(10, 4, 0) break; }
+  } else if (R == 4) {
+    switch (S4) { case 4: LSD(4, 4, 0) break; case 5: LSD(5, 4, 0) break; case 9: LSD(9, 4, 0) break; case 10: LSD(10, 4, 0) break; case 12: LSD(12, 4, 0) break; default: LSD(17, 4, 0) break; }
+  } else if (R == 8) { if (S4 == 4) LSD(4, 8, 0) else LSD(10, 8, 0) }
+  else if (R == 16) { if (S4 == 4) LSD(4, 16, 0) else LSD(10, 16, 0) }
+  else { if (S4 == 4) LSD(4, 32, 0) else LSD(10, 32, 0) }
+#undef LSD
   DSR_HIP(hipGetLastError());
-  hipLaunchKernelGGL((k_gmm_tie_compact<kSpNT>), grid, dim3(256), 0, st, masks.p, m.GT, N, m.D, m.Dp, m.K, x, m.d_mean.p, m.d_ivar.p, m.d_cst.p, m.d_val.p, score, argmin, tieList, tieCount, cap);
+  hipLaunchKernelGGL((k_gmm_tie_compact<kSpNT>), grid, dim3(256), 0, st, masks.p, m.GT, N, m.D, m.Dp, m.K, R, x, m.d_mean.p, m.d_ivar.p, m.d_cst.p, m.d_val.p, score, argmin, tieList, tieCount, cap);
   DSR_HIP(hipGetLastError());
   return true;
 }

@@ -691,15 +691,16 @@ def test_gmm_mfma_mode(dsr, oracle, cuda, K, R, D):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("K,D,N,tiecap", [(7, 39, 1000, None), (9, 13, 129, None), (17, 39, 700, None), (100, 20, 513, None), (41, 39, 2000, 3), (1024, 39, 640, 16), (16, 5, 1, None)])
-def test_gmm_mfma_four_gaussian_codebooks(dsr, oracle, cuda, monkeypatch, K, D, N, tiecap):
-    """Codebooks of four Gaussians go through the software-pipelined shape (k_gmm_sp.hip): a last chunk of fewer than eight codebooks, an odd chunk
+@pytest.mark.parametrize("K,D,N,tiecap,R", [(7, 39, 1000, None, 4), (9, 13, 129, None, 4), (17, 39, 700, None, 4), (100, 20, 513, None, 4), (41, 39, 2000, 3, 4), (1024, 39, 640, 16, 4), (16, 5, 1, None, 4),
+                                            (7, 39, 1000, None, 8), (33, 13, 515, 2, 8), (5, 39, 700, None, 16), (67, 13, 129, None, 16), (130, 39, 300, 5, 16), (3, 39, 1000, None, 32), (37, 13, 640, 4, 32)])
+def test_gmm_mfma_four_gaussian_codebooks(dsr, oracle, cuda, monkeypatch, K, D, N, tiecap, R):
+    """Codebooks of four (and, at the depths of 13- and 39-dimensional features, 8 / 16 / 32) Gaussians go through the one-wave-per-SIMD shape (k_gmm_sp.hip): a last chunk that the codebooks do not fill, an odd chunk
     count (a phantom chunk closes the pair), frame counts that end inside a tile / a wave / a workgroup, a strip of fewer than 32 codebooks, every
     contraction depth the kernel is instantiated for -- and a tie list that fills up (entries settled in place).  Argmin = the reference's on every
     frame, scores within the stated tolerance; the other shape (DSR_GMM_SP=0: two waves per SIMD) gives the same argmins and scores within the same
     tolerance (an entry on the edge of the trust radius may be re-scored exactly by one shape and not by the other)."""
     import torch
-    m = synth.gmm_model(K, 4, D, seed=12 + K)
+    m = synth.gmm_model(K, R, D, seed=12 + K)
     rng = np.random.default_rng(K)
     x = rng.standard_normal((N, D)).astype(np.float32)
     gm = dsr.Gmm(**m)
