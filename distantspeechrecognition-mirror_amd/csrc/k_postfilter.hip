@@ -23,7 +23,7 @@ namespace dsr {
 // densities likewise with E(t) = sum_i |a_i|^2.  P and E of different frames are independent:
 //   k_zel_pairs   one thread per (frame, bin), all frames in parallel: reads every snapshot once, fully coalesced ([frame][bin] is contiguous per
 //                 channel), the time-alignment vector from its transposed copy [channel][bin] (the waves of a CU walk the channels together: L1);
-//   k_zel_recur   one thread per (stream, bin) walks the frames: the two scalar recursions, the weight, the filtered output.
+//   k_zel_recur   the two scalar recursions, the weight, the filtered output: sixteen threads per (stream, bin), a stretch of the frames each (see the kernel).
 // fp64 throughout, as the reference; the sums are the reference's numbers up to the rounding of a different summation order (1e-13 relative:
 // tests compare at 1e-6).  The carried state of a stream (block streaming) is S and the auto sum: three doubles per bin instead of C (C + 1) / 2
 // complex densities.  At 64 channels x 32 streams x 1250 frames: 24.0 -> 1.6 ms (the wave-per-bin kernel that kept all 2016 densities was bound
@@ -55,41 +55,80 @@ __global__ __launch_bounds__(256) void k_zel_pairs(const float2* __restrict__ X,
   Pb[(long) u * TF + idx] = make_double2(Pr, Pi); Eb[(long) u * TF + idx] = E;
 }
 
-__global__ __launch_bounds__(64) void k_zel_recur(const double2* __restrict__ Pb, const double* __restrict__ Eb, const float2* __restrict__ Y,
-                                                  const int* __restrict__ nframesArr, double2* __restrict__ state, float2* __restrict__ out,
-                                                  float* __restrict__ wp1, int U, int C, int Tmax, int F, double alphaCfg, int type, int minFrames,
-                                                  const int* __restrict__ seenIn, int* __restrict__ seenOut, int carryIn, int carryOut)
+// One workgroup = 64 (stream, bin) series x 16 stretches of the time axis (a wave per stretch; lanes = neighbouring bins: every load is one contiguous run).
+// A step of either recursion is an affine map s -> a s + b (a = alpha, or 0 where the reference restarts it), maps compose, so a stretch is first reduced to its
+// own map from the sums alone (no weight, no output), the sixteen maps are chained through LDS, and every stretch then runs again from the state it really starts
+// in -- hypot, division, clamps and the output, the expensive part, sixteen stretches at once.  (One thread a series, 4128 threads walking 1250 frames: 0.9 ms, then
+// 0.5 ms with sixteen frames' loads in flight; this way the series of a stream are 66 k threads.)  The states differ from the frame-by-frame walk by the rounding
+// of a different association (1e-16 relative).
+__global__ __launch_bounds__(1024) void k_zel_recur(const double2* __restrict__ Pb, const double* __restrict__ Eb, const float2* __restrict__ Y,
+                                                    const int* __restrict__ nframesArr, double2* __restrict__ state, float2* __restrict__ out,
+                                                    float* __restrict__ wp1, int U, int C, int Tmax, int F, double alphaCfg, int type, int minFrames,
+                                                    const int* __restrict__ seenIn, int* __restrict__ seenOut, int carryIn, int carryOut)
 {
-  const long n = (long) blockIdx.x * 64 + threadIdx.x;
+  constexpr int NST = 16;                                        // stretches = waves of the workgroup
+  __shared__ double s_a[NST][64], s_br[NST][64], s_bi[NST][64], s_bd[NST][64];
+  const int lane = threadIdx.x & 63, k = threadIdx.x >> 6;
+  const long n = (long) blockIdx.x * 64 + lane;
   const long S = (long) U * F;
-  if (n >= S) return;
-  const int u = (int) (n / F), f = (int) (n - (long) u * F);
+  const bool live = n < S;
+  const int u = live ? (int) (n / F) : 0, f = live ? (int) (n - (long) u * F) : 0;
   const int T = nframesArr[u] < Tmax ? nframesArr[u] : Tmax;
   const int seen = seenIn ? seenIn[u] : 0;
-  if (seenOut && f == 0) seenOut[u] = seen + T;
-  double Sr = 0.0, Si = 0.0, D = 0.0;
-  if (carryIn) { const double2 s0 = state[n]; Sr = s0.x; Si = s0.y; D = state[S + n].x; }
+  if (seenOut && live && f == 0 && k == 0) seenOut[u] = seen + T;
+  const int L = (Tmax + NST - 1) / NST, t0 = k * L, t1 = (t0 + L < Tmax) ? t0 + L : Tmax;
   const long base = (long) u * Tmax * F + f;
-  const double scale = 2.0 / ((double) C - 1.0);
-#pragma unroll 4
-  for (int t = 0; t < Tmax; t++) {
-    const long o = base + (long) t * F;
-    if (t >= T) { out[o] = make_float2(0.f, 0.f); if (wp1) wp1[o] = 0.f; continue; }
-    const double2 P = Pb[o]; const double E = Eb[o]; const float2 y = Y[o];
-    const int frameX = seen + t - 1;                                      // _frameX before _increment() (postfilter.cc:463-466)
-    const double alpha = (frameX > 0) ? alphaCfg : 0.0;
-    if (alpha > 0.0) { Sr = Sr * alpha + P.x * (1.0 - alpha); Si = Si * alpha + P.y * (1.0 - alpha); D = alpha * D + (1.0 - alpha) * E; }
-    else { Sr = P.x; Si = P.y; D = E; }
-    const int pfType = (frameX < minFrames) ? 0 : type;
-    double numerator;
-    if (1 & pfType) { numerator = Sr; if (numerator < 0.0) numerator = 0.0; } else numerator = hypot(Sr, Si);
-    double W = (numerator / D) * scale;
-    if (W >= 1.0) W = 1.0;
-    if (W < 0.0001) W = 0.0001;
-    if (wp1) wp1[o] = (float) W;
-    out[o] = (pfType == 0) ? y : make_float2((float) (W * (double) y.x), (float) (W * (double) y.y));
+  // ---- the stretch as a map: (a, b) with b = (Sr, Si, D) reached from zero
+  double a = 1.0, br = 0.0, bi = 0.0, bd = 0.0;
+  if (live) {
+    constexpr int PF = 8;
+    for (int tb = t0; tb < t1 && tb < T; tb += PF) {
+      double2 Pv[PF]; double Ev[PF];
+#pragma unroll
+      for (int i = 0; i < PF; i++) { const int t = tb + i < T ? tb + i : T - 1; const long o = base + (long) t * F; Pv[i] = Pb[o]; Ev[i] = Eb[o]; }
+#pragma unroll
+      for (int i = 0; i < PF; i++) {
+        const int t = tb + i; if (t >= t1 || t >= T) break;
+        const double alpha = (seen + t - 1 > 0) ? alphaCfg : 0.0;
+        if (alpha > 0.0) { br = br * alpha + Pv[i].x * (1.0 - alpha); bi = bi * alpha + Pv[i].y * (1.0 - alpha); bd = alpha * bd + (1.0 - alpha) * Ev[i]; a *= alpha; }
+        else { br = Pv[i].x; bi = Pv[i].y; bd = Ev[i]; a = 0.0; }
+      }
+    }
   }
-  if (carryOut) { state[n] = make_double2(Sr, Si); state[S + n] = make_double2(D, 0.0); }
+  s_a[k][lane] = a; s_br[k][lane] = br; s_bi[k][lane] = bi; s_bd[k][lane] = bd;
+  __syncthreads();
+  // ---- the state this stretch starts in: the stream's carried state through the maps of the stretches before
+  double Sr = 0.0, Si = 0.0, D = 0.0;
+  if (live && carryIn) { const double2 s0 = state[n]; Sr = s0.x; Si = s0.y; D = state[S + n].x; }
+  for (int j = 0; j < k; j++) { const double aj = s_a[j][lane]; Sr = aj * Sr + s_br[j][lane]; Si = aj * Si + s_bi[j][lane]; D = aj * D + s_bd[j][lane]; }
+  if (!live) return;
+  const double scale = 2.0 / ((double) C - 1.0);
+  constexpr int PF = 8;
+  for (int tb = t0; tb < t1; tb += PF) {
+    double2 Pv[PF]; double Ev[PF]; float2 yv[PF];
+#pragma unroll
+    for (int i = 0; i < PF; i++) { const int t = tb + i < T ? tb + i : (T > 0 ? T - 1 : 0); const long o = base + (long) t * F; Pv[i] = Pb[o]; Ev[i] = Eb[o]; yv[i] = Y[o]; }
+#pragma unroll
+    for (int i = 0; i < PF; i++) {
+      const int t = tb + i; if (t >= t1) break;
+      const long o = base + (long) t * F;
+      if (t >= T) { out[o] = make_float2(0.f, 0.f); if (wp1) wp1[o] = 0.f; continue; }
+      const double2 P = Pv[i]; const double E = Ev[i]; const float2 y = yv[i];
+      const int frameX = seen + t - 1;                                    // _frameX before _increment() (postfilter.cc:463-466)
+      const double alpha = (frameX > 0) ? alphaCfg : 0.0;
+      if (alpha > 0.0) { Sr = Sr * alpha + P.x * (1.0 - alpha); Si = Si * alpha + P.y * (1.0 - alpha); D = alpha * D + (1.0 - alpha) * E; }
+      else { Sr = P.x; Si = P.y; D = E; }
+      const int pfType = (frameX < minFrames) ? 0 : type;
+      double numerator;
+      if (1 & pfType) { numerator = Sr; if (numerator < 0.0) numerator = 0.0; } else numerator = hypot(Sr, Si);
+      double W = (numerator / D) * scale;
+      if (W >= 1.0) W = 1.0;
+      if (W < 0.0001) W = 0.0001;
+      if (wp1) wp1[o] = (float) W;
+      out[o] = (pfType == 0) ? y : make_float2((float) (W * (double) y.x), (float) (W * (double) y.y));
+    }
+  }
+  if (carryOut && k == NST - 1) { state[n] = make_double2(Sr, Si); state[S + n] = make_double2(D, 0.0); }
 }
 
 // McCowanPostFilter (postfilter.cc:706-744,789-826,833-945): the same recursions, then the noise-coherence corrected estimate of the
@@ -571,7 +610,7 @@ dsr_status dsr_zelinski_apply(dsr_zelinski* p, const float* X, const float* Y, c
       ZelinskiPlan::PE& pe = p->pe.at(st); const size_t TF = (size_t) Tmax * F;
       pe.P.reserve((size_t) U * TF); pe.E.reserve((size_t) U * TF);
       hipLaunchKernelGGL(k_zel_pairs, dim3((unsigned) ((TF + 255) / 256), (unsigned) U), dim3(256), 0, st, (const float2*) X, nframes_dev, p->wqT.p, pe.P.p, pe.E.p, C, Tmax, F);
-      hipLaunchKernelGGL(k_zel_recur, dim3((unsigned) ((S + 63) / 64)), dim3(64), 0, st, pe.P.p, pe.E.p, (const float2*) Y, nframes_dev, p->state.p, (float2*) out, wp1,
+      hipLaunchKernelGGL(k_zel_recur, dim3((unsigned) ((S + 63) / 64)), dim3(1024), 0, st, pe.P.p, pe.E.p, (const float2*) Y, nframes_dev, p->state.p, (float2*) out, wp1,
                          U, C, Tmax, F, p->alpha, p->type, p->minFrames, PF_TAIL);
     } else if (wave) {
       const size_t ldsPf = p->kind ? sizeof(double2) * (size_t) C * (C - 1) / 2 : 0;
