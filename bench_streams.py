@@ -55,6 +55,7 @@ class Chain:
         self.sa = dsr.FilterBankState(self.ana, U, Cn); self.ss = dsr.FilterBankState(self.syn, U)
         self.pf = dsr.ZelinskiPostFilter(M, Cn, self.wq[:F], alpha=0.6, type=2, minFrames=0); self.pf.carry(True)
         self.lowerN, self.upperN, self.iters = lowerN, upperN, iters
+        self.fuse_pf = not os.environ.get("DSR_BENCH_NO_PF_FUSE")     # beamformer + post-filter as one pass over the snapshots (dsr_zelinski_apply_bf)
         self.gn = torch.zeros((U, F, upperN - lowerN + 1), dtype=torch.complex128, device=dev)
         self.ev = None
 
@@ -65,9 +66,13 @@ class Chain:
         if timed: ev[0].record()
         X = self.sa.analysis_block(x, last=last)
         if timed: ev[1].record()
-        Y = self.bf.apply(X)
-        if timed: ev[2].record()
-        Z = self.pf.apply(X, Y)
+        if self.fuse_pf:                                         # the post-filter behind its beamformer: one pass over the snapshots for both (setBeamformer)
+            if timed: ev[2].record()
+            Z = self.pf.apply_bf(self.bf, X)
+        else:
+            Y = self.bf.apply(X)
+            if timed: ev[2].record()
+            Z = self.pf.apply(X, Y)
         if timed: ev[3].record()
         V, self.gn = dsr.wpe_single(Z, self.M, self.lowerN, self.upperN, self.iters, -20.0, 0.0, 16000.0, gn=self.gn)
         if timed: ev[4].record()
@@ -154,6 +159,13 @@ def run(args, ROOT):
             roof["traffic"] = tj["kernels"][roof["kernel"]]["bytes_per_launch"]; roof["traffic_note"] = "PMC FETCH_SIZE + WRITE_SIZE (profiles/r03_config5_traffic.json)"
     except (OSError, ValueError, KeyError):
         pass
+    if ch.fuse_pf:
+        # the beamformer's sum is formed in the post-filter's pass over the snapshots: one stage, (C + 1) rows in (snapshots + nothing else), one row out -- SURVEY 8d's
+        # bytes of the two stages minus the row they no longer hand over through memory twice
+        alg["postfilter"] = U * T * (Cn + 1) * F * 8.0; names = ["analysis", "postfilter", "wpe", "synthesis"]; stage_ms = [stage_ms[0], stage_ms[2], stage_ms[3], stage_ms[4]]
+        dom = int(np.argmax(stage_ms)); dn = names[dom]
+        roof.update(kernel=dict(analysis="k_analysis_q256", postfilter="k_zel_pairs", wpe="k_wpe", synthesis="k_synthesis")[dn], achieved=alg[dn] / (stage_ms[dom] / 1000.0) / 1e9, launch_ms=stage_ms[dom])
+        roof["frac"] = roof["achieved"] / roof["peak"]
     stages = {nm: dict(ms=round(stage_ms[i], 3), bound="hbm", achieved=round(alg[nm] / (stage_ms[i] / 1000.0) / 1e9, 1), unit="GB/s",
                        frac_of_hbm_peak=round(alg[nm] / (stage_ms[i] / 1000.0) / 1e9 / HBM_PEAK_GBS, 3)) for i, nm in enumerate(names)}
     cpu = None
@@ -167,7 +179,7 @@ def run(args, ROOT):
     line = dict(metric="decoded_audio_hours_per_sec", value=audio_s / 3600.0 / (dt / args.steps), unit="audio_hours/s", n_gpus=world, steps=args.steps, warmup=args.warmup,
                 ms_per_step=1000.0 * dt / args.steps, higher_is_better=True, scaling="weak", vs_baseline=None, dtype="f32", data="synthetic",
                 config=dict(workload="BASELINE configs[4]: %d streams/GPU x %d blocks of %.2f s x 64 ch (8 x 8 planar, 20 mm), carried state: analysis M=256 m=4 r=1 -> MVDR "
-                                     "(diffuse model, mu 0.01) -> Zelinski post-filter (alpha 0.6) -> single-channel WPE (taps %d..%d, %d iterations) -> synthesis; "
+                                     "(diffuse model, mu 0.01) -> Zelinski post-filter (alpha 0.6; behind its beamformer: one pass over the snapshots for both) -> single-channel WPE (taps %d..%d, %d iterations) -> synthesis; "
                                      "no decode in this configuration" % (U, args.steps, nsamp / 16000.0, ch.lowerN, ch.upperN, ch.iters),
                             streams_per_gpu=U, stream_minutes=args.steps * nsamp / 16000.0 / 60.0, frames_per_block=int(T), xRT=audio_s / (dt / args.steps),
                             output_finite=finite, parallelism="stream-sharded x%d, no exchange" % world),

@@ -30,8 +30,13 @@ namespace dsr {
 // by its fp64 pair updates, 1.4 % of HBM); the kernel is now bound by reading the snapshots.
 // Carried state (block streaming, dsr_zelinski_carry): seenIn[u] = frames of stream u the earlier calls have filtered (the recursions start from
 // scratch only on the stream's own first two frames), seenOut[u] = that plus this call's; the sums are read from / left in `state`.
+// BF: the same pass also forms the beamformer's output Y = sum_c conj(w_c) x_c (SubbandDS / MVDR::next, beamformer.cc:1159-1175; the operation and its order are
+// k_bf_apply's) from the channel-major weight image of the beamformer the post-filter sits behind (ZelinskiPostFilter::setBeamformer, postfilter.cc:376) -- beamformer
+// and post-filter read the snapshots once instead of twice (64 channels x 32 streams x 1250 frames: 2.7 GB, 0.65 ms at the rate either pass reaches).
+template <bool BF>
 __global__ __launch_bounds__(256) void k_zel_pairs(const float2* __restrict__ X, const int* __restrict__ nframesArr, const double2* __restrict__ wqT,
-                                                   double2* __restrict__ Pb, double* __restrict__ Eb, int C, int Tmax, int F)
+                                                   double2* __restrict__ Pb, double* __restrict__ Eb, int C, int Tmax, int F,
+                                                   const float2* __restrict__ wT, int wPitch, float2* __restrict__ Yout)
 {
   const long TF = (long) Tmax * F;
   const long idx = (long) blockIdx.x * 256 + threadIdx.x;
@@ -39,13 +44,14 @@ __global__ __launch_bounds__(256) void k_zel_pairs(const float2* __restrict__ X,
   if (idx >= TF) return;
   const int t = (int) (idx / F), f = (int) (idx - (long) t * F);
   const int T = nframesArr[u] < Tmax ? nframesArr[u] : Tmax;
-  if (t >= T) return;
+  if (t >= T) { if (BF) Yout[(long) u * TF + idx] = make_float2(0.f, 0.f); return; }      // (the padded rows of the snapshots are zero, so is the beamformer's output there)
   const float2* Xp = X + (long) u * C * TF + idx;
   const double2* dp = wqT + f;
-  double Ar = 0.0, Ai = 0.0, Pr = 0.0, Pi = 0.0, E = 0.0;
+  double Ar = 0.0, Ai = 0.0, Pr = 0.0, Pi = 0.0, E = 0.0; float2 acc = make_float2(0.f, 0.f);
 #pragma unroll 4
   for (int c = 0; c < C; c++) {
     const float2 x = Xp[(long) c * TF]; const double2 d = dp[(long) c * F];
+    if (BF) { const float2 wc = wT[(long) c * wPitch + f]; acc.x += wc.x * x.x + wc.y * x.y; acc.y += wc.x * x.y - wc.y * x.x; }       // conj(w) x
     const double dr = d.x, di = -d.y, xr = (double) x.x, xi = (double) x.y;
     const double ar = dr * xr - di * xi, ai = dr * xi + di * xr;          // TimeAlignment: conj(d_c) x_c (postfilter.cc:30-43)
     Pr += Ar * ar + Ai * ai; Pi += Ai * ar - Ar * ai;                     // (sum of the channels before) conj(a_c)
@@ -53,6 +59,7 @@ __global__ __launch_bounds__(256) void k_zel_pairs(const float2* __restrict__ X,
     Ar += ar; Ai += ai;
   }
   Pb[(long) u * TF + idx] = make_double2(Pr, Pi); Eb[(long) u * TF + idx] = E;
+  if (BF) Yout[(long) u * TF + idx] = acc;
 }
 
 // One workgroup = 64 (stream, bin) series x 16 stretches of the time axis (a wave per stretch; lanes = neighbouring bins: every load is one contiguous run).
@@ -444,7 +451,7 @@ __global__ __launch_bounds__(64) void k_pf_wave(const float2* __restrict__ X, co
 struct ZelinskiPlan { int M = 0, C = 0, type = 2, minFrames = 0; double alpha = 0.6; std::vector<double> h_wq; bool dirty = true; DevBuf<double2> wq, state;
                       int kind = 0; double threshold = 0.99; std::vector<double> h_R; bool haveR = false, dirtyR = true; DevBuf<double2> R;       // kind 1: McCowan
                       double minSV = 1e-8; int fbinX1 = 0; bool dirtyL = true; DevBuf<double2> lambda;                                                 // kind 2: Lefkimmiatis
-                      DevBuf<double2> wqT; struct PE { DevBuf<double2> P; DevBuf<double> E; }; PerStream<PE> pe;                                          // Zelinski: [chan][bin] manifold, P / E of a call (one set per stream)
+                      DevBuf<double2> wqT; struct PE { DevBuf<double2> P; DevBuf<double> E; DevBuf<float2> Y; }; PerStream<PE> pe;                                          // Zelinski: [chan][bin] manifold, P / E of a call (one set per stream)
                       DevBuf<unsigned short> pairIJ;                                                                                                      // wave kernel: pair e -> i | j << 8
                       bool carry = false, haveState = false; int stateU = 0; DevBuf<int> seen[2]; int seenCur = 0; };                                      // carried state (block streaming)
 
@@ -565,10 +572,12 @@ dsr_status dsr_zelinski_set_manifold(dsr_zelinski* p, int fbinX, const double* v
     memcpy(&p->h_wq[(size_t) fbinX * p->C * 2], vec, sizeof(double) * 2 * p->C); p->dirty = true;
   });
 }
-dsr_status dsr_zelinski_apply(dsr_zelinski* p, const float* X, const float* Y, const int32_t* nframes_dev, int U, int Tmax, float* out, float* wp1, void* stream)
+namespace dsr { const float2* bf_fixed_weights_dev(dsr_bf* s); }
+// bfW: null -- Y is the beamformer's output; else the channel-major weights of the beamformer (pitch F + 1): the Zelinski streaming pass forms Y itself (into Yscr, or the
+// caller's array when it wants the beamformer's output too)
+static void zelinski_apply_impl(dsr_zelinski* p, const float* X, const float* Y, const float2* bfW, float* Ykeep, const int32_t* nframes_dev, int U, int Tmax, float* out, float* wp1, void* stream)
 {
-  return guard([&] {
-    if (!p || !X || !Y || !nframes_dev || !out) throw Error(DSR_E_PARAMETER, "null argument");
+  {
     if (U <= 0 || Tmax <= 0) return;
     hipStream_t st = (hipStream_t) stream;
     const int F = p->M / 2 + 1, C = p->C;
@@ -609,7 +618,12 @@ dsr_status dsr_zelinski_apply(dsr_zelinski* p, const float* X, const float* Y, c
       if (!p->carry) p->state.reserve(16);
       ZelinskiPlan::PE& pe = p->pe.at(st); const size_t TF = (size_t) Tmax * F;
       pe.P.reserve((size_t) U * TF); pe.E.reserve((size_t) U * TF);
-      hipLaunchKernelGGL(k_zel_pairs, dim3((unsigned) ((TF + 255) / 256), (unsigned) U), dim3(256), 0, st, (const float2*) X, nframes_dev, p->wqT.p, pe.P.p, pe.E.p, C, Tmax, F);
+      if (bfW) {
+        float2* Yw = (float2*) Ykeep; if (!Yw) { pe.Y.reserve((size_t) U * TF); Yw = pe.Y.p; }
+        hipLaunchKernelGGL(k_zel_pairs<true>, dim3((unsigned) ((TF + 255) / 256), (unsigned) U), dim3(256), 0, st, (const float2*) X, nframes_dev, p->wqT.p, pe.P.p, pe.E.p, C, Tmax, F, bfW, F + 1, Yw);
+        Y = (const float*) Yw;
+      } else
+      hipLaunchKernelGGL(k_zel_pairs<false>, dim3((unsigned) ((TF + 255) / 256), (unsigned) U), dim3(256), 0, st, (const float2*) X, nframes_dev, p->wqT.p, pe.P.p, pe.E.p, C, Tmax, F, (const float2*) nullptr, 0, (float2*) nullptr);
       hipLaunchKernelGGL(k_zel_recur, dim3((unsigned) ((S + 63) / 64)), dim3(1024), 0, st, pe.P.p, pe.E.p, (const float2*) Y, nframes_dev, p->state.p, (float2*) out, wp1,
                          U, C, Tmax, F, p->alpha, p->type, p->minFrames, PF_TAIL);
     } else if (wave) {
@@ -636,6 +650,31 @@ dsr_status dsr_zelinski_apply(dsr_zelinski* p, const float* X, const float* Y, c
 #undef PF_TAIL
     DSR_HIP(hipGetLastError());
     if (p->carry) { p->haveState = true; p->stateU = U; p->seenCur ^= 1; }
+  }
+}
+dsr_status dsr_zelinski_apply(dsr_zelinski* p, const float* X, const float* Y, const int32_t* nframes_dev, int U, int Tmax, float* out, float* wp1, void* stream)
+{
+  return guard([&] {
+    if (!p || !X || !Y || !nframes_dev || !out) throw Error(DSR_E_PARAMETER, "null argument");
+    zelinski_apply_impl(p, X, Y, nullptr, nullptr, nframes_dev, U, Tmax, out, wp1, stream);
+  });
+}
+// The post-filter behind its beamformer (ZelinskiPostFilter::setBeamformer, postfilter.cc:376-384: the filter takes snapshots and array manifold from the beamformer
+// whose output it filters): out = postfilter(X, bf(X)).  Where the filter streams the snapshots anyway (Zelinski on arrays the register kernel is not instantiated
+// for) the beamformer's sum is formed in the same pass; elsewhere this is dsr_bf_apply_frames followed by dsr_zelinski_apply.  Y_dev (optional) receives bf(X).
+dsr_status dsr_zelinski_apply_bf(dsr_zelinski* p, dsr_bf* bf, const float* X, const int32_t* nframes_dev, int U, int Tmax, float* out, float* wp1, float* Y_dev, void* stream)
+{
+  return guard([&] {
+    if (!p || !bf || !X || !nframes_dev || !out) throw Error(DSR_E_PARAMETER, "null argument");
+    if (U <= 0 || Tmax <= 0) return;
+    const int F = p->M / 2 + 1, C = p->C;
+    const bool zsum = p->kind == 0 && (!(C == 2 || C == 3 || C == 4 || C == 6 || C == 8) || getenv("DSR_PF_SUM"));
+    const float2* w = (zsum && !getenv("DSR_PF_NOFUSE")) ? bf_fixed_weights_dev(bf) : nullptr;
+    if (w) { zelinski_apply_impl(p, X, nullptr, w, Y_dev, nframes_dev, U, Tmax, out, wp1, stream); return; }
+    float* Y = Y_dev;
+    if (!Y) { ZelinskiPlan::PE& pe = p->pe.at((hipStream_t) stream); pe.Y.reserve((size_t) U * Tmax * F); Y = (float*) pe.Y.p; }
+    { const dsr_status rc = dsr_bf_apply_frames(bf, X, nframes_dev, U, Tmax, Y, stream); if (rc != DSR_OK) throw Error(rc, "%s", dsr_last_error()); }
+    zelinski_apply_impl(p, X, Y, nullptr, nullptr, nframes_dev, U, Tmax, out, wp1, stream);
   });
 }
 // Carried densities (block streaming): carry = 1 makes every apply of the same U continue the recursions of the call before it (stream u of one call

@@ -1874,6 +1874,10 @@ dsr_status dsr_decoder_decode_collect(dsr_decoder* d, dsr_decode_result* res, in
       double tmin = 1e30, tmax = 0.0, tsum = 0.0;                   // busy time per slot: how even the slots' shares of the batch were
       for (int s2 = 0; s2 < slots; s2++) { double t = 0.0; for (int i = 0; i < 32; i++) if (i != 15) t += (double) hp[(size_t) s2 * 32 + i]; t /= 100.0; tsum += t; if (t < tmin) tmin = t; if (t > tmax) tmax = t; }
       fprintf(stderr, "[dsr viterbi prof] busy us per slot: mean %.0f min %.0f max %.0f\n", tsum / slots, tmin, tmax);
+      if (slots >= 64 && slots % 8 == 0) {                       // by XCD (workgroup i runs on XCD i mod 8): how even the eight queues of the time-sliced decode come out
+        double bx[8] = {0}; for (int s2 = 0; s2 < slots; s2++) { double t = 0.0; for (int i = 0; i < 32; i++) if (i != 15) t += (double) hp[(size_t) s2 * 32 + i]; bx[s2 & 7] += t / 100.0; }
+        fprintf(stderr, "[dsr viterbi prof] busy us per slot, by XCD:"); for (int q = 0; q < 8; q++) fprintf(stderr, " %.0f", bx[q] / (slots / 8)); fprintf(stderr, "\n");
+      }
     }
     if (d->dumpOn) {
       long cnt[2]; DSR_HIP(hipMemcpy(cnt, d->d_dumpCount.p, sizeof(cnt), hipMemcpyDeviceToHost));

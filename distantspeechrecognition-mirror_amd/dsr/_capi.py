@@ -494,6 +494,20 @@ class ZelinskiPostFilter:
         check(_lib.dsr_zelinski_apply(self.h, _dev(X.contiguous()), _dev(Y.contiguous()), _dev(nframes), U, T, _dev(out), _dev(w) if want_weights else None, cur_stream()))
         return (out, w) if want_weights else out
 
+    def apply_bf(self, bf, X, nframes=None, want_weights=False, want_bf_output=False):
+        """The post-filter behind its beamformer (setBeamformer, postfilter.cc:376): out = postfilter(X, bf(X)); the beamformer's sum is formed in the filter's own
+        pass over the snapshots where it streams them.  X: cuda complex64 [U][C][T][F] -> out [U][T][F] (+ the weights, + bf(X))"""
+        import torch
+        U, Cn, T, F = X.shape
+        if nframes is None:
+            nframes = torch.full((U,), T, dtype=torch.int32, device=X.device)
+        out = torch.zeros((U, T, F), dtype=torch.complex64, device=X.device)
+        w = torch.zeros((U, T, F), dtype=torch.float32, device=X.device) if want_weights else None
+        Y = torch.zeros((U, T, F), dtype=torch.complex64, device=X.device) if want_bf_output else None
+        check(_lib.dsr_zelinski_apply_bf(self.h, bf.h, _dev(X.contiguous()), _dev(nframes), U, T, _dev(out), _dev(w) if want_weights else None,
+                                         _dev(Y) if want_bf_output else None, cur_stream()))
+        r = (out,) + ((w,) if want_weights else ()) + ((Y,) if want_bf_output else ())
+        return r if len(r) > 1 else out
 
     def carry(self, on=True):
         """keep the spectral densities from call to call (block streaming)"""

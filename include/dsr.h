@@ -543,6 +543,12 @@ dsr_status dsr_mccowan_divide_nondiagonal(dsr_zelinski*, float myu);
 dsr_status dsr_lefkimmiatis_create(int fftLen, int chanN, double minSV, int fbinX1, double alpha, int type, int minFrames, float threshold, dsr_zelinski** out);
 dsr_status dsr_zelinski_apply(dsr_zelinski*, const float* X_dev, const float* Y_dev, const int32_t* nframes_dev, int U, int Tmax,
                               float* out_dev, float* wp1_dev, void* stream);
+/* The post-filter behind its beamformer: out = postfilter(X, bf(X)) -- ZelinskiPostFilter::setBeamformer (btk/postfilter/postfilter.h:100, postfilter.cc:376-384:
+ * the filter takes snapshots and array manifold from the beamformer whose output it filters).  Where the filter streams the snapshots anyway (Zelinski on arrays
+ * of other than 2/3/4/6/8 channels) the beamformer's sum is formed in the same pass over them; elsewhere the call is dsr_bf_apply_frames followed by
+ * dsr_zelinski_apply.  Y_dev (optional, [U][Tmax][fftLen/2+1] complex64) receives bf(X). */
+dsr_status dsr_zelinski_apply_bf(dsr_zelinski*, dsr_bf*, const float* X_dev, const int32_t* nframes_dev, int U, int Tmax,
+                                 float* out_dev, float* wp1_dev, float* Y_dev, void* stream);
 /* Carried densities for block-wise processing of long streams (BASELINE configs[4]).  The reference operator's auto/cross spectral densities
  * (postfilter.cc:428-497) live as long as the object: carry = 1 makes every apply of the same U continue the recursions where the previous call
  * stopped (stream u of one call = stream u of the next; the start-up alpha = 0 and minFrames count from a stream's own first frame);

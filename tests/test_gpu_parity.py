@@ -924,6 +924,43 @@ def test_zelinski_postfilter(dsr, oracle, cuda, Cn, ptype, alpha, minFrames):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("Cn", [13, 64, 8])
+def test_zelinski_postfilter_behind_its_beamformer(dsr, oracle, cuda, Cn):
+    """dsr_zelinski_apply_bf = postfilter(X, bf(X)) (ZelinskiPostFilter::setBeamformer, postfilter.cc:376-384).  Arrays the filter streams (13 and 64 channels) get the
+    beamformer's sum from the filter's own pass over the snapshots; 8 channels go through the two separate calls inside.  Ragged lengths, two blocks of a carried stream:
+    the beamformer's output is dsr_bf_apply's (2e-6 of its largest value: the same sum, with and without fused multiply-adds), the filtered output the two-call result
+    and the oracle's."""
+    import torch
+    rng = np.random.default_rng(40 + Cn)
+    U, T, M = 3, 50, 64
+    F = M // 2 + 1
+    mp = synth.linear_array(Cn)
+    delays = dsr.calcDelaysPolar2(np.float32(0.5), np.float32(np.pi / 2), mp)
+    bf = dsr.Beamformer(M, Cn); bf.calcArrayManifoldVectors(16000.0, delays); bf.select("ds")
+    wq = bf.get(0)[:F]
+    X = (rng.standard_normal((U, Cn, 2 * T, F)) + 1j * rng.standard_normal((U, Cn, 2 * T, F))).astype(np.complex64)
+    nfr = [T, T - 9, 1]
+    for u in range(U):
+        X[u, :, nfr[u]:T] = 0; X[u, :, T + nfr[u]:] = 0
+    Xd = torch.from_numpy(X).to(cuda); nd = torch.tensor(nfr, dtype=torch.int32, device=cuda)
+    pfa = dsr.ZelinskiPostFilter(M, Cn, wq, alpha=0.7, type=2, minFrames=1); pfa.carry(True)
+    pfb = dsr.ZelinskiPostFilter(M, Cn, wq, alpha=0.7, type=2, minFrames=1); pfb.carry(True)
+    for blk in range(2):
+        Xb = Xd[:, :, blk * T:(blk + 1) * T].contiguous()
+        got, w, Yf = pfa.apply_bf(bf, Xb, nd, want_weights=True, want_bf_output=True)
+        Y = bf.apply(Xb)
+        ref, wr = pfb.apply(Xb, Y, nd, want_weights=True)
+        assert float((Yf - Y).abs().max()) <= 2e-6 * float(Y.abs().max())
+        assert float((got - ref).abs().max()) <= 1e-5 * float(ref.abs().max()) and float((w - wr).abs().max()) <= 1e-5
+    u = 0                                                                    # the first block of the longest stream against the oracle
+    pfc = dsr.ZelinskiPostFilter(M, Cn, wq, alpha=0.7, type=2, minFrames=1)
+    got = pfc.apply_bf(bf, Xd[:, :, :T].contiguous(), nd).cpu().numpy()
+    Yo = np.einsum("fc,ctf->tf", np.conj(wq), X[u, :, :T].astype(np.complex128))
+    wo, _ = oracle.zelinski_postfilter(X[u, :, :T].astype(np.complex128), Yo, wq, 0.7, 2, 1)
+    assert np.abs(got[u] - wo).max() <= 2e-5 * np.abs(wo).max()
+
+
+@pytest.mark.gpu
 def test_zelinski_postfilter_stream(dsr, oracle, cuda, protos, headset):
     """ZelinskiPostFilterPtr behind the stream protocol: analysis banks -> SubbandDS -> post-filter (setBeamformer)."""
     from dsr.btk import feature as F, modulated as Mo, beamformer as B, postfilter as P
