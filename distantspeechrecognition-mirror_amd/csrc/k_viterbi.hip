@@ -76,7 +76,7 @@ struct DecDev {
   double beam, lmScale, lmPenalty, silPenalty; uint32_t silenceX; int noPen;
   // time slicing: frames per segment (0: off), segments per utterance, queues (8: one per XCD, 1: one for all), the pool of back-pointer records and how many of
   // them an utterance takes at a time (a barrier pair and a device atomic each time: 9 us)
-  int segFrames, segCount, segQueues; long poolCap, poolChunk; unsigned long long* poolNext; SegState* segState; int* segDone; TokA* saveA; TokB* saveB;
+  int segFrames, segCount, segQueues, segDrop; long poolCap, poolChunk;   /* segDrop (tests): bit x set = the workgroups on XCD x do not serve their own queue */ unsigned long long* poolNext; SegState* segState; int* segDone; TokA* saveA; TokB* saveB;
   int maxTok, maxCand; long arenaCap;
   // per-slot scratch (slot s at base + s*stride)
   TokA* tokA; TokB* tokB; TokA* ctok; Side* side; int fastOK; int* tokOff; int* tokCnt; int* owner; int* rank; int* chead; CandA* cA; CandB* cB; unsigned* first; unsigned* tags; Bp* arena;
@@ -266,7 +266,7 @@ __global__ __launch_bounds__(kThreads) void k_viterbi(const VitArgs argsInKernar
   if (PROF && threadIdx.x < 32) s_prof[threadIdx.x] = 0;
 #define TICK(ix) do { if (PROF && tid == 0) { const long long tn = (long long) wall_clock64(); s_prof[ix] += tn - s_tlast; s_tlast = tn; } } while (0)
   constexpr int nthr = kThreads, nw = kWaves;
-  __shared__ int s_u; __shared__ long long s_chunk;
+  __shared__ int s_u, s_seg, s_help; __shared__ long long s_chunk;
 
   const int tid = threadIdx.x;
   const int slot = blockIdx.x;
@@ -300,17 +300,36 @@ __global__ __launch_bounds__(kThreads) void k_viterbi(const VitArgs argsInKernar
   // (segQueues == 1: one queue, any workgroup may take any utterance up -- the hand-over then pays device-scope fences; small grids and the tests)
   const int nq = (EXTRA || ka->D.segFrames <= 0) ? 1 : ka->D.segQueues;
   const int xcd = nq == 8 ? (int) (__builtin_amdgcn_s_getreg((3 << 11) | 20) & 7u) : 0;
+  // help > 0: this workgroup's own queue is empty and it looks into queue (xcd + help) mod 8 for utterances NOBODY HAS STARTED.  With workgroups on every XCD
+  // there are none by then; this is the net under the one assumption the XCD-bound queues make (a queue whose XCD got no workgroup of the grid would otherwise
+  // never be served): such an utterance is decoded here in one go -- no hand-over, so no coherence question -- and marked so that its own queue passes it by.
+  // (the queue being served lives in LDS, the work item comes out of it as (utterance, segment): nothing of this rides in registers through the frame loop)
+  if (tid == 0) s_help = (nq == 8 && ((ka->D.segDrop >> xcd) & 1)) ? 1 : 0;
   for (;;) {
     __syncthreads();
-    if (tid == 0) s_u = atomicAdd(ka->D.queue + xcd, 1);
+    if (tid == 0) {
+      const int segS0 = EXTRA ? 0 : ka->D.segFrames; int help = s_help, uu = -1, sg = 0;
+      for (;;) {
+        const int qx = (xcd + help) & (nq - 1), Uq = (ka->U - qx + nq - 1) / nq;     // (nq is 1 or 8); utterances of this queue: u = qx mod nq
+        int it = -1;
+        if (help == 0) { it = atomicAdd(ka->D.queue + qx, 1); if (it >= (segS0 > 0 ? ka->D.segCount * Uq : Uq)) it = -1; }
+        else {                                                                // first-segment items only, and only by compare-and-swap: a later item of that queue is not ours to take
+          int c = ld_i32(ka->D.queue + qx);
+          while (c < Uq) { const int prev = atomicCAS(ka->D.queue + qx, c, c + 1); if (prev == c) { it = c; break; } c = prev; }
+        }
+        if (it >= 0) { uu = segS0 > 0 ? qx + nq * (it % Uq) : it; sg = segS0 > 0 ? it / Uq : 0; break; }
+        if (segS0 > 0 && nq == 8 && help < 7) help++; else break;
+      }
+      if (uu >= 0 && help > 0) { st_i32(&ka->D.segState[uu].status, -2); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); st_i32(&ka->D.segDone[uu], 0x7FFFFFFF); sg = -1; }   // taken whole
+      s_help = help; s_u = uu; s_seg = sg;
+    }
     __syncthreads();
     RELOAD();
-    const int item = s_u, segS = EXTRA ? 0 : ka->D.segFrames;               // segS > 0: time slicing (never with the lattice / topN / dump modes)
-    const int Ux = (ka->U - xcd + nq - 1) / nq;                               // utterances of this queue: u = xcd mod nq
-    if (item >= (segS > 0 ? ka->D.segCount * Ux : Ux)) break;
-    const int u = segS > 0 ? xcd + nq * (item % Ux) : item, seg = segS > 0 ? item / Ux : 0;
+    const int segS = EXTRA ? 0 : ka->D.segFrames;                           // segS > 0: time slicing (never with the lattice / topN / dump modes)
+    const int u = s_u; if (u < 0) break;
+    const bool whole = s_seg < 0; const int seg = whole ? 0 : s_seg;        // whole: an utterance of another queue that nobody had started, decoded here in one go
     const int T = ka->nframesArr[u] < ka->Tmax ? ka->nframesArr[u] : ka->Tmax;
-    const int fr0 = seg * segS, frEnd = segS > 0 ? fr0 + segS : 0x7FFFFFFF;   // this item: frames fr0 .. frEnd-1 (the end expansion is "frame" T)
+    const int fr0 = seg * segS, frEnd = (segS > 0 && !whole) ? fr0 + segS : 0x7FFFFFFF;   // this item: frames fr0 .. frEnd-1 (the end expansion is "frame" T)
     if (fr0 > T) continue;                                                     // the utterance ended in an earlier segment
     if (EXTRA && ka->D.latOn && tid == 0) ka->D.latFrameOff[(size_t) u * (ka->Tmax + 3)] = 0;
     if (PROF && tid == 0) { const long long tn = (long long) wall_clock64(); if (s_prof[15]) s_prof[10] += tn - s_prof[15]; s_tlast = tn; }
@@ -1787,6 +1806,7 @@ dsr_status dsr_decoder_decode_launch(dsr_decoder* d, const float* score, const i
     D.tokA = d->d_tokA.p; D.tokB = d->d_tokB.p; D.ctok = d->d_ctok.p; D.side = d->d_side.p; D.fastOK = d->fastOK; D.tokOff = d->d_tokOff.p; D.owner = d->d_owner.p; D.rank = d->d_rank.p; D.cA = d->d_cA.p; D.cB = d->d_cB.p;
     D.first = d->d_first.p; D.tags = d->d_tags.p; D.tokCnt = d->d_tokCnt.p; D.chead = d->d_chead.p; D.arena = d->d_arena.p; D.queue = d->d_queue.p;
     if (getenv("DSR_VITERBI_SEG_VERBOSE")) fprintf(stderr, "[dsr viterbi] %d utterances on %d workgroups: %s\n", U, slots, segFrames > 0 ? (segQueues == 8 ? "time-sliced, XCD-bound queues" : "time-sliced, one queue") : "run to completion");
+    D.segDrop = getenv("DSR_VITERBI_SEG_DROP") ? (int) strtol(getenv("DSR_VITERBI_SEG_DROP"), nullptr, 0) : 0;
     D.segQueues = segQueues; D.segFrames = segFrames; D.segCount = segFrames > 0 ? (Tmax + segFrames) / segFrames : 1;            // segments cover frames 0 .. Tmax (the end expansion is "frame" T)
     D.poolCap = 0; D.poolChunk = 0; D.poolNext = nullptr; D.segState = nullptr; D.segDone = nullptr; D.saveA = nullptr; D.saveB = nullptr;
     if (segFrames > 0) {

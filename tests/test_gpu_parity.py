@@ -455,7 +455,8 @@ def test_viterbi_long_epsilon_paths(dsr, oracle, cuda):
         assert (out[0]["registerFrames"] > 0) == (env is None)
 
 
-@pytest.mark.parametrize("seg,streams,path,U", [(7, 3, "register", 29), (5, 8, "register", 29), (16, 9, "register", 29), (7, 3, "memory", 29), (6, 256, "register", 700), (9, 64, "register", 150)])
+@pytest.mark.parametrize("seg,streams,path,U", [(7, 3, "register", 29), (5, 8, "register", 29), (16, 9, "register", 29), (7, 3, "memory", 29), (6, 256, "register", 700), (9, 64, "register", 150),
+                                                 (6, 256, "drop", 700)])
 def test_viterbi_time_sliced(dsr, oracle, cuda, monkeypatch, seg, streams, path, U):
     """More utterances than workgroups: the decode is time-sliced (DSR_VITERBI_SEG frames a segment; an utterance is put down after its segment -- token list and
     scalars in memory, back-pointer records in the batch's pool -- and taken up by whichever workgroup comes next: of its XCD (grids of 8 k >= 64 workgroups, the
@@ -473,6 +474,8 @@ def test_viterbi_time_sliced(dsr, oracle, cuda, monkeypatch, seg, streams, path,
     nfr[0] = T; nfr[3] = 1; nfr[5] = 0; nfr[9] = seg; nfr[10] = seg + 1; nfr[11] = 2 * seg - 1
     if path == "memory":
         monkeypatch.setenv("DSR_VITERBI_NOFAST", "1")
+    if path == "drop":                                      # the workgroups of XCDs 2 and 5 do not serve their queues: the others pick those utterances up whole (the net under the XCD-bound queues)
+        monkeypatch.setenv("DSR_VITERBI_SEG_DROP", "0x24")
 
     def run(segv, **dkw):
         monkeypatch.setenv("DSR_VITERBI_SEG", str(segv))
