@@ -338,8 +338,8 @@ def main():
         sync(); ts = time.time(); submit(0); serial_ms = finish(0)[2]; sync(); serial_step_ms = 1000.0 * (time.time() - ts)
     # ---- configs[3] as literally stated ("1k-utterance batch sharded over N GPUs"): a second timed region of the same run.  Every rank decodes the
     # utterances u = rank mod world of a 1000-utterance batch; at world = 1 that is the region above.  speedup = the weak region's step (one GPU,
-    # 1000 utterances) over this one.  The decode runs one utterance per workgroup per CU: a shard takes ceil(shard / 256) rounds, so 125
-    # utterances (8 GPUs) cost as much as 250 (4 GPUs).
+    # 1000 utterances) over this one.  The decode runs one utterance per workgroup per CU (time-sliced when there are more utterances than workgroups):
+    # a shard costs max(1, shard / 256) utterance-durations, so 125 utterances (8 GPUs) cost as much as 250 (4 GPUs).
     strong2 = None
     if world > 1 and not strong and args.strong_total > 0:
         ids = shard_utterances(args.strong_total, world, rank); Us = min(len(ids), U)
@@ -351,7 +351,8 @@ def main():
             bad2 = sum(1 for res, _, _ in done2 for r in res if r.status != 0)
             strong2 = dict(total_utts=args.strong_total, utts_this_rank=Us, ms_per_step=1000.0 * dts / args.steps,
                            value=args.strong_total * args.secs / 3600.0 / (dts / args.steps), unit="audio_hours/s", failed_utts_rank0=bad2,
-                           decode_rounds=int(-(-Us // 256)), note="shard u -> rank u mod world; one utterance per workgroup per CU: ceil(shard/256) decode rounds")
+                           decode_rounds=round(max(1.0, Us / 256.0), 2), note="shard u -> rank u mod world; one workgroup per CU decodes an utterance: a shard of more than 256 utterances is time-sliced and "
+                                "costs shard/256 utterance-durations, a smaller one costs one")
             batch[0], batch[1], batch[2] = x, ns_dev, ns_host
     stage = np.zeros(6); placements = 0; active = 0; bad = 0; frames = 0
     for res, words, sms in done:
