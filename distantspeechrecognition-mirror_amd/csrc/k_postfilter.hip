@@ -33,33 +33,49 @@ namespace dsr {
 // BF: the same pass also forms the beamformer's output Y = sum_c conj(w_c) x_c (SubbandDS / MVDR::next, beamformer.cc:1159-1175; the operation and its order are
 // k_bf_apply's) from the channel-major weight image of the beamformer the post-filter sits behind (ZelinskiPostFilter::setBeamformer, postfilter.cc:376) -- beamformer
 // and post-filter read the snapshots once instead of twice (64 channels x 32 streams x 1250 frames: 2.7 GB, 0.65 ms at the rate either pass reaches).
+// (A thread takes TWO frames of a bin, t and t + ceil(Tmax / 2): the time-alignment vector and the beamformer's weight of a channel are fetched once for both.)
 template <bool BF>
 __global__ __launch_bounds__(256) void k_zel_pairs(const float2* __restrict__ X, const int* __restrict__ nframesArr, const double2* __restrict__ wqT,
                                                    double2* __restrict__ Pb, double* __restrict__ Eb, int C, int Tmax, int F,
                                                    const float2* __restrict__ wT, int wPitch, float2* __restrict__ Yout)
 {
   const long TF = (long) Tmax * F;
-  const long idx = (long) blockIdx.x * 256 + threadIdx.x;
+  const int H = (Tmax + 1) / 2;                                   // frames of the first half
+  const long idx = (long) blockIdx.x * 256 + threadIdx.x;         // (frame of the first half, bin)
   const int u = blockIdx.y;
-  if (idx >= TF) return;
+  if (idx >= (long) H * F) return;
   const int t = (int) (idx / F), f = (int) (idx - (long) t * F);
   const int T = nframesArr[u] < Tmax ? nframesArr[u] : Tmax;
-  if (t >= T) { if (BF) Yout[(long) u * TF + idx] = make_float2(0.f, 0.f); return; }      // (the padded rows of the snapshots are zero, so is the beamformer's output there)
+  const int t2 = t + H; const long idx2 = idx + (long) H * F;
+  const bool on1 = t < T, on2 = t2 < T, in2 = t2 < Tmax;
+  if (BF) { if (!on1) Yout[(long) u * TF + idx] = make_float2(0.f, 0.f); if (in2 && !on2) Yout[(long) u * TF + idx2] = make_float2(0.f, 0.f); }   // (the padded rows of the snapshots are zero, so is the beamformer's output there)
+  if (!on1) return;                                               // (t2 > t: nothing to do for the second frame either)
   const float2* Xp = X + (long) u * C * TF + idx;
+  const long o2 = on2 ? (long) H * F : 0;                         // (an idle second frame re-reads the first: its sums are dropped)
   const double2* dp = wqT + f;
   double Ar = 0.0, Ai = 0.0, Pr = 0.0, Pi = 0.0, E = 0.0; float2 acc = make_float2(0.f, 0.f);
+  double Br = 0.0, Bi = 0.0, Qr = 0.0, Qi = 0.0, G = 0.0; float2 acd = make_float2(0.f, 0.f);
 #pragma unroll 4
   for (int c = 0; c < C; c++) {
-    const float2 x = Xp[(long) c * TF]; const double2 d = dp[(long) c * F];
-    if (BF) { const float2 wc = wT[(long) c * wPitch + f]; acc.x += wc.x * x.x + wc.y * x.y; acc.y += wc.x * x.y - wc.y * x.x; }       // conj(w) x
-    const double dr = d.x, di = -d.y, xr = (double) x.x, xi = (double) x.y;
-    const double ar = dr * xr - di * xi, ai = dr * xi + di * xr;          // TimeAlignment: conj(d_c) x_c (postfilter.cc:30-43)
-    Pr += Ar * ar + Ai * ai; Pi += Ai * ar - Ar * ai;                     // (sum of the channels before) conj(a_c)
-    E += ar * ar + ai * ai;
-    Ar += ar; Ai += ai;
+    const float2 x = Xp[(long) c * TF], z = Xp[(long) c * TF + o2]; const double2 d = dp[(long) c * F];
+    if (BF) {
+      const float2 wc = wT[(long) c * wPitch + f];
+      acc.x += wc.x * x.x + wc.y * x.y; acc.y += wc.x * x.y - wc.y * x.x;           // conj(w) x
+      acd.x += wc.x * z.x + wc.y * z.y; acd.y += wc.x * z.y - wc.y * z.x;
+    }
+    const double dr = d.x, di = -d.y;
+    { const double xr = (double) x.x, xi = (double) x.y;
+      const double ar = dr * xr - di * xi, ai = dr * xi + di * xr;        // TimeAlignment: conj(d_c) x_c (postfilter.cc:30-43)
+      Pr += Ar * ar + Ai * ai; Pi += Ai * ar - Ar * ai;                   // (sum of the channels before) conj(a_c)
+      E += ar * ar + ai * ai; Ar += ar; Ai += ai; }
+    { const double xr = (double) z.x, xi = (double) z.y;
+      const double ar = dr * xr - di * xi, ai = dr * xi + di * xr;
+      Qr += Br * ar + Bi * ai; Qi += Bi * ar - Br * ai;
+      G += ar * ar + ai * ai; Br += ar; Bi += ai; }
   }
   Pb[(long) u * TF + idx] = make_double2(Pr, Pi); Eb[(long) u * TF + idx] = E;
   if (BF) Yout[(long) u * TF + idx] = acc;
+  if (on2) { Pb[(long) u * TF + idx2] = make_double2(Qr, Qi); Eb[(long) u * TF + idx2] = G; if (BF) Yout[(long) u * TF + idx2] = acd; }
 }
 
 // One workgroup = 64 (stream, bin) series x 16 stretches of the time axis (a wave per stretch; lanes = neighbouring bins: every load is one contiguous run).
@@ -620,10 +636,10 @@ static void zelinski_apply_impl(dsr_zelinski* p, const float* X, const float* Y,
       pe.P.reserve((size_t) U * TF); pe.E.reserve((size_t) U * TF);
       if (bfW) {
         float2* Yw = (float2*) Ykeep; if (!Yw) { pe.Y.reserve((size_t) U * TF); Yw = pe.Y.p; }
-        hipLaunchKernelGGL(k_zel_pairs<true>, dim3((unsigned) ((TF + 255) / 256), (unsigned) U), dim3(256), 0, st, (const float2*) X, nframes_dev, p->wqT.p, pe.P.p, pe.E.p, C, Tmax, F, bfW, F + 1, Yw);
+        hipLaunchKernelGGL(k_zel_pairs<true>, dim3((unsigned) (((size_t) ((Tmax + 1) / 2) * F + 255) / 256), (unsigned) U), dim3(256), 0, st, (const float2*) X, nframes_dev, p->wqT.p, pe.P.p, pe.E.p, C, Tmax, F, bfW, F + 1, Yw);
         Y = (const float*) Yw;
       } else
-      hipLaunchKernelGGL(k_zel_pairs<false>, dim3((unsigned) ((TF + 255) / 256), (unsigned) U), dim3(256), 0, st, (const float2*) X, nframes_dev, p->wqT.p, pe.P.p, pe.E.p, C, Tmax, F, (const float2*) nullptr, 0, (float2*) nullptr);
+      hipLaunchKernelGGL(k_zel_pairs<false>, dim3((unsigned) (((size_t) ((Tmax + 1) / 2) * F + 255) / 256), (unsigned) U), dim3(256), 0, st, (const float2*) X, nframes_dev, p->wqT.p, pe.P.p, pe.E.p, C, Tmax, F, (const float2*) nullptr, 0, (float2*) nullptr);
       hipLaunchKernelGGL(k_zel_recur, dim3((unsigned) ((S + 63) / 64)), dim3(1024), 0, st, pe.P.p, pe.E.p, (const float2*) Y, nframes_dev, p->state.p, (float2*) out, wp1,
                          U, C, Tmax, F, p->alpha, p->type, p->minFrames, PF_TAIL);
     } else if (wave) {
