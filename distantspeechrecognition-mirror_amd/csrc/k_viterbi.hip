@@ -1769,6 +1769,10 @@ dsr_status dsr_decoder_decode_launch(dsr_decoder* d, const float* score, const i
     if (!latOn && !d->dumpOn && d->cfg.topN <= 0 && U > slots) {
       segFrames = getenv("DSR_VITERBI_SEG") ? atoi(getenv("DSR_VITERBI_SEG")) : 125;
       if (segFrames < 0 || 2 * segFrames > Tmax + 1) segFrames = 0;
+      // between its segments an utterance's token list waits in a save area of maxActive tokens: with very large lists and very many utterances that is more memory
+      // than the scheduling is worth (DSR_VITERBI_SEG_SAVE_GB, default 16)
+      const double saveGB = (double) U * (double) d->cfg.maxActive * 24.0 / 1e9;
+      if (saveGB > (getenv("DSR_VITERBI_SEG_SAVE_GB") ? atof(getenv("DSR_VITERBI_SEG_SAVE_GB")) : 16.0)) segFrames = 0;
     }
     // XCD-bound queues (the cheap hand-over) need workgroups on every XCD: grids of 8 k >= 64 workgroups on a device that deals workgroups out round robin.
     // Anything else decodes every utterance in one go -- unless DSR_VITERBI_SEG_ANY asks for the one-queue form (device-scope fences at every hand-over: the tests).
