@@ -34,9 +34,9 @@ with open(os.path.join(dst, RD + "_pmc_summary.txt"), "w") as f:
         f.write("\n# k_viterbi per wave and frame: VALU %.0f  SALU %.0f  LDS %.0f;  wait-any %.0f %%  wait-for-issue %.0f %% of the wave cycles;  LDS bank conflicts %.0f %% of the LDS cycles\n"
                 % (v["SQ_INSTS_VALU"] / wf, v["SQ_INSTS_SALU"] / wf, v["SQ_INSTS_LDS"] / wf, 100 * v["SQ_WAIT_ANY"] / v["SQ_WAVE_CYCLES"],
                    100 * v["SQ_WAIT_INST_ANY"] / v["SQ_WAVE_CYCLES"], 100 * v["SQ_LDS_BANK_CONFLICT"] / v["SQ_LDS_IDX_ACTIVE"]))
-    for gk in ("k_gmm_mfma_sp<10, 4, 0>", "k_gmm_mfma_reg<10, 4>"):
+    for gk in [k for k in acc if k.startswith("k_gmm_mfma_sp") or k.startswith("k_gmm_mfma_reg")]:
         g = acc.get(gk)
-        if g:
+        if g and g.get("SQ_BUSY_CU_CYCLES"):
             f.write("# %s: MFMA busy %.0f %% of the SIMD cycles (SQ_VALU_MFMA_BUSY_CYCLES / 4 / SQ_BUSY_CU_CYCLES)\n" % (gk.split("<")[0], 100 * g["SQ_VALU_MFMA_BUSY_CYCLES"] / 4 / g["SQ_BUSY_CU_CYCLES"]))
 tj = {"config": "bench.py --serial --steps 1 --warmup 1 --no-cpu --beam 53.787 (1000 utt x 10 s x 8 ch per GPU); counters summed over the probe (4 utterances) and two full-batch launches; per-launch = sum / 2",
       "beam": 53.787,
