@@ -238,30 +238,47 @@ __global__ __launch_bounds__(256) void k_mfcc_frames_w(MfccDev P, int melCoefN, 
       continue;
     }
     double* zr = reinterpret_cast<double*>(bufA);
+    // The frame's samples come in ONCE, a coalesced run of 64 per load; the pre-emphasis' "sample before" is the neighbouring lane's (lane 0: the last lane of the
+    // run before; the frame's first sample: the last sample of the frame before, feature.cc's carried prior).  One load per sample instead of two, none of them
+    // behind a branch on the sample index (the framing + window stage was 1.6 of the kernel's 3.9 ms).
+    // (asking for the NEXT frame's samples before this frame is worked on was measured too: 3.63 against 3.53 ms -- eight more registers a lane, nothing hidden that
+    // the three waves of a SIMD did not hide already)
+    constexpr int NJ = FFTN / 64;
+    float smp[NJ]; float prior0 = 0.0f;
+#ifndef DSR_MFCC_NOWIN
 #pragma unroll
-    for (int i0 = 0; i0 < FFTN; i0 += 64) {
-      const int i = i0 + lane;
+    for (int jj = 0; jj < NJ; jj++) { const int i = 64 * jj + lane; const long n = cur + i; smp[jj] = (i < P.blockLen && n < nsamp) ? ys[n] : 0.0f; }
+    if (P.preOn && t > 0) { const long n1 = (long) (t - 1) * P.shiftLen + P.blockLen - 1; prior0 = (n1 < nsamp) ? ys[n1] : 0.0f; }
+#endif
+#pragma unroll
+    for (int jj = 0; jj < NJ; jj++) {
+      const int i = 64 * jj + lane;
       double v = 0.0;
+#ifndef DSR_MFCC_NOWIN                                                                      /* (measurement only: no samples read, no pre-emphasis, no window) */
+      float prior = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(smp[jj]), 0x138 /* wave_shr:1 */, 0xF, 0xF, false));    // lane - 1's sample, no LDS round trip
+      if (jj > 0) { const float last = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(smp[jj - 1]), 63)); if (lane == 0) prior = last; } else if (lane == 0) prior = prior0;
       if (i < P.blockLen) {
-        const long n = cur + i;
-        const float b = (n < nsamp) ? ys[n] : 0.0f;
+        const float b = smp[jj];
         float pre = b;
-        if (P.preOn) {
-          float prior;
-          if (i > 0) { const long n1 = n - 1; prior = (n1 < nsamp) ? ys[n1] : 0.0f; }
-          else if (t == 0) prior = 0.0f;
-          else { const long n1 = (long) (t - 1) * P.shiftLen + P.blockLen - 1; prior = (n1 < nsamp) ? ys[n1] : 0.0f; }
-          pre = (float) __dsub_rn((double) b, __dmul_rn(P.mu, (double) prior));
-        }
+        if (P.preOn) pre = (float) __dsub_rn((double) b, __dmul_rn(P.mu, (double) prior));
         const float hm = (float) __dmul_rn(hamL[i], (double) pre);
         v = (double) hm;
       }
+#endif
       zr[i] = v;
     }
     stage_sync<true>();
+#ifdef DSR_MFCC_NOFFT                                                                       /* (measurement only, tools/build_variants.sh: what the other stages cost) */
+    double2* Z = bufA;
+#else
     double2* Z = fft_lds_d<N, true>(bufA, bufB, twL, 2, -1, lane, 64);
+#endif
     double* pw = reinterpret_cast<double*>(Z == bufA ? bufB : bufA);
+#ifdef DSR_MFCC_NOPOW                                                                       /* (measurement only: no even/odd split, no power spectrum) */
+    for (int f = lane; f < 0; f += 64) {
+#else
     for (int f = lane; f < P.powN; f += 64) {
+#endif
       const int ff = (f <= N) ? f : (FFTN - f);
       const double2 zf = Z[ff & (N - 1)]; double2 zc = Z[(N - ff) & (N - 1)]; zc.y = -zc.y;
       const double2 E = make_double2(0.5 * (zf.x + zc.x), 0.5 * (zf.y + zc.y));
@@ -289,6 +306,11 @@ __global__ __launch_bounds__(256) void k_mfcc_frames_w(MfccDev P, int melCoefN, 
       stage_sync<true>();
     }
     float* lg = reinterpret_cast<float*>(vt == pw ? reinterpret_cast<double*>(Z) : pw);    // the buffer the mel bank does not read
+#ifdef DSR_MFCC_NOTAIL                                                                     /* (measurement only: no mel bank, no log, no DCT) */
+    for (int k = lane; k < P.ncep; k += 64) cep[((long) u * Tmax + t) * P.ncep + k] = (float) vt[k];
+    stage_sync<true>();
+    continue;
+#endif
     for (int j = lane; j < P.filterN; j += 64) {
       const int s0 = mIdxL[j], n = mIdxL[P.filterN + j], o = mIdxL[2 * P.filterN + j];
       double sum = 0.0; int i = 0;
@@ -740,7 +762,10 @@ dsr_status dsr_mfcc_run(dsr_mfcc* p, const float* y, const int32_t* nsamp, int U
 #define LAUNCH(FN) { DSR_HIP(hipFuncSetAttribute((const void*) k_mfcc_frames<FN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds)); \
     hipLaunchKernelGGL(k_mfcc_frames<FN>, grid, dim3(64 * FPB), lds, st, P, y, nsamp, (long) sampStride, Tmax, cepOut, powOut, lmOut); }
     // tables in LDS + wave-private frames when the lot fits beside three more workgroups on a CU; the plain kernel otherwise (and on request)
-    constexpr int FW = 8;
+#ifndef DSR_MFCC_FW
+#define DSR_MFCC_FW 8
+#endif
+    constexpr int FW = DSR_MFCC_FW;
     const size_t ldsW = (size_t) c.fftLen * sizeof(double2) * (1 + 4) + (size_t) c.blockLen * sizeof(double)
                         + ((size_t) p->melCoefN + (size_t) c.ncep * c.filterN + 3 * (size_t) c.filterN) * sizeof(float);
     static const bool plainOnly = getenv("DSR_MFCC_PLAIN") != nullptr;
